@@ -1,0 +1,175 @@
+/*
+ * mcpc.h -- C ABI of libmcpc.so: the MI355X-native Monte Carlo Predictive Coding engine.
+ *
+ * Drop-in boundary for ONE hot path of gaspardol/MonteCarloPredictiveCoding: the body of
+ * PCTrainer.train_on_batch's `for t in range(T)` loop
+ * (reference predictive_coding/pc_trainer.py:712-981) together with the Langevin callback
+ * random_step (reference utils/model.py:35-44), for networks of the shape built by
+ * get_model (reference utils/model.py:47-69) and by the toy scripts
+ * (reference figure_2.py:40-44, figure_3.py:50-55):
+ *
+ *     Sequential[ Linear, PCLayer, (act), Linear, PCLayer, (act), ..., Linear (, PCLayer) ]
+ *
+ * The reference has no FFI layer of its own (it is pure Python on torch); the entry points
+ * below are what a binding for this path has to call, each annotated with the reference
+ * lines it replaces.  Plain pointers and sizes only: no torch types.  All `float*`/`double*`
+ * arguments are DEVICE pointers (HIP, gfx950) unless stated otherwise; `stream` is a
+ * hipStream_t passed as void*.  Every function returns 0 on success or a negative MCPC_E*
+ * code; mcpc_last_error() returns a human-readable message for the calling thread.
+ *
+ * Threading: one engine per (device, stream); an engine is not re-entrant.  All launches are
+ * asynchronous on the given stream; nothing in this API synchronises the host except
+ * mcpc_create/mcpc_destroy (allocation).
+ */
+#ifndef MCPC_H
+#define MCPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCPC_ABI_VERSION 1
+#define MCPC_MAX_LATENT 6
+
+/* status codes */
+#define MCPC_OK 0
+#define MCPC_EINVAL (-1)       /* bad argument / unsupported configuration */
+#define MCPC_EHIP (-2)         /* a HIP runtime call failed */
+#define MCPC_ENOMEM (-3)       /* configuration does not fit the device (LDS / HBM) */
+#define MCPC_ESTATE (-4)       /* call order violated (e.g. run before bind) */
+
+/* activation applied to x_l before the next Linear (reference utils/model.py:49-52) */
+#define MCPC_ACT_IDENTITY 0
+#define MCPC_ACT_RELU 1
+#define MCPC_ACT_TANH 2
+
+/* output loss (reference utils/model.py:17-33); masked variants = mask_start > 0 */
+#define MCPC_LOSS_NONE 0       /* loss_fn=None or zero_fn */
+#define MCPC_LOSS_GAUSSIAN 1   /* fe_fn: (1/var)*0.5*(out-y)^2, summed */
+#define MCPC_LOSS_BERNOULLI 2  /* bernoulli_fn: BCEWithLogits, summed */
+
+/* optimizer on x (reference pc_trainer.py:465-475,871-877) */
+#define MCPC_XOPT_SGD 0        /* optim.SGD(lr), no momentum / weight decay */
+#define MCPC_XOPT_ADAM 1       /* optim.Adam(lr, betas, eps), state reset per run */
+
+/* noise source for the Langevin kick x += sqrt(noise_var*lr)*xi (reference utils/model.py:35-44) */
+#define MCPC_NOISE_NONE 0      /* PC / MAP inference */
+#define MCPC_NOISE_PHILOX 1    /* fused counter-based Philox4x32-10 + Box-Muller */
+#define MCPC_NOISE_EXTERNAL 2  /* xi read from ext_noise[l] (parity tests, arbitrary generators) */
+
+/* which steps write loss / layer energies (reference pc_trainer.py:776-797,835-836) */
+#define MCPC_ENERGY_NONE 0
+#define MCPC_ENERGY_LAST 1
+#define MCPC_ENERGY_ALL 2
+
+typedef struct mcpc_engine mcpc_engine;
+
+/* Static description of the network and the shard of chains this engine owns. */
+typedef struct mcpc_net_desc {
+    int32_t abi_version;                 /* MCPC_ABI_VERSION */
+    int32_t n_latent;                    /* number of PCLayers L, 1..MCPC_MAX_LATENT */
+    int32_t n_in;                        /* width of the pseudo-input fed to the first Linear */
+    int32_t sizes[MCPC_MAX_LATENT];      /* n_1..n_L, top latent first (reference utils/model.py:54-65) */
+    int32_t acts[MCPC_MAX_LATENT];       /* MCPC_ACT_* applied to x_l */
+    float ecoef[MCPC_MAX_LATENT];        /* c_l in energy c_l*0.5*(mu-x)^2 (reference pc_layer.py:17-18, figure_3.py:47-48) */
+    int32_t n_out;                       /* width of the read-out Linear; 0 = model ends with a PCLayer */
+    int32_t batch;                       /* chains held by this engine (local shard) */
+    int32_t device;                      /* HIP device ordinal */
+    int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default (2 GiB) */
+} mcpc_net_desc;
+
+/* One train_on_batch call (or a slice of it).  Steps are numbered 0..T-1 inside the call. */
+typedef struct mcpc_run_desc {
+    int32_t T;                   /* total steps of the reference call (PCTrainer T), for 'last' semantics */
+    int32_t t_begin;             /* first step executed by this run */
+    int32_t n_steps;             /* steps executed by this run (t_begin + n_steps <= T) */
+
+    int32_t loss_kind;           /* MCPC_LOSS_* */
+    float loss_var;              /* Gaussian variance (_var) */
+    int32_t mask_start;          /* first output column that contributes: n_out - round(n_out*perc); 0 = unmasked */
+
+    int32_t xopt_kind;           /* MCPC_XOPT_* */
+    float lr;
+    float beta1, beta2, eps;     /* Adam */
+    int32_t adam_step0;          /* Adam step count before this run (0 at the start of a call) */
+
+    int32_t update_x;            /* 1: fused x update (the fast path). 0: gradients only -> xgrad (generic callbacks) */
+
+    int32_t noise_mode;          /* MCPC_NOISE_* */
+    float noise_var;             /* random_step's `var` (2.0 = correct Langevin) */
+    uint64_t seed;               /* Philox key */
+    uint64_t step_base;          /* Philox step counter of step 0 of this call (advances across calls) */
+    uint64_t chain_base;         /* global id of this shard's first chain (sharding-invariant noise) */
+    const float* ext_noise[MCPC_MAX_LATENT]; /* MCPC_NOISE_EXTERNAL: [n_steps][batch][n_l] per layer */
+
+    int32_t acc_begin, acc_end;  /* accumulate parameter-gradient sums over steps [acc_begin, acc_end) of the call */
+    int32_t acc_reset;           /* 1: zero the sums when this run starts accumulating (reference pc_trainer.py:853-859) */
+
+    int32_t energy_mode;         /* MCPC_ENERGY_* */
+    double* energies_out;        /* [T or 1][MCPC_MAX_LATENT+2]: loss, E_1..E_L (unused = 0), overall; device pointer */
+
+    int32_t rec_begin, rec_stride, rec_count; /* record x_t / outputs at t = rec_begin + k*rec_stride, k < rec_count */
+    float* rec_x[MCPC_MAX_LATENT];            /* [rec_count][batch][n_l] or NULL (reference pc_trainer.py:440-445,772-774) */
+    float* rec_out;                           /* [rec_count][batch][n_out] or NULL (is_return_outputs, :769-770) */
+
+    float* xgrad[MCPC_MAX_LATENT];            /* update_x == 0: dF/dx_l -> [batch][n_l] */
+} mcpc_run_desc;
+
+/* lifetime -------------------------------------------------------------------------------- */
+int mcpc_abi_version(void);
+const char* mcpc_last_error(void);
+int mcpc_create(const mcpc_net_desc* desc, mcpc_engine** out);
+int mcpc_destroy(mcpc_engine* e);
+
+/* Parameters of Linear j (j = 0..L-1 predicts latent layer j+1; j = L is the read-out), torch
+ * nn.Linear layout W[out][in] row-major, bias[out] or NULL.  The engine keeps the pointers
+ * (borrowed storage) and re-packs them into MFMA fragment order at mcpc_params_changed().
+ * Replaces: nn.Linear.forward inside self._model(self.inputs), pc_trainer.py:733. */
+int mcpc_bind_params(mcpc_engine* e, int j, const float* W, const float* bias);
+/* Re-pack all bound parameters (call after binding and after every optimizer_p.step()). */
+int mcpc_params_changed(mcpc_engine* e, void* stream);
+
+/* Pseudo-input [batch][n_in] (NULL = zeros, the reference's usual call) and target [batch][n_out].
+ * Replaces: `inputs`, loss_fn_kwargs['_target'] of train_on_batch, pc_trainer.py:500-524. */
+int mcpc_bind_inputs(mcpc_engine* e, const float* inputs, void* stream);
+int mcpc_bind_target(mcpc_engine* e, const float* target, void* stream);
+
+/* Latent state x_l, [batch][n_l] row-major (PCLayer._x, pc_layer.py:230,300).  load copies the
+ * caller's tensors into the engine's padded state; store writes the current state back. */
+int mcpc_load_state(mcpc_engine* e, const float* const* x, void* stream);
+int mcpc_store_state(mcpc_engine* e, float* const* x, void* stream);
+
+/* The hot loop: n_steps iterations of pc_trainer.py:712-981 (+ random_step) on every chain. */
+int mcpc_run(mcpc_engine* e, const mcpc_run_desc* run, void* stream);
+
+/* Un-normalised parameter-gradient sums of Linear j accumulated by mcpc_run:
+ *   dW[out][in] = scale * sum_t dF/dW(x_t),  db[out] = scale * sum_t dF/db(x_t)   (db may be NULL)
+ * accumulate != 0 adds to the destination instead of overwriting (autograd's += into .grad).
+ * Replaces: overall.backward()'s parameter part + the normalisation of pc_trainer.py:905-913. */
+int mcpc_read_param_grads(mcpc_engine* e, int j, float* dW, float* db, float scale, int accumulate, void* stream);
+/* Same, all Linears concatenated (W0,b0,W1,b1,...; absent biases skipped) into one flat buffer,
+ * the bucket that is all-reduced once per call across shards. */
+int mcpc_read_param_grads_flat(mcpc_engine* e, float* flat, int64_t n_floats, float scale, void* stream);
+int64_t mcpc_param_count(const mcpc_engine* e);
+
+/* Fill out[batch][n_units] with the engine's Philox normals for (seed, step, layer): the device
+ * generator exposed for bit-exactness tests against oracle/philox.py. raw != 0 writes the u32 stream. */
+int mcpc_philox_normals(int device, uint64_t seed, uint64_t step, int layer, uint64_t chain_base,
+                        int batch, int n_units, float* out, int raw, void* stream);
+
+/* Introspection for benchmarks / DESIGN.md: bytes of LDS per workgroup, chains per workgroup,
+ * workgroups per step launch, spill slots. */
+int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg, int32_t* n_workgroups,
+               int32_t* spill_slots);
+
+/* Timing hook: HIP-event time (ms) of the step-kernel launches of the most recent mcpc_run
+ * whose run had profiling enabled via mcpc_set_profiling(e, 1).  Synchronises the stream. */
+int mcpc_set_profiling(mcpc_engine* e, int enable);
+int mcpc_last_step_kernel_ms(mcpc_engine* e, float* ms, int32_t* n_launches, int64_t* n_steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCPC_H */

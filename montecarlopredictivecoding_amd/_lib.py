@@ -1,0 +1,132 @@
+"""ctypes binding of libmcpc.so (C ABI: include/mcpc.h).  No torch types cross this boundary.
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``montecarlopredictivecoding_amd/csrc/Makefile``.  There is NO fallback: if the shared object is
+missing or does not load, every entry point raises ``MCPCLibraryError``.
+"""
+import ctypes as C
+import os
+
+MAX_LATENT = 6
+ENERGY_COLS = MAX_LATENT + 2
+ABI_VERSION = 1
+
+ACT_IDENTITY, ACT_RELU, ACT_TANH = 0, 1, 2
+LOSS_NONE, LOSS_GAUSSIAN, LOSS_BERNOULLI = 0, 1, 2
+XOPT_SGD, XOPT_ADAM = 0, 1
+NOISE_NONE, NOISE_PHILOX, NOISE_EXTERNAL = 0, 1, 2
+ENERGY_NONE, ENERGY_LAST, ENERGY_ALL = 0, 1, 2
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmcpc.so")
+
+
+class MCPCLibraryError(RuntimeError):
+    pass
+
+
+class MCPCError(RuntimeError):
+    """A libmcpc call returned a non-zero status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libmcpc error {code}: {message}")
+        self.code = code
+
+
+class NetDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("n_latent", C.c_int32),
+        ("n_in", C.c_int32),
+        ("sizes", C.c_int32 * MAX_LATENT),
+        ("acts", C.c_int32 * MAX_LATENT),
+        ("ecoef", C.c_float * MAX_LATENT),
+        ("n_out", C.c_int32),
+        ("batch", C.c_int32),
+        ("device", C.c_int32),
+        ("spill_budget_bytes", C.c_int64),
+    ]
+
+
+class RunDesc(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32), ("t_begin", C.c_int32), ("n_steps", C.c_int32),
+        ("loss_kind", C.c_int32), ("loss_var", C.c_float), ("mask_start", C.c_int32),
+        ("xopt_kind", C.c_int32), ("lr", C.c_float),
+        ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("adam_step0", C.c_int32),
+        ("update_x", C.c_int32),
+        ("noise_mode", C.c_int32), ("noise_var", C.c_float),
+        ("seed", C.c_uint64), ("step_base", C.c_uint64), ("chain_base", C.c_uint64),
+        ("ext_noise", C.c_void_p * MAX_LATENT),
+        ("acc_begin", C.c_int32), ("acc_end", C.c_int32), ("acc_reset", C.c_int32),
+        ("energy_mode", C.c_int32),
+        ("energies_out", C.c_void_p),
+        ("rec_begin", C.c_int32), ("rec_stride", C.c_int32), ("rec_count", C.c_int32),
+        ("rec_x", C.c_void_p * MAX_LATENT),
+        ("rec_out", C.c_void_p),
+        ("xgrad", C.c_void_p * MAX_LATENT),
+    ]
+
+
+# every symbol include/mcpc.h declares: (restype, argtypes)
+SYMBOLS = {
+    "mcpc_abi_version": (C.c_int, []),
+    "mcpc_last_error": (C.c_char_p, []),
+    "mcpc_create": (C.c_int, [C.POINTER(NetDesc), C.POINTER(C.c_void_p)]),
+    "mcpc_destroy": (C.c_int, [C.c_void_p]),
+    "mcpc_bind_params": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mcpc_params_changed": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mcpc_bind_inputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcpc_bind_target": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mcpc_load_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
+    "mcpc_store_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
+    "mcpc_run": (C.c_int, [C.c_void_p, C.POINTER(RunDesc), C.c_void_p]),
+    "mcpc_read_param_grads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
+    "mcpc_read_param_grads_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "mcpc_param_count": (C.c_int64, [C.c_void_p]),
+    "mcpc_philox_normals": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_int, C.c_void_p]),
+    "mcpc_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                             C.POINTER(C.c_int32)]),
+    "mcpc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "mcpc_last_step_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmcpc.so once; raise loudly if it is absent (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MCPCLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C montecarlopredictivecoding_amd/csrc`. There is no fallback path.")
+    # torch must be imported first: its wheel bundles the HIP runtime (SONAME libamdhip64.so.7) and
+    # libmcpc.so has to bind to THAT copy so that streams and allocations are shared.  Loading the
+    # system copy first leaves the process with two runtimes ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:   # pragma: no cover - depends on the machine
+        raise MCPCLibraryError(f"could not load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise MCPCLibraryError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.mcpc_abi_version()
+    if v != ABI_VERSION:
+        raise MCPCLibraryError(f"libmcpc ABI {v} != binding ABI {ABI_VERSION}: rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise MCPCError(code, load().mcpc_last_error().decode("utf-8", "replace"))

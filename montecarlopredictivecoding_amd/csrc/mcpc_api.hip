@@ -1,0 +1,605 @@
+// Host side of libmcpc.so: the C ABI declared in include/mcpc.h.
+// Allocation, weight packing, launch orchestration (step segments + Hebbian flushes); no torch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mcpc_kernels.h"
+
+using namespace mcpc;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) return fail(MCPC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+inline int pad16(int n) { return (n + 15) / 16 * 16; }
+inline int grid_for(size_t n, int block = 256) { return (int)std::min<size_t>((n + block - 1) / block, 4096); }
+
+struct Lin {
+    const float* W = nullptr;      // borrowed, torch layout [out][in]
+    const float* bias = nullptr;   // borrowed or null
+    bool bound = false;
+    int n_out = 0, n_in = 0, out_pad = 0, in_pad = 0;
+    float* Wf = nullptr;           // packed forward  [out_tiles][in_tiles][64][4]
+    float* Wb = nullptr;           // packed backward [in_tiles][out_tiles][64][4]
+    float* bias_pad = nullptr;     // [out_pad]
+    float* G = nullptr;            // gradient sums [out_pad][g_ld]
+    float* Gb = nullptr;           // [out_pad]
+    int g_ld = 0;
+};
+
+}  // namespace
+
+struct mcpc_engine {
+    mcpc_net_desc d{};
+    int L = 0, Bpad = 0, nwg = 0, has_head = 0;
+    int npad[kMaxLatent]{};
+    int out_pad = 0;
+    Lin lin[kMaxLatent + 1];
+    float* x[kMaxLatent]{};
+    float* m[kMaxLatent]{};
+    float* v[kMaxLatent]{};
+    float* e0sum = nullptr;
+    float* mu1 = nullptr;
+    float* ypad = nullptr;
+    bool target_bound = false;
+    const float* inputs = nullptr;
+    // Hebbian spill ring
+    int slots = 0;
+    float* spill_a[kMaxLatent]{};
+    float* spill_e[kMaxLatent]{};
+    float* spill_eo = nullptr;
+    float* slab = nullptr;
+    size_t slab_floats = 0;
+    // energies
+    double* epart = nullptr;
+    size_t epart_rows = 0;
+    float* adam_coef = nullptr;
+    size_t adam_cap = 0;
+    std::vector<float> adam_host;
+    // LDS plan
+    int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_bytes = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    int64_t prof_steps = 0;
+};
+
+namespace {
+
+int free_all(mcpc_engine* e) {
+    auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
+    for (int l = 0; l < kMaxLatent; ++l) { F(e->x[l]); F(e->m[l]); F(e->v[l]); F(e->spill_a[l]); F(e->spill_e[l]); }
+    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef);
+    for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
+    for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    e->events.clear();
+    return 0;
+}
+
+template <typename T>
+int dmalloc(T*& p, size_t count) {
+    void* q = nullptr;
+    hipError_t err = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    if (err != hipSuccess) return fail(MCPC_ENOMEM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(err));
+    p = (T*)q;
+    return 0;
+}
+
+// LDS plan: activations ping-pong between two buffers (FX_l in buffer l&1), the read-out error
+// chunk takes the buffer FX_{L-1} is NOT in, errors E_l (l>=1) get their own rows.
+int plan_lds(mcpc_engine* e) {
+    int buf[2] = {0, 0};
+    for (int l = 0; l < e->L; ++l) buf[l & 1] = std::max(buf[l & 1], kCT * (e->npad[l] + kLdPad));
+    const int eo_floats = e->has_head ? kCT * (kChunkTiles * 16 + kLdPad) : 0;
+    const int eo_buf = ((e->L - 1) & 1) ^ 1;
+    buf[eo_buf] = std::max(buf[eo_buf], eo_floats);
+    int off = 0;
+    const int base0 = off; off += buf[0];
+    const int base1 = off; off += buf[1];
+    for (int l = 0; l < e->L; ++l) e->lds_a[l] = (l & 1) ? base1 : base0;
+    e->lds_eo = eo_buf ? base1 : base0;
+    for (int l = 1; l < e->L; ++l) { e->lds_e[l] = off; off += kCT * (e->npad[l] + kLdPad); }
+    e->lds_e[0] = 0;
+    e->lds_red = off; off += 2 * (kMaxLatent + 1) * kWaves;
+    e->lds_bytes = off * (int)sizeof(float);
+    if (e->lds_bytes > 160 * 1024)
+        return fail(MCPC_ENOMEM, "network needs %d bytes of LDS per workgroup (> 163840): latent widths too large for the fused kernel", e->lds_bytes);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcpc_abi_version(void) { return MCPC_ABI_VERSION; }
+const char* mcpc_last_error(void) { return g_err.c_str(); }
+
+int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
+    if (!d || !out) return fail(MCPC_EINVAL, "null argument");
+    *out = nullptr;
+    if (d->abi_version != MCPC_ABI_VERSION) return fail(MCPC_EINVAL, "ABI version mismatch: header %d, library %d", d->abi_version, MCPC_ABI_VERSION);
+    if (d->n_latent < 1 || d->n_latent > kMaxLatent) return fail(MCPC_EINVAL, "n_latent=%d out of range 1..%d", d->n_latent, kMaxLatent);
+    if (d->batch < 1 || d->n_in < 1 || d->n_out < 0) return fail(MCPC_EINVAL, "bad batch/n_in/n_out (%d/%d/%d)", d->batch, d->n_in, d->n_out);
+    for (int l = 0; l < d->n_latent; ++l) {
+        if (d->sizes[l] < 1) return fail(MCPC_EINVAL, "sizes[%d]=%d", l, d->sizes[l]);
+        if (d->acts[l] < 0 || d->acts[l] > 2) return fail(MCPC_EINVAL, "acts[%d]=%d", l, d->acts[l]);
+        if (!(d->ecoef[l] > 0.f)) return fail(MCPC_EINVAL, "ecoef[%d] must be positive", l);
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (d->device < 0 || d->device >= ndev) return fail(MCPC_EINVAL, "device %d not present (%d devices)", d->device, ndev);
+    HIP_TRY(hipSetDevice(d->device));
+
+    mcpc_engine* e = new mcpc_engine();
+    e->d = *d;
+    e->L = d->n_latent;
+    e->has_head = d->n_out > 0;
+    e->Bpad = (d->batch + kCT - 1) / kCT * kCT;
+    e->nwg = e->Bpad / kCT;
+    for (int l = 0; l < e->L; ++l) e->npad[l] = pad16(d->sizes[l]);
+    e->out_pad = pad16(d->n_out);
+    if (e->has_head && e->npad[e->L - 1] / 16 > kNTB * kWaves) {
+        delete e;
+        return fail(MCPC_ENOMEM, "last latent layer wider than %d units is not supported by the fused read-out", kNTB * kWaves * 16);
+    }
+    int rc = plan_lds(e);
+    if (rc) { delete e; return rc; }
+
+    auto bail = [&](int code) { free_all(e); delete e; return code; };
+    for (int l = 0; l < e->L; ++l) {
+        const size_t n = (size_t)e->Bpad * e->npad[l];
+        if ((rc = dmalloc(e->x[l], n)) || (rc = dmalloc(e->m[l], n)) || (rc = dmalloc(e->v[l], n))) return bail(rc);
+        if (hipMemset(e->x[l], 0, n * 4) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
+    }
+    if ((rc = dmalloc(e->e0sum, (size_t)e->Bpad * e->npad[0])) || (rc = dmalloc(e->mu1, (size_t)e->Bpad * e->npad[0]))) return bail(rc);
+    if (hipMemset(e->e0sum, 0, (size_t)e->Bpad * e->npad[0] * 4) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
+    if (e->has_head) {
+        if ((rc = dmalloc(e->ypad, (size_t)e->Bpad * e->out_pad))) return bail(rc);
+        if (hipMemset(e->ypad, 0, (size_t)e->Bpad * e->out_pad * 4) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
+    }
+    // Linear descriptors + gradient sums
+    const int nlin = e->L + (e->has_head ? 1 : 0);
+    for (int j = 0; j < nlin; ++j) {
+        Lin& ln = e->lin[j];
+        ln.n_in = j == 0 ? d->n_in : d->sizes[j - 1];
+        ln.n_out = j < e->L ? d->sizes[j] : d->n_out;
+        ln.in_pad = j == 0 ? d->n_in : e->npad[j - 1];
+        ln.out_pad = pad16(ln.n_out);
+        ln.g_ld = ln.in_pad;
+        if ((rc = dmalloc(ln.G, (size_t)ln.out_pad * ln.g_ld)) || (rc = dmalloc(ln.Gb, (size_t)ln.out_pad))) return bail(rc);
+        if (hipMemset(ln.G, 0, (size_t)ln.out_pad * ln.g_ld * 4) != hipSuccess || hipMemset(ln.Gb, 0, (size_t)ln.out_pad * 4) != hipSuccess)
+            return bail(fail(MCPC_EHIP, "hipMemset failed"));
+        if (j >= 1) {
+            const size_t pk = (size_t)ln.out_pad * ln.in_pad;
+            if ((rc = dmalloc(ln.Wf, pk)) || (rc = dmalloc(ln.Wb, pk)) || (rc = dmalloc(ln.bias_pad, (size_t)ln.out_pad))) return bail(rc);
+        }
+    }
+    // spill ring
+    size_t per_slot = 0;
+    for (int l = 0; l < e->L; ++l) per_slot += (size_t)e->Bpad * e->npad[l] * (l >= 1 ? 2 : 1);
+    per_slot += (size_t)e->Bpad * e->out_pad;
+    per_slot *= sizeof(float);
+    const int64_t budget = d->spill_budget_bytes > 0 ? d->spill_budget_bytes : (int64_t)2 << 30;
+    e->slots = (int)std::max<int64_t>(1, std::min<int64_t>(64, budget / (int64_t)per_slot));
+    for (int l = 0; l < e->L; ++l) {
+        const size_t n = (size_t)e->slots * e->Bpad * e->npad[l];
+        if ((rc = dmalloc(e->spill_a[l], n))) return bail(rc);
+        if (l >= 1 && (rc = dmalloc(e->spill_e[l], n))) return bail(rc);
+    }
+    if (e->has_head && (rc = dmalloc(e->spill_eo, (size_t)e->slots * e->Bpad * e->out_pad))) return bail(rc);
+
+    hipError_t herr = hipFuncSetAttribute((const void*)mcpc_steps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
+    if (herr != hipSuccess) return bail(fail(MCPC_EHIP, "hipFuncSetAttribute(%d bytes LDS) failed: %s", e->lds_bytes, hipGetErrorString(herr)));
+    *out = e;
+    return MCPC_OK;
+}
+
+int mcpc_destroy(mcpc_engine* e) {
+    if (!e) return MCPC_OK;
+    (void)hipSetDevice(e->d.device);
+    (void)hipDeviceSynchronize();
+    free_all(e);
+    delete e;
+    return MCPC_OK;
+}
+
+int mcpc_bind_params(mcpc_engine* e, int j, const float* W, const float* bias) {
+    if (!e) return fail(MCPC_EINVAL, "null engine");
+    const int nlin = e->L + (e->has_head ? 1 : 0);
+    if (j < 0 || j >= nlin) return fail(MCPC_EINVAL, "Linear index %d out of range 0..%d", j, nlin - 1);
+    if (!W) return fail(MCPC_EINVAL, "null weight pointer for Linear %d", j);
+    e->lin[j].W = W;
+    e->lin[j].bias = bias;
+    e->lin[j].bound = true;
+    return MCPC_OK;
+}
+
+int mcpc_params_changed(mcpc_engine* e, void* stream_) {
+    if (!e) return fail(MCPC_EINVAL, "null engine");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(e->d.device));
+    const int nlin = e->L + (e->has_head ? 1 : 0);
+    for (int j = 0; j < nlin; ++j)
+        if (!e->lin[j].bound) return fail(MCPC_ESTATE, "Linear %d has no bound parameters", j);
+    for (int j = 1; j < nlin; ++j) {
+        Lin& ln = e->lin[j];
+        const size_t total = (size_t)ln.out_pad * ln.in_pad;
+        const int grid = std::max(grid_for(total), (ln.out_pad + 255) / 256);
+        hipLaunchKernelGGL(mcpc_pack_kernel, dim3(grid), dim3(256), 0, stream, ln.W, ln.bias, ln.Wf, ln.Wb, ln.bias_pad,
+                           ln.n_out, ln.n_in, ln.out_pad / 16, ln.in_pad / 16);
+    }
+    HIP_TRY(hipGetLastError());
+    return MCPC_OK;
+}
+
+int mcpc_bind_inputs(mcpc_engine* e, const float* inputs, void* /*stream*/) {
+    if (!e) return fail(MCPC_EINVAL, "null engine");
+    e->inputs = inputs;
+    return MCPC_OK;
+}
+
+int mcpc_bind_target(mcpc_engine* e, const float* target, void* stream_) {
+    if (!e) return fail(MCPC_EINVAL, "null engine");
+    if (!e->has_head) return fail(MCPC_EINVAL, "network has no read-out: no target to bind");
+    if (!target) return fail(MCPC_EINVAL, "null target");
+    HIP_TRY(hipSetDevice(e->d.device));
+    const size_t total = (size_t)e->Bpad * e->out_pad;
+    hipLaunchKernelGGL(mcpc_pad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, target, e->ypad,
+                       e->d.batch, e->d.n_out, e->Bpad, e->out_pad);
+    HIP_TRY(hipGetLastError());
+    e->target_bound = true;
+    return MCPC_OK;
+}
+
+int mcpc_load_state(mcpc_engine* e, const float* const* x, void* stream_) {
+    if (!e || !x) return fail(MCPC_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(e->d.device));
+    for (int l = 0; l < e->L; ++l) {
+        if (!x[l]) return fail(MCPC_EINVAL, "null state pointer for layer %d", l);
+        const size_t total = (size_t)e->Bpad * e->npad[l];
+        hipLaunchKernelGGL(mcpc_pad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, x[l], e->x[l],
+                           e->d.batch, e->d.sizes[l], e->Bpad, e->npad[l]);
+    }
+    HIP_TRY(hipGetLastError());
+    return MCPC_OK;
+}
+
+int mcpc_store_state(mcpc_engine* e, float* const* x, void* stream_) {
+    if (!e || !x) return fail(MCPC_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(e->d.device));
+    for (int l = 0; l < e->L; ++l) {
+        if (!x[l]) return fail(MCPC_EINVAL, "null state pointer for layer %d", l);
+        const size_t total = (size_t)e->d.batch * e->d.sizes[l];
+        hipLaunchKernelGGL(mcpc_unpad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, e->x[l], x[l],
+                           e->d.batch, e->d.sizes[l], e->npad[l]);
+    }
+    HIP_TRY(hipGetLastError());
+    return MCPC_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// One Hebbian flush: fold `n_slots` spilled steps into the gradient sums of every Linear j >= 1.
+int flush_spill(mcpc_engine* e, int n_slots, hipStream_t stream) {
+    const int rows = n_slots * e->Bpad;
+    const int nlin = e->L + (e->has_head ? 1 : 0);
+    for (int j = 1; j < nlin; ++j) {
+        Lin& ln = e->lin[j];
+        const float* E = j < e->L ? e->spill_e[j] : e->spill_eo;
+        const float* A = e->spill_a[j - 1];
+        const int ne = ln.out_pad, na = ln.in_pad;
+        const int wave_tiles = ((ne + 63) / 64) * ((na + 63) / 64);
+        int ksplit = std::max(1, std::min(2048 / wave_tiles, rows / 64));
+        int rps = ((rows + ksplit - 1) / ksplit + 3) / 4 * 4;
+        ksplit = (rows + rps - 1) / rps;
+        const size_t need = std::max((size_t)ksplit * ne * std::max(na, 1), (size_t)64 * ne);
+        if (need > e->slab_floats) {
+            if (e->slab) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(e->slab)); e->slab = nullptr; }
+            int rc = dmalloc(e->slab, need);
+            if (rc) return rc;
+            e->slab_floats = need;
+        }
+        hipLaunchKernelGGL(mcpc_dw_kernel, dim3((wave_tiles + 3) / 4, ksplit), dim3(256), 0, stream, E, A, e->slab, rows, ne, na, rps);
+        hipLaunchKernelGGL(mcpc_reduce_slabs_kernel, dim3(grid_for((size_t)ne * na)), dim3(256), 0, stream, e->slab, ln.G,
+                           (size_t)ne * na, ksplit, j < e->L ? -1.0f : 1.0f, 1);
+        // bias: column sums of E (slab reused: ksplit_b * ne floats <= need)
+        int ksb = std::max(1, std::min(64, rows / 256));
+        int rpsb = ((rows + ksb - 1) / ksb + 3) / 4 * 4;
+        ksb = (rows + rpsb - 1) / rpsb;
+        hipLaunchKernelGGL(mcpc_colsum_kernel, dim3((ne + 63) / 64, ksb), dim3(256), 0, stream, E, e->slab, rows, ne, rpsb);
+        hipLaunchKernelGGL(mcpc_reduce_slabs_kernel, dim3(grid_for((size_t)ne)), dim3(256), 0, stream, e->slab, ln.Gb,
+                           (size_t)ne, ksb, j < e->L ? -1.0f : 1.0f, 1);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
+    if (!e || !r) return fail(MCPC_EINVAL, "null argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(e->d.device));
+    const int nlin = e->L + (e->has_head ? 1 : 0);
+    for (int j = 0; j < nlin; ++j)
+        if (!e->lin[j].bound) return fail(MCPC_ESTATE, "Linear %d has no bound parameters (mcpc_bind_params + mcpc_params_changed first)", j);
+    if (r->T < 1 || r->t_begin < 0 || r->n_steps < 1 || r->t_begin + r->n_steps > r->T)
+        return fail(MCPC_EINVAL, "bad step range: T=%d t_begin=%d n_steps=%d", r->T, r->t_begin, r->n_steps);
+    if (r->loss_kind < 0 || r->loss_kind > 2) return fail(MCPC_EINVAL, "loss_kind=%d", r->loss_kind);
+    if (r->loss_kind != MCPC_LOSS_NONE) {
+        if (!e->has_head) return fail(MCPC_EINVAL, "a loss needs a read-out Linear (n_out > 0)");
+        if (!e->target_bound) return fail(MCPC_ESTATE, "loss requested but no target bound");
+        if (r->loss_kind == MCPC_LOSS_GAUSSIAN && !(r->loss_var > 0.f)) return fail(MCPC_EINVAL, "loss_var must be positive");
+        if (r->mask_start < 0 || r->mask_start >= e->d.n_out) return fail(MCPC_EINVAL, "mask_start=%d outside 0..%d", r->mask_start, e->d.n_out - 1);
+    }
+    if (r->xopt_kind != MCPC_XOPT_SGD && r->xopt_kind != MCPC_XOPT_ADAM) return fail(MCPC_EINVAL, "xopt_kind=%d", r->xopt_kind);
+    if (!(r->lr > 0.f)) return fail(MCPC_EINVAL, "lr must be positive");
+    if (r->noise_mode < 0 || r->noise_mode > 2) return fail(MCPC_EINVAL, "noise_mode=%d", r->noise_mode);
+    if (r->noise_mode != MCPC_NOISE_NONE && r->xopt_kind != MCPC_XOPT_SGD)
+        return fail(MCPC_EINVAL, "the fused Langevin kick is defined for SGD on x only (reference utils/model.py:35-44 steps the same optimizer)");
+    if (r->noise_mode != MCPC_NOISE_NONE && !(r->noise_var >= 0.f)) return fail(MCPC_EINVAL, "noise_var must be >= 0");
+    if (r->noise_mode == MCPC_NOISE_EXTERNAL)
+        for (int l = 0; l < e->L; ++l)
+            if (!r->ext_noise[l]) return fail(MCPC_EINVAL, "ext_noise[%d] is null", l);
+    if (!r->update_x)
+        for (int l = 0; l < e->L; ++l)
+            if (!r->xgrad[l]) return fail(MCPC_EINVAL, "update_x=0 needs xgrad[%d]", l);
+    if (r->energy_mode < 0 || r->energy_mode > 2) return fail(MCPC_EINVAL, "energy_mode=%d", r->energy_mode);
+    if (r->energy_mode != MCPC_ENERGY_NONE && !r->energies_out) return fail(MCPC_EINVAL, "energies_out is null");
+    if (r->rec_count < 0 || (r->rec_count > 0 && r->rec_stride < 1)) return fail(MCPC_EINVAL, "bad record schedule");
+    const int acc_b = std::max(r->acc_begin, 0), acc_e = std::min(r->acc_end, r->T);
+
+    // ---- per-run device tables ----------------------------------------------------------------
+    if (r->xopt_kind == MCPC_XOPT_ADAM) {
+        if ((size_t)r->n_steps * 2 > e->adam_cap) {
+            if (e->adam_coef) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(e->adam_coef)); e->adam_coef = nullptr; }
+            int rc = dmalloc(e->adam_coef, (size_t)r->n_steps * 2);
+            if (rc) return rc;
+            e->adam_cap = (size_t)r->n_steps * 2;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));          // host table may still feed a previous async copy
+        e->adam_host.resize((size_t)r->n_steps * 2);
+        for (int s = 0; s < r->n_steps; ++s) {
+            const double step = (double)(r->adam_step0 + s + 1);
+            const double bc1 = 1.0 - std::pow((double)r->beta1, step);
+            const double bc2 = 1.0 - std::pow((double)r->beta2, step);
+            e->adam_host[2 * s] = (float)((double)r->lr / bc1);
+            e->adam_host[2 * s + 1] = (float)(1.0 / std::sqrt(bc2));
+        }
+        HIP_TRY(hipMemcpyAsync(e->adam_coef, e->adam_host.data(), (size_t)r->n_steps * 2 * sizeof(float), hipMemcpyHostToDevice, stream));
+        if (r->adam_step0 == 0)
+            for (int l = 0; l < e->L; ++l) {
+                HIP_TRY(hipMemsetAsync(e->m[l], 0, (size_t)e->Bpad * e->npad[l] * 4, stream));
+                HIP_TRY(hipMemsetAsync(e->v[l], 0, (size_t)e->Bpad * e->npad[l] * 4, stream));
+            }
+    }
+    const size_t erows = r->energy_mode == MCPC_ENERGY_ALL ? (size_t)r->T : 1;
+    if (r->energy_mode != MCPC_ENERGY_NONE && erows > e->epart_rows) {
+        if (e->epart) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(e->epart)); e->epart = nullptr; }
+        int rc = dmalloc(e->epart, erows * e->nwg * (kMaxLatent + 1));
+        if (rc) return rc;
+        e->epart_rows = erows;
+    }
+    // mu_1 = inputs W0^T + b0 (constant during the run: weights only change between runs)
+    {
+        const Lin& l0 = e->lin[0];
+        const size_t total = (size_t)e->Bpad * e->npad[0];
+        hipLaunchKernelGGL(mcpc_mu1_kernel, dim3(grid_for(total)), dim3(256), 0, stream, e->inputs, l0.W, l0.bias, e->mu1,
+                           e->d.batch, e->d.n_in, e->d.sizes[0], e->Bpad, e->npad[0]);
+    }
+    const bool run_accumulates = acc_b < acc_e && r->t_begin < acc_e && r->t_begin + r->n_steps > acc_b;
+    if (r->acc_reset && run_accumulates) {
+        for (int j = 0; j < nlin; ++j) {
+            HIP_TRY(hipMemsetAsync(e->lin[j].G, 0, (size_t)e->lin[j].out_pad * e->lin[j].g_ld * 4, stream));
+            HIP_TRY(hipMemsetAsync(e->lin[j].Gb, 0, (size_t)e->lin[j].out_pad * 4, stream));
+        }
+        HIP_TRY(hipMemsetAsync(e->e0sum, 0, (size_t)e->Bpad * e->npad[0] * 4, stream));
+    }
+
+    // ---- kernel parameters ----------------------------------------------------------------------
+    KParams P{};
+    for (int l = 0; l < e->L; ++l) {
+        KLayer& K = P.layer[l];
+        K.x = e->x[l]; K.m = e->m[l]; K.v = e->v[l];
+        K.xgrad = r->update_x ? nullptr : r->xgrad[l];
+        K.rec = r->rec_count > 0 ? r->rec_x[l] : nullptr;
+        K.spill_e = l == 0 ? e->e0sum : e->spill_e[l];
+        K.spill_a = e->spill_a[l];
+        K.ext_noise = nullptr;
+        if (l >= 1) {
+            K.Wf = (const f32x4*)e->lin[l].Wf; K.Wb = (const f32x4*)e->lin[l].Wb; K.bias = e->lin[l].bias_pad;
+        }
+        K.n = e->d.sizes[l]; K.npad = e->npad[l]; K.ntiles = e->npad[l] / 16;
+        K.act = e->d.acts[l]; K.ecoef = e->d.ecoef[l];
+        K.lds_a = e->lds_a[l]; K.lds_e = e->lds_e[l]; K.ld = e->npad[l] + kLdPad;
+    }
+    if (e->has_head) {
+        KHead& H = P.head;
+        const Lin& ln = e->lin[e->L];
+        H.Wf = (const f32x4*)ln.Wf; H.Wb = (const f32x4*)ln.Wb; H.bias = ln.bias_pad;
+        H.y = e->ypad; H.rec_out = r->rec_count > 0 ? r->rec_out : nullptr; H.spill_e = e->spill_eo;
+        H.n = e->d.n_out; H.npad = e->out_pad; H.ntiles = e->out_pad / 16;
+        H.loss_kind = r->loss_kind;
+        H.inv_var = r->loss_kind == MCPC_LOSS_GAUSSIAN ? (float)(1.0 / (double)r->loss_var) : 1.0f;
+        H.mask_start = r->loss_kind == MCPC_LOSS_NONE ? 0 : r->mask_start;
+        H.lds_eo = e->lds_eo; H.ld = kChunkTiles * 16 + kLdPad;
+    }
+    P.mu1 = e->mu1; P.epart = e->epart;
+    P.L = e->L; P.has_head = e->has_head; P.B = e->d.batch; P.Bpad = e->Bpad; P.T = r->T;
+    P.xopt = r->xopt_kind; P.update_x = r->update_x ? 1 : 0;
+    P.lr = r->lr; P.beta2 = r->beta2;
+    P.omb1 = (float)(1.0 - (double)r->beta1); P.omb2 = (float)(1.0 - (double)r->beta2); P.eps = r->eps;
+    P.noise_mode = r->update_x ? r->noise_mode : MCPC_NOISE_NONE;
+    P.noise_scale = (float)std::sqrt((double)r->noise_var * (double)r->lr);
+    P.seed = r->seed; P.step_base = r->step_base; P.chain_base = r->chain_base;
+    P.acc_begin = acc_b; P.acc_end = acc_e;
+    P.energy_mode = r->energy_mode;
+    P.rec_begin = r->rec_begin; P.rec_stride = std::max(r->rec_stride, 1); P.rec_count = r->rec_count;
+    P.lds_red = e->lds_red;
+
+    if (e->profiling) { e->events_used = 0; e->prof_steps = 0; }
+
+    // ---- step segments: non-accumulating stretches run as one persistent launch; accumulating
+    //      stretches are cut at the spill ring's capacity and followed by a Hebbian flush ----------
+    int t = r->t_begin;
+    const int end = r->t_begin + r->n_steps;
+    while (t < end) {
+        const bool in_acc = t >= acc_b && t < acc_e;
+        int n;
+        if (in_acc) n = std::min(std::min(end, acc_e) - t, e->slots);
+        else n = (t < acc_b ? std::min(end, acc_b) : end) - t;
+        P.t0 = t; P.n_steps = n; P.spill_t0 = t;
+        const int s0 = t - r->t_begin;
+        P.adam_coef = r->xopt_kind == MCPC_XOPT_ADAM ? e->adam_coef + 2 * (size_t)s0 : nullptr;
+        if (r->noise_mode == MCPC_NOISE_EXTERNAL)
+            for (int l = 0; l < e->L; ++l) P.layer[l].ext_noise = r->ext_noise[l] + (size_t)s0 * e->d.batch * e->d.sizes[l];
+        if (e->profiling) {
+            if (e->events_used == e->events.size()) {
+                hipEvent_t a, b;
+                HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+                e->events.emplace_back(a, b);
+            }
+            HIP_TRY(hipEventRecord(e->events[e->events_used].first, stream));
+        }
+        hipLaunchKernelGGL(mcpc_steps_kernel, dim3(e->nwg), dim3(kThreads), e->lds_bytes, stream, P);
+        if (e->profiling) {
+            HIP_TRY(hipEventRecord(e->events[e->events_used].second, stream));
+            ++e->events_used; e->prof_steps += n;
+        }
+        HIP_TRY(hipGetLastError());
+        if (in_acc) { int rc = flush_spill(e, n, stream); if (rc) return rc; }
+        t += n;
+    }
+    if (run_accumulates) {
+        // Linear 0 sees a constant input: fold sum_t e_1 now, then clear the running sum
+        Lin& l0 = e->lin[0];
+        const int total = std::max(l0.n_out * l0.n_in, l0.n_out);
+        hipLaunchKernelGGL(mcpc_dw0_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, e->e0sum, e->inputs, l0.G, l0.Gb,
+                           e->d.batch, l0.n_out, e->npad[0], l0.n_in, l0.g_ld, 1);
+        HIP_TRY(hipMemsetAsync(e->e0sum, 0, (size_t)e->Bpad * e->npad[0] * 4, stream));
+    }
+    if (r->energy_mode == MCPC_ENERGY_ALL) {
+        hipLaunchKernelGGL(mcpc_energy_reduce_kernel, dim3((r->n_steps + 63) / 64), dim3(64), 0, stream,
+                           e->epart + (size_t)r->t_begin * e->nwg * (kMaxLatent + 1),
+                           r->energies_out + (size_t)r->t_begin * kEnergyCols, r->n_steps, e->nwg, e->L);
+    } else if (r->energy_mode == MCPC_ENERGY_LAST && end == r->T) {
+        hipLaunchKernelGGL(mcpc_energy_reduce_kernel, dim3(1), dim3(64), 0, stream, e->epart, r->energies_out, 1, e->nwg, e->L);
+    }
+    HIP_TRY(hipGetLastError());
+    return MCPC_OK;
+}
+
+int mcpc_read_param_grads(mcpc_engine* e, int j, float* dW, float* db, float scale, int accumulate, void* stream_) {
+    if (!e) return fail(MCPC_EINVAL, "null engine");
+    const int nlin = e->L + (e->has_head ? 1 : 0);
+    if (j < 0 || j >= nlin) return fail(MCPC_EINVAL, "Linear index %d out of range", j);
+    if (!dW) return fail(MCPC_EINVAL, "null dW");
+    HIP_TRY(hipSetDevice(e->d.device));
+    const Lin& ln = e->lin[j];
+    hipStream_t stream = (hipStream_t)stream_;
+    hipLaunchKernelGGL(mcpc_export_grad_kernel, dim3(grid_for((size_t)ln.n_out * ln.n_in)), dim3(256), 0, stream, ln.G, dW,
+                       ln.n_out, ln.n_in, ln.g_ld, scale, accumulate);
+    if (db)
+        hipLaunchKernelGGL(mcpc_export_grad_kernel, dim3(grid_for((size_t)ln.n_out)), dim3(256), 0, stream, ln.Gb, db,
+                           ln.n_out, 1, 1, scale, accumulate);
+    HIP_TRY(hipGetLastError());
+    return MCPC_OK;
+}
+
+int64_t mcpc_param_count(const mcpc_engine* e) {
+    if (!e) return 0;
+    const int nlin = e->L + (e->has_head ? 1 : 0);
+    int64_t n = 0;
+    for (int j = 0; j < nlin; ++j) n += (int64_t)e->lin[j].n_out * e->lin[j].n_in + (e->lin[j].bias ? e->lin[j].n_out : 0);
+    return n;
+}
+
+int mcpc_read_param_grads_flat(mcpc_engine* e, float* flat, int64_t n_floats, float scale, void* stream_) {
+    if (!e || !flat) return fail(MCPC_EINVAL, "null argument");
+    if (n_floats != mcpc_param_count(e)) return fail(MCPC_EINVAL, "flat buffer holds %lld floats, parameters need %lld", (long long)n_floats, (long long)mcpc_param_count(e));
+    const int nlin = e->L + (e->has_head ? 1 : 0);
+    int64_t off = 0;
+    for (int j = 0; j < nlin; ++j) {
+        const Lin& ln = e->lin[j];
+        float* dW = flat + off; off += (int64_t)ln.n_out * ln.n_in;
+        float* db = nullptr;
+        if (ln.bias) { db = flat + off; off += ln.n_out; }
+        int rc = mcpc_read_param_grads(e, j, dW, db, scale, 0, stream_);
+        if (rc) return rc;
+    }
+    return MCPC_OK;
+}
+
+int mcpc_philox_normals(int device, uint64_t seed, uint64_t step, int layer, uint64_t chain_base, int batch, int n_units,
+                        float* out, int raw, void* stream_) {
+    if (!out || batch < 1 || n_units < 1 || layer < 0 || layer > 255) return fail(MCPC_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const size_t total = (size_t)batch * ((n_units + 3) / 4);
+    hipLaunchKernelGGL(mcpc_philox_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, seed, step, layer, chain_base,
+                       batch, n_units, out, raw);
+    HIP_TRY(hipGetLastError());
+    return MCPC_OK;
+}
+
+int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg, int32_t* n_workgroups, int32_t* spill_slots) {
+    if (!e) return fail(MCPC_EINVAL, "null engine");
+    if (lds_bytes) *lds_bytes = e->lds_bytes;
+    if (chains_per_wg) *chains_per_wg = kCT;
+    if (n_workgroups) *n_workgroups = e->nwg;
+    if (spill_slots) *spill_slots = e->slots;
+    return MCPC_OK;
+}
+
+int mcpc_set_profiling(mcpc_engine* e, int enable) {
+    if (!e) return fail(MCPC_EINVAL, "null engine");
+    e->profiling = enable != 0;
+    e->events_used = 0;
+    e->prof_steps = 0;
+    return MCPC_OK;
+}
+
+int mcpc_last_step_kernel_ms(mcpc_engine* e, float* ms, int32_t* n_launches, int64_t* n_steps) {
+    if (!e || !ms) return fail(MCPC_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(e->d.device));
+    float total = 0.f;
+    for (size_t i = 0; i < e->events_used; ++i) {
+        HIP_TRY(hipEventSynchronize(e->events[i].second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e->events[i].first, e->events[i].second));
+        total += t;
+    }
+    *ms = total;
+    if (n_launches) *n_launches = (int32_t)e->events_used;
+    if (n_steps) *n_steps = e->prof_steps;
+    return MCPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// Device-side helpers shared by the MCPC kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace mcpc {
+
+// ---- Philox4x32-10 (Salmon et al. SC'11).  Bit-exact twin: oracle/philox.py -------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Two u32 -> two standard normals (Box-Muller).  u1 in (0,1], u2 in [0,1) (fraction of a turn).
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float u1 = (float)((a >> 8) + 1u) * 0x1p-24f;
+    const float u2 = (float)(b >> 8) * 0x1p-24f;
+    // -2 ln(u1) = -2 ln2 * log2(u1); v_log_f32 is log2, v_sin/v_cos take turns.
+    const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    z0 = r * __builtin_amdgcn_cosf(u2);
+    z1 = r * __builtin_amdgcn_sinf(u2);
+}
+
+// Four normals for units 4g..4g+3 of `layer` of global chain `chain` at global step `step`.
+__device__ __forceinline__ f32x4 normals4(uint64_t seed, uint64_t step, uint32_t layer, uint32_t chain, uint32_t group) {
+    uint32_t r[4];
+    philox4x32_10(chain, (layer << 24) | group, (uint32_t)step, (uint32_t)(step >> 32),
+                  (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    f32x4 z;
+    float a, b;
+    box_muller(r[0], r[1], a, b); z.x = a; z.y = b;
+    box_muller(r[2], r[3], a, b); z.z = a; z.w = b;
+    return z;
+}
+
+// ---- activations (reference utils/model.py:49-52: nn.ReLU / nn.Tanh; none for the linear toys) --
+__device__ __forceinline__ float tanh_f(float x) {
+    // tanh(x) = 1 - 2/(exp(2x)+1); exp via v_exp_f32 (2^x).  |err| ~ 1e-7 absolute.
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // exp(2x)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ float act_f(int a, float x) {
+    return a == 1 ? fmaxf(x, 0.0f) : (a == 2 ? tanh_f(x) : x);
+}
+// derivative given x and f(x)
+__device__ __forceinline__ float act_d(int a, float x, float fx) {
+    return a == 1 ? (x > 0.0f ? 1.0f : 0.0f) : (a == 2 ? 1.0f - fx * fx : 1.0f);
+}
+
+__device__ __forceinline__ float sigmoid_f(float o) {
+    const float e = __builtin_amdgcn_exp2f(-o * 1.4426950408889634f);  // exp(-o)
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+// BCEWithLogits element: max(o,0) - o*y + log1p(exp(-|o|))
+__device__ __forceinline__ float bce_logits_f(float o, float y) {
+    const float e = __builtin_amdgcn_exp2f(-fabsf(o) * 1.4426950408889634f);
+    return fmaxf(o, 0.0f) - o * y + log1pf(e);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+}  // namespace mcpc

@@ -1,0 +1,226 @@
+"""Thin object wrapper over the libmcpc C ABI.
+
+PyTorch appears here only as the owner of device memory and of the HIP stream: every tensor is
+handed to the library as ``data_ptr()`` + sizes.  The computation is the hand-written HIP code in
+``csrc/`` -- this module contains no arithmetic and no fallback.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _check_tensor(t: torch.Tensor, shape, device, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if t.device != device:
+        raise ValueError(f"{name}: expected device {device}, got {t.device}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+
+
+@dataclass
+class RunResult:
+    energies: Optional[torch.Tensor] = None      # float64 [rows, ENERGY_COLS]: loss, E_1..E_L, overall
+    rec_x: List[torch.Tensor] = field(default_factory=list)
+    rec_out: Optional[torch.Tensor] = None
+    xgrad: List[torch.Tensor] = field(default_factory=list)
+
+
+class Engine:
+    """One MCPC engine = one network shape + one shard of chains on one GPU."""
+
+    def __init__(self, sizes: Sequence[int], acts: Sequence[int], n_in: int, n_out: int, batch: int,
+                 device=None, ecoef: Optional[Sequence[float]] = None, spill_budget_bytes: int = 0):
+        self._h = C.c_void_p()
+        self._lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.MCPCLibraryError("no HIP device visible: the MCPC engine has no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.sizes = [int(s) for s in sizes]
+        self.acts = [int(a) for a in acts]
+        self.ecoef = [1.0] * len(self.sizes) if ecoef is None else [float(c) for c in ecoef]
+        self.n_in, self.n_out, self.batch = int(n_in), int(n_out), int(batch)
+        self.L = len(self.sizes)
+        if not (1 <= self.L <= L.MAX_LATENT):
+            raise ValueError(f"1..{L.MAX_LATENT} latent layers supported, got {self.L}")
+        d = L.NetDesc()
+        d.abi_version = L.ABI_VERSION
+        d.n_latent, d.n_in, d.n_out, d.batch = self.L, self.n_in, self.n_out, self.batch
+        d.device = self.device.index
+        d.spill_budget_bytes = int(spill_budget_bytes)
+        for i in range(self.L):
+            d.sizes[i], d.acts[i], d.ecoef[i] = self.sizes[i], self.acts[i], self.ecoef[i]
+        L.check(self._lib.mcpc_create(C.byref(d), C.byref(self._h)))
+        self._keep = {}          # borrowed tensors the library holds pointers to
+        self.n_lin = self.L + (1 if self.n_out > 0 else 0)
+        self.step_counter = 0    # Philox step offset, advances across runs
+
+    # ---- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mcpc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def lin_shape(self, j):
+        n_in = self.n_in if j == 0 else self.sizes[j - 1]
+        n_out = self.sizes[j] if j < self.L else self.n_out
+        return n_out, n_in
+
+    # ---- binding -------------------------------------------------------------------------------
+    def bind_params(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]]):
+        if len(weights) != self.n_lin or len(biases) != self.n_lin:
+            raise ValueError(f"expected {self.n_lin} Linear layers, got {len(weights)}")
+        for j, (W, b) in enumerate(zip(weights, biases)):
+            n_out, n_in = self.lin_shape(j)
+            _check_tensor(W, (n_out, n_in), self.device, f"weight[{j}]")
+            if b is not None:
+                _check_tensor(b, (n_out,), self.device, f"bias[{j}]")
+            L.check(self._lib.mcpc_bind_params(self._h, j, _ptr(W), _ptr(b)))
+        self._keep["W"], self._keep["b"] = list(weights), list(biases)
+        self.params_changed()
+
+    def params_changed(self):
+        L.check(self._lib.mcpc_params_changed(self._h, self._stream()))
+
+    def bind_inputs(self, inputs: Optional[torch.Tensor]):
+        if inputs is not None:
+            _check_tensor(inputs, (self.batch, self.n_in), self.device, "inputs")
+        self._keep["inputs"] = inputs
+        L.check(self._lib.mcpc_bind_inputs(self._h, _ptr(inputs), self._stream()))
+
+    def bind_target(self, target: torch.Tensor):
+        _check_tensor(target, (self.batch, self.n_out), self.device, "target")
+        L.check(self._lib.mcpc_bind_target(self._h, _ptr(target), self._stream()))
+
+    def _ptr_array(self, tensors, names):
+        arr = (C.c_void_p * self.L)()
+        for l, t in enumerate(tensors):
+            _check_tensor(t, (self.batch, self.sizes[l]), self.device, f"{names}[{l}]")
+            arr[l] = t.data_ptr()
+        return arr
+
+    def load_state(self, xs: Sequence[torch.Tensor]):
+        L.check(self._lib.mcpc_load_state(self._h, self._ptr_array(xs, "x"), self._stream()))
+
+    def store_state(self, xs: Sequence[torch.Tensor]):
+        L.check(self._lib.mcpc_store_state(self._h, self._ptr_array(xs, "x"), self._stream()))
+
+    # ---- the hot loop ----------------------------------------------------------------------------
+    def run(self, T: int, t_begin: int = 0, n_steps: Optional[int] = None, *,
+            loss_kind=L.LOSS_NONE, loss_var=1.0, mask_start=0,
+            xopt=L.XOPT_SGD, lr=0.1, betas=(0.9, 0.999), eps=1e-8, adam_step0=0,
+            update_x=True, noise_mode=L.NOISE_NONE, noise_var=2.0, seed=0, step_base=None, chain_base=0,
+            ext_noise: Optional[Sequence[torch.Tensor]] = None,
+            acc_begin=0, acc_end=0, acc_reset=True,
+            energy_mode=L.ENERGY_NONE,
+            rec_begin=0, rec_stride=1, rec_count=0, rec_x=False, rec_out=False) -> RunResult:
+        n_steps = T - t_begin if n_steps is None else n_steps
+        r = L.RunDesc()
+        r.T, r.t_begin, r.n_steps = T, t_begin, n_steps
+        r.loss_kind, r.loss_var, r.mask_start = loss_kind, loss_var, mask_start
+        r.xopt_kind, r.lr = xopt, lr
+        r.beta1, r.beta2, r.eps, r.adam_step0 = betas[0], betas[1], eps, adam_step0
+        r.update_x = 1 if update_x else 0
+        r.noise_mode, r.noise_var = noise_mode, noise_var
+        r.seed = seed & 0xFFFFFFFFFFFFFFFF
+        r.step_base = self.step_counter if step_base is None else step_base
+        r.chain_base = chain_base
+        res = RunResult()
+        keep = []
+        if noise_mode == L.NOISE_EXTERNAL:
+            if ext_noise is None or len(ext_noise) != self.L:
+                raise ValueError("NOISE_EXTERNAL needs one tensor per latent layer")
+            for l, t in enumerate(ext_noise):
+                _check_tensor(t, (n_steps, self.batch, self.sizes[l]), self.device, f"ext_noise[{l}]")
+                r.ext_noise[l] = t.data_ptr()
+                keep.append(t)
+        r.acc_begin, r.acc_end, r.acc_reset = acc_begin, acc_end, 1 if acc_reset else 0
+        r.energy_mode = energy_mode
+        if energy_mode != L.ENERGY_NONE:
+            rows = T if energy_mode == L.ENERGY_ALL else 1
+            res.energies = torch.zeros(rows, L.ENERGY_COLS, dtype=torch.float64, device=self.device)
+            r.energies_out = res.energies.data_ptr()
+        r.rec_begin, r.rec_stride, r.rec_count = rec_begin, rec_stride, rec_count
+        if rec_count > 0:
+            if rec_x:
+                for l in range(self.L):
+                    t = torch.empty(rec_count, self.batch, self.sizes[l], dtype=torch.float32, device=self.device)
+                    res.rec_x.append(t)
+                    r.rec_x[l] = t.data_ptr()
+            if rec_out and self.n_out > 0:
+                res.rec_out = torch.empty(rec_count, self.batch, self.n_out, dtype=torch.float32, device=self.device)
+                r.rec_out = res.rec_out.data_ptr()
+        if not update_x:
+            for l in range(self.L):
+                t = torch.empty(self.batch, self.sizes[l], dtype=torch.float32, device=self.device)
+                res.xgrad.append(t)
+                r.xgrad[l] = t.data_ptr()
+        L.check(self._lib.mcpc_run(self._h, C.byref(r), self._stream()))
+        if step_base is None and update_x:
+            self.step_counter += n_steps
+        self._keep["run"] = keep
+        return res
+
+    # ---- parameter gradients ---------------------------------------------------------------------
+    def read_param_grads(self, j: int, dW: torch.Tensor, db: Optional[torch.Tensor], scale=1.0, accumulate=False):
+        n_out, n_in = self.lin_shape(j)
+        _check_tensor(dW, (n_out, n_in), self.device, "dW")
+        if db is not None:
+            _check_tensor(db, (n_out,), self.device, "db")
+        L.check(self._lib.mcpc_read_param_grads(self._h, j, _ptr(dW), _ptr(db), scale, 1 if accumulate else 0, self._stream()))
+
+    def param_count(self) -> int:
+        return int(self._lib.mcpc_param_count(self._h))
+
+    def read_param_grads_flat(self, scale=1.0) -> torch.Tensor:
+        flat = torch.empty(self.param_count(), dtype=torch.float32, device=self.device)
+        L.check(self._lib.mcpc_read_param_grads_flat(self._h, _ptr(flat), flat.numel(), scale, self._stream()))
+        return flat
+
+    # ---- introspection -----------------------------------------------------------------------------
+    def query(self):
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        L.check(self._lib.mcpc_query(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(lds_bytes=a.value, chains_per_wg=b.value, n_workgroups=c.value, spill_slots=d.value)
+
+    def set_profiling(self, enable: bool):
+        L.check(self._lib.mcpc_set_profiling(self._h, 1 if enable else 0))
+
+    def last_step_kernel_ms(self):
+        ms, n, s = C.c_float(), C.c_int32(), C.c_int64()
+        L.check(self._lib.mcpc_last_step_kernel_ms(self._h, C.byref(ms), C.byref(n), C.byref(s)))
+        return ms.value, n.value, s.value
+
+
+def philox_normals(seed, step, layer, chain_base, batch, n_units, device, raw=False) -> torch.Tensor:
+    """The device generator's normals (or raw u32 bit patterns viewed as int32) for one layer/step."""
+    lib = L.load()
+    device = torch.device(device)
+    out = torch.empty(batch, n_units, dtype=torch.float32, device=device)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    L.check(lib.mcpc_philox_normals(device.index or 0, seed, step, layer, chain_base, batch, n_units,
+                                    _ptr(out), 1 if raw else 0, stream))
+    return out.view(torch.int32) if raw else out

@@ -1,0 +1,153 @@
+"""GPU parity: the HIP engine (through the C ABI) vs the reference's golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+from tests.golden_util import Golden, fixture_names
+
+pytestmark = pytest.mark.gpu
+
+ACT = {"identity": 0, "relu": 1, "tanh": 2}
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def make_engine(g, **kw):
+    from montecarlopredictivecoding_amd.engine import Engine
+    c = g.case
+    return Engine(c["sizes"], [ACT[a] for a in c["acts"]], c["n_in"], c["n_out"], c["B"], device=_dev(),
+                  ecoef=c["ecoef"], **kw)
+
+
+def bind(eng, g, W=None, b=None):
+    dev = _dev()
+    W = g.W if W is None else W
+    b = g.b if b is None else b
+    Wt = [torch.from_numpy(np.ascontiguousarray(w)).to(dev) for w in W]
+    bt = [None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in b]
+    eng.bind_params(Wt, bt)
+    inputs = None if not g.inputs.any() else torch.from_numpy(g.inputs).to(dev)
+    eng.bind_inputs(inputs)
+    if g.target is not None:
+        eng.bind_target(torch.from_numpy(g.target).to(dev))
+    return Wt, bt
+
+
+def run_call(eng, g, ci, call, acc_window=None, **kw):
+    """One golden call on the engine with the SAME injected normals that drove the reference."""
+    from montecarlopredictivecoding_amd import _lib as L
+    dev = _dev()
+    c = g.case
+    T = call["T"]
+    ls = g.loss_spec()
+    noise = g.noise(ci)
+    ext = None
+    if noise is not None:
+        ext = [torch.from_numpy(np.stack([noise(t, l) for t in range(T)])).to(dev) for l in range(len(c["sizes"]))]
+    up, acc = g.schedules(call)
+    if acc_window is None:
+        if acc:
+            acc_window = (acc[0], T)          # autograd keeps adding until the call ends (pc_trainer.py:853-862)
+        elif up:
+            acc_window = (up[-1], up[-1] + 1)
+        else:
+            acc_window = (0, T)               # .grad is never zeroed: sum over the whole call
+    res = eng.run(T, loss_kind=ls.kind, loss_var=ls.var, mask_start=ls.mask_start,
+                  xopt=L.XOPT_ADAM if call["xopt"] == "adam" else L.XOPT_SGD, lr=call["lr"],
+                  noise_mode=L.NOISE_EXTERNAL if ext is not None else L.NOISE_NONE,
+                  noise_var=call.get("noise_var", 2.0), ext_noise=ext,
+                  acc_begin=acc_window[0], acc_end=acc_window[1],
+                  # .grad is only zeroed by the schedules (pc_trainer.py:853-859): with neither an update
+                  # nor an accumulate list, a later call keeps adding to what the earlier call left
+                  acc_reset=not (ci > 0 and not acc and not up),
+                  energy_mode=L.ENERGY_ALL, rec_begin=0, rec_stride=1, rec_count=T, rec_x=True, rec_out=True, **kw)
+    return res, (up, acc)
+
+
+def check_against_golden(g, ci, call, res, eng, xs_final, sched, x_atol=3e-4, e_rtol=3e-5):
+    nc = g.case.get("rec_chains", None)
+    L_ = len(g.case["sizes"])
+    en = res.energies.cpu().numpy()
+    np.testing.assert_allclose(en[:, 1:1 + L_].sum(1), g.get(ci, "energy"), rtol=e_rtol, atol=1e-5)
+    np.testing.assert_allclose(en[:, 0], g.get(ci, "loss"), rtol=e_rtol, atol=1e-5)
+    np.testing.assert_allclose(en[:, -1], g.get(ci, "overall"), rtol=e_rtol, atol=1e-5)
+    for t in call.get("record_at", []):
+        for l in range(L_):
+            np.testing.assert_allclose(res.rec_x[l][t].cpu().numpy()[:nc], g.get(ci, f"x_t{t}_l{l}"), rtol=0, atol=x_atol)
+        if g.case["n_out"]:
+            np.testing.assert_allclose(res.rec_out[t].cpu().numpy()[:nc], g.get(ci, f"out_t{t}"), rtol=0, atol=3 * x_atol)
+    for l in range(L_):
+        np.testing.assert_allclose(xs_final[l].cpu().numpy()[:nc], g.get(ci, f"x_final_l{l}"), rtol=0, atol=x_atol)
+    # parameter gradients as the reference leaves them in .grad
+    up, acc = sched
+    B = g.case["B"]
+    scale = 1.0
+    if up:
+        scale = 1.0 / (len(acc) * B) if acc else 1.0 / B
+    for j in range(eng.n_lin):
+        n_out, n_in = eng.lin_shape(j)
+        dW = torch.empty(n_out, n_in, device=_dev())
+        db = torch.empty(n_out, device=_dev())
+        eng.read_param_grads(j, dW, db, scale=scale)
+        dW, db = dW.cpu().numpy(), db.cpu().numpy()
+        if g.has(ci, f"gW{j}"):
+            ref = g.get(ci, f"gW{j}")
+            np.testing.assert_allclose(dW, ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()))
+        if g.has(ci, f"gb{j}"):
+            ref = g.get(ci, f"gb{j}")
+            np.testing.assert_allclose(db, ref, rtol=2e-4, atol=1e-4 * max(1.0, np.abs(ref).max()))
+        if g.has(ci, f"gW{j}_idx"):
+            idx, ref = g.get(ci, f"gW{j}_idx"), g.get(ci, f"gW{j}_val")
+            scale_abs = g.get(ci, f"gW{j}_abs") / dW.size
+            np.testing.assert_allclose(dW.reshape(-1)[idx], ref, rtol=2e-3, atol=2e-3 * scale_abs)
+            np.testing.assert_allclose(np.abs(dW.astype(np.float64)).sum(), g.get(ci, f"gW{j}_abs"), rtol=2e-4)
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_engine_matches_reference_golden(name):
+    g = Golden(name)
+    eng = make_engine(g)
+    W, b = g.W, g.b
+    keep = bind(eng, g)
+    dev = _dev()
+    xs = [torch.from_numpy(x).to(dev) for x in g.X0]
+    for ci, call in enumerate(g.case["calls"]):
+        if call.get("sample_x", True):
+            xs = [torch.from_numpy(x).to(dev) for x in g.X0]
+        eng.load_state(xs)
+        res, sched = run_call(eng, g, ci, call)
+        xs = [torch.empty_like(x) for x in xs]
+        eng.store_state(xs)
+        torch.cuda.synchronize()
+        check_against_golden(g, ci, call, res, eng, xs, sched)
+        if sched[0]:   # the reference's optimizer_p changed the parameters: continue from its values
+            W = [g.get(ci, f"W{j}_after") for j in range(len(W))]
+            b = [g.get(ci, f"b{j}_after") if bb is not None else None for j, bb in enumerate(b)]
+            keep = bind(eng, g, W, b)   # noqa: F841
+    eng.close()
+
+
+def test_philox_bits_match_numpy():
+    from montecarlopredictivecoding_amd.engine import philox_normals
+    for (seed, step, layer, base, B, n) in [(0, 0, 0, 0, 7, 5), (0x123456789ABCDEF, 2 ** 33 + 5, 2, 4000, 64, 257),
+                                            (30, 4999, 1, 0, 129, 256)]:
+        raw = philox_normals(seed, step, layer, base, B, n, _dev(), raw=True).cpu().numpy().view(np.uint32)
+        ref = philox.layer_u32(seed, step, layer, base, B, n)
+        assert np.array_equal(raw, ref)
+        z = philox_normals(seed, step, layer, base, B, n, _dev()).cpu().numpy()
+        zr = philox.layer_normals(seed, step, layer, base, B, n)
+        np.testing.assert_allclose(z, zr, rtol=0, atol=2e-5)
+
+
+def test_philox_statistics():
+    from montecarlopredictivecoding_amd.engine import philox_normals
+    z = philox_normals(99, 12345, 0, 0, 8192, 512, _dev()).double().cpu().numpy().reshape(-1)
+    n = z.size
+    assert abs(z.mean()) < 5.0 / np.sqrt(n)
+    assert abs(z.var() - 1.0) < 5.0 * np.sqrt(2.0 / n)
+    assert abs((z ** 3).mean()) < 5.0 * np.sqrt(15.0 / n)
+    assert abs((z ** 4).mean() - 3.0) < 5.0 * np.sqrt(96.0 / n)
+    assert np.abs(z).max() < 6.5
