@@ -135,8 +135,9 @@ class Engine:
             update_x=True, noise_mode=L.NOISE_NONE, noise_var=2.0, seed=0, step_base=None, chain_base=0,
             ext_noise: Optional[Sequence[torch.Tensor]] = None,
             acc_begin=0, acc_end=0, acc_reset=True,
-            energy_mode=L.ENERGY_NONE,
+            energy_mode=L.ENERGY_NONE, energies_out: Optional[torch.Tensor] = None,
             rec_begin=0, rec_stride=1, rec_count=0, rec_x=False, rec_out=False) -> RunResult:
+        """``rec_x``: bool, or one bool per latent layer (record only those layers)."""
         n_steps = T - t_begin if n_steps is None else n_steps
         r = L.RunDesc()
         r.T, r.t_begin, r.n_steps = T, t_begin, n_steps
@@ -161,15 +162,22 @@ class Engine:
         r.energy_mode = energy_mode
         if energy_mode != L.ENERGY_NONE:
             rows = T if energy_mode == L.ENERGY_ALL else 1
-            res.energies = torch.zeros(rows, L.ENERGY_COLS, dtype=torch.float64, device=self.device)
+            if energies_out is None:
+                res.energies = torch.zeros(rows, L.ENERGY_COLS, dtype=torch.float64, device=self.device)
+            else:
+                _check_tensor(energies_out, (rows, L.ENERGY_COLS), self.device, "energies_out", torch.float64)
+                res.energies = energies_out
             r.energies_out = res.energies.data_ptr()
         r.rec_begin, r.rec_stride, r.rec_count = rec_begin, rec_stride, rec_count
         if rec_count > 0:
-            if rec_x:
-                for l in range(self.L):
+            want = [bool(rec_x)] * self.L if isinstance(rec_x, bool) else [bool(v) for v in rec_x]
+            for l in range(self.L):
+                if want[l]:
                     t = torch.empty(rec_count, self.batch, self.sizes[l], dtype=torch.float32, device=self.device)
                     res.rec_x.append(t)
                     r.rec_x[l] = t.data_ptr()
+                else:
+                    res.rec_x.append(None)
             if rec_out and self.n_out > 0:
                 res.rec_out = torch.empty(rec_count, self.batch, self.n_out, dtype=torch.float32, device=self.device)
                 r.rec_out = res.rec_out.data_ptr()

@@ -1,0 +1,693 @@
+"""PCTrainer -- host-side mirror of the reference trainer, driving the HIP engine.
+
+API parity target: /root/reference/predictive_coding/pc_trainer.py:22-1108 -- constructor keywords
+(:27-49), getters (:268-461), ``train_on_batch`` keywords and the ``results`` dict (:500-524,
+:682-694, :768-836), schedule strings (:1068-1108), assertion / warning behaviour (:144-264,
+:609-655, :199-220).
+
+How a call is executed
+----------------------
+``train_on_batch`` first *recognises* the call (``recognise.py``).  Three outcomes:
+
+fused     the whole T-step loop runs inside ``mcpc_run`` (libmcpc.so): network
+          Sequential[Linear, PCLayer, act, ...], quadratic energies, Gaussian / Bernoulli / masked /
+          no loss, SGD or Adam on x at every step, ``update_p_at`` in {'never','last'}, and either no
+          callback or this package's tagged ``random_step`` (fused as Philox noise).
+          This is every call pattern of the reference's scripts.
+stepwise  same network/loss, but arbitrary callbacks, ``update_p_at='all'``, custom x optimizers
+          (any torch optimizer), dynamic x-lr ...: per step the HIP kernel produces dF/dx and
+          dF/dtheta (``update_x=0``), the reference's control flow around them is replayed with the
+          user's torch optimizers and callbacks.
+rejected  anything the kernels do not express (S/M masks, non-quadratic ``energy_fn``, ``loss_x_fn``,
+          optimised inputs, non-Sequential models ...) raises ``NotImplementedError`` naming the
+          reason.  There is no silent torch or CPU execution of the loop.
+"""
+import typing
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from .. import _lib as L
+from ..engine import Engine
+from . import recognise
+from .pc_layer import PCLayer
+
+
+# Philox step counter shared by every trainer of the process: consecutive calls never reuse noise,
+# and all ranks of a sharded job (same sequence of calls) stay in lock-step.
+_PHILOX_STEPS = [0]
+# engines are keyed by (network shape, batch, device) and shared between trainers of one model
+# (the scripts build a PC and an MCPC trainer over the same nn.Sequential).
+_ENGINES = {}
+
+
+def _take_philox_steps(n):
+    base = _PHILOX_STEPS[0]
+    _PHILOX_STEPS[0] += int(n)
+    return base
+
+
+def slow_down_warning(base, prop, solution):
+    """Same message as the reference (predictive_coding/utils.py:8-16)."""
+    warnings.warn(
+        "In {}, you have {} enabled, this will slow down training. Set to {} to disable it. ".format(base, prop, solution),
+        category=RuntimeWarning)
+
+
+class PCTrainer(object):
+    """Trainer for predictive-coding networks built from :class:`PCLayer`."""
+
+    def __init__(
+        self,
+        model: nn.Module,
+        optimizer_x_fn: typing.Callable = optim.SGD,
+        optimizer_x_kwargs: dict = {"lr": 0.1},
+        manual_optimizer_x_fn: typing.Callable = None,
+        x_lr_amplifier: float = 1.0,
+        x_lr_discount: float = 1.0,
+        loss_x_fn: typing.Callable = None,
+        loss_inputs_fn: typing.Callable = None,
+        optimizer_p_fn: typing.Callable = optim.Adam,
+        optimizer_p_kwargs: dict = {"lr": 0.001},
+        manual_optimizer_p_fn: typing.Callable = None,
+        T: int = 512,
+        update_x_at: typing.Union[str, typing.List[int]] = "all",
+        update_p_at: typing.Union[str, typing.List[int]] = "all",
+        accumulate_p_at: typing.Union[str, typing.List[int]] = "never",
+        energy_coefficient: float = 1.0,
+        early_stop_condition: str = "False",
+        update_p_at_early_stop: bool = True,
+        plot_progress_at: typing.Union[str, typing.List[int]] = "all",
+        is_disable_warning_energy_from_different_batch_sizes: bool = False,
+    ):
+        assert isinstance(model, nn.Module)
+        self._model = model
+        assert callable(optimizer_x_fn)
+        assert isinstance(optimizer_x_kwargs, dict)
+        self._optimizer_x_fn, self._optimizer_x_kwargs = optimizer_x_fn, optimizer_x_kwargs
+        if manual_optimizer_x_fn is not None:
+            assert callable(manual_optimizer_x_fn)
+        self._manual_optimizer_x_fn = manual_optimizer_x_fn
+        self._optimizer_x = None
+        assert isinstance(x_lr_discount, float) and x_lr_discount <= 1.0
+        assert isinstance(x_lr_amplifier, float) and x_lr_amplifier >= 1.0
+        self._x_lr_discount, self._x_lr_amplifier = x_lr_discount, x_lr_amplifier
+        for fn, what in ((loss_x_fn, "loss_x_fn"), (loss_inputs_fn, "loss_inputs_fn")):
+            if fn is not None:
+                assert callable(fn)
+                assert self.get_is_model_has_pc_layers(), f"<{what}> should only work with models with <PCLayer>. "
+        self._loss_x_fn, self._loss_inputs_fn = loss_x_fn, loss_inputs_fn
+        assert callable(optimizer_p_fn)
+        assert isinstance(optimizer_p_kwargs, dict)
+        self._optimizer_p_fn, self._optimizer_p_kwargs = optimizer_p_fn, optimizer_p_kwargs
+        if manual_optimizer_p_fn is not None:
+            assert callable(manual_optimizer_p_fn)
+        self._manual_optimizer_p_fn = manual_optimizer_p_fn
+        self.recreate_optimize_p()
+        assert isinstance(T, int) and T > 0
+        self._T = T
+        if self.get_is_model_has_pc_layers():
+            if self._T < self.get_num_pc_layers() + 1:
+                warnings.warn(
+                    "You should always choose T such that T >= (<pc_trainer.get_num_pc_layers()> + 1), "
+                    "as it ensures that the error can be PC-propagated through the network.", category=RuntimeWarning)
+            min_t = self.get_least_T()
+            if self._T < min_t:
+                warnings.warn(
+                    f"If you have one pc_layer per layer, T={self._T} is too small. Please use a minimum T of {min_t}, "
+                    "which is just enough to PC-propagate the error through the network and have all weigths updated "
+                    "based on these PC-propagated errors. In practice, you normally should have T much larger than this minimum T. ",
+                    category=RuntimeWarning)
+        self._update_x_at = self._preprocess_step_index_list(indices=update_x_at, T=self._T)
+        self._update_p_at = self._preprocess_step_index_list(indices=update_p_at, T=self._T)
+        self._accumulate_p_at = self._preprocess_step_index_list(indices=accumulate_p_at, T=self._T)
+        assert isinstance(energy_coefficient, float)
+        self._energy_coefficient = energy_coefficient
+        assert isinstance(early_stop_condition, str)
+        self._early_stop_condition = early_stop_condition
+        assert isinstance(update_p_at_early_stop, bool)
+        self._update_p_at_early_stop = update_p_at_early_stop
+        if isinstance(plot_progress_at, str):
+            assert plot_progress_at in ["all"]
+        elif isinstance(plot_progress_at, list):
+            for h in plot_progress_at:
+                assert isinstance(h, int)
+        else:
+            raise NotImplementedError
+        self._plot_progress_at = plot_progress_at
+        self._is_plot_progress = not (isinstance(plot_progress_at, list) and len(plot_progress_at) == 0)
+        assert isinstance(is_disable_warning_energy_from_different_batch_sizes, bool)
+        self.is_disable_warning_energy_from_different_batch_sizes = is_disable_warning_energy_from_different_batch_sizes
+
+        # ---- engine-side state (no counterpart in the reference) ------------------------------------
+        self._param_versions = None
+        self.mcpc_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF   # Philox key; follows torch.manual_seed
+        self.mcpc_chain_base = 0              # global id of this shard's first chain
+        self.mcpc_process_group = None        # torch.distributed group for the Hebbian all-reduce (or None)
+        self.mcpc_world_batch = None          # global batch for the 1/(n*B) normalisation when sharded
+        self.mcpc_sharded = False
+        self.mcpc_materialize_unused_grads = False   # reference quirk: autograd fills .grad even if never used
+        self.last_call_mode = None            # 'fused' | 'stepwise' (for tests / diagnostics)
+
+    # ---- getters & setters (reference :268-461) -------------------------------------------------------
+    def get_T(self) -> int:
+        return self._T
+
+    def get_model(self) -> nn.Module:
+        return self._model
+
+    def get_optimizer_x(self) -> optim.Optimizer:
+        return self._optimizer_x
+
+    def get_optimizer_x_lr(self):
+        for group in self._optimizer_x.param_groups:
+            return group["lr"]
+
+    def set_optimizer_x(self, optimizer_x: optim.Optimizer) -> None:
+        assert isinstance(optimizer_x, optim.Optimizer)
+        self._optimizer_x = optimizer_x
+
+    def set_optimizer_x_lr(self, lr: float) -> None:
+        for group in self._optimizer_x.param_groups:
+            group["lr"] = lr
+
+    def get_optimizer_p(self) -> optim.Optimizer:
+        return self._optimizer_p
+
+    def set_optimizer_p(self, optimizer_p: optim.Optimizer) -> None:
+        assert isinstance(optimizer_p, optim.Optimizer)
+        self._optimizer_p = optimizer_p
+
+    def get_model_pc_layers(self) -> typing.Generator[PCLayer, None, None]:
+        for module in self._model.modules():
+            if isinstance(module, PCLayer):
+                yield module
+
+    def get_named_model_pc_layers(self):
+        for name, module in self._model.named_modules():
+            if isinstance(module, PCLayer):
+                yield name, module
+
+    def get_is_model_has_pc_layers(self) -> bool:
+        return any(True for _ in self.get_model_pc_layers())
+
+    def get_model_pc_layers_training(self) -> list:
+        return [layer.training for layer in self.get_model_pc_layers()]
+
+    def get_is_model_training(self):
+        flags = self.get_model_pc_layers_training()
+        if self._model.training and all(flags):
+            return True
+        if (not self._model.training) and not any(flags):
+            return False
+        return None
+
+    def get_energies(self, is_per_datapoint: bool = False, named_layers: bool = False):
+        energies, batch_sizes = {}, []
+        for name, layer in self.get_named_model_pc_layers():
+            energy = layer.energy_per_datapoint() if is_per_datapoint else layer.energy()
+            if energy is not None:
+                energies[name] = energy
+                batch_sizes.append(energy.size(0) if is_per_datapoint else energy.size())
+        assert len(energies) > 0, "You don't have any pc_layers or none of them is holding energy. "
+        if (not self.is_disable_warning_energy_from_different_batch_sizes) and batch_sizes.count(batch_sizes[0]) != len(batch_sizes):
+            warnings.warn(f"You pc_layers hold energy of different batch_sizes: {batch_sizes}.", category=RuntimeWarning)
+        return energies if named_layers else list(energies.values())
+
+    def get_model_xs(self, is_warning_x_not_initialized=True) -> typing.Generator[nn.Parameter, None, None]:
+        for layer in self.get_model_pc_layers():
+            x = layer.get_x()
+            if x is not None:
+                yield x
+            elif is_warning_x_not_initialized:
+                warnings.warn(
+                    "While you are getting x from all pc layers (calling <pc_trainer.get_model_xs()>), some pc layers has "
+                    "not been initialized yet (i.e., has x being None). This potentially causes bugs. ", category=RuntimeWarning)
+
+    def get_model_parameters(self) -> typing.Generator[nn.Parameter, None, None]:
+        xs = list(self.get_model_xs(is_warning_x_not_initialized=False))
+        for param in self._model.parameters():
+            if not any(param is x for x in xs):
+                yield param
+
+    def get_numparameters(self, is_gen=True):
+        params = list(self.get_model_parameters())
+        return sum(p.numel() for i, p in enumerate(params) if not (is_gen and i == 0))
+
+    def get_weights_norms(self):
+        weights_abs, mu_abs = [], []
+        for par in self.get_model_parameters():
+            (mu_abs if par.dim() == 1 else weights_abs).append(par.abs().mean())
+        return weights_abs, mu_abs
+
+    def get_model_representations(self):
+        return self._model[1].get_x()          # reference hard-codes model[1] (pc_trainer.py:437-438)
+
+    def get_model_xs_copy(self):
+        return [x.clone().detach().cpu() for x in self.get_model_xs()]
+
+    def get_num_pc_layers(self) -> int:
+        return sum(1 for _ in self.get_model_pc_layers())
+
+    def get_least_T(self) -> int:
+        return self.get_num_pc_layers() + 1
+
+    def recreate_optimize_x(self) -> None:
+        if self._manual_optimizer_x_fn is None:
+            self._optimizer_x = self._optimizer_x_fn(self.get_model_xs(), **self._optimizer_x_kwargs)
+        else:
+            self._optimizer_x = self._manual_optimizer_x_fn()
+
+    def recreate_optimize_p(self) -> None:
+        if self._manual_optimizer_p_fn is None:
+            self._optimizer_p = self._optimizer_p_fn(self.get_model_parameters(), **self._optimizer_p_kwargs)
+        else:
+            self._optimizer_p = self._manual_optimizer_p_fn()
+
+    # ---- distributed sharding (no counterpart in the reference: it is single-device) -------------------
+    def set_shard(self, process_group=None, chain_base: int = 0, world_batch: typing.Optional[int] = None):
+        """Declare that this trainer holds one shard of a larger batch of chains.
+
+        ``chain_base``  global index of the first local chain (keeps Philox noise independent of the sharding),
+        ``world_batch`` total number of chains over all shards (the reference divides grads by ``len(inputs)``),
+        ``process_group`` the group whose members' Hebbian sums are all-reduced once per learning call.
+        """
+        self.mcpc_process_group = process_group
+        self.mcpc_chain_base = int(chain_base)
+        self.mcpc_world_batch = world_batch
+        self.mcpc_sharded = True
+
+    # ---- the call --------------------------------------------------------------------------------------
+    def train_on_batch(
+        self,
+        inputs: typing.Any,
+        loss_fn: typing.Callable = None,
+        loss_fn_kwargs: dict = {},
+        is_sample_x_at_batch_start: bool = True,
+        is_reset_optimizer_x_at_batch_start: bool = True,
+        is_reset_optimizer_p_at_batch_start: bool = False,
+        is_unwrap_inputs: bool = False,
+        is_optimize_inputs: bool = False,
+        callback_after_backward: typing.Callable = None,
+        callback_after_backward_kwargs: dict = {},
+        callback_after_t: typing.Callable = None,
+        callback_after_t_kwargs: dict = {},
+        is_log_progress: bool = True,
+        is_return_results_every_t: bool = True,
+        is_checking_after_callback_after_t: bool = True,
+        debug: dict = {},
+        backward_kwargs: dict = {},
+        is_clear_energy_after_use: bool = False,
+        is_return_outputs: bool = False,
+        is_return_representations: bool = False,
+        is_return_xs: bool = False,
+        is_return_batchelement_loss: bool = False,
+    ):
+        """Run T inference steps on one batch (reference pc_trainer.py:500-1064).  Returns the results dict."""
+        self.inputs = inputs
+        assert self.get_is_model_training() == True, (  # noqa: E712  (three-valued: True / False / None)
+            "PCLayer behaves differently in train and eval modes, like Dropout or Batch Normalization. "
+            "Make sure your model is in train mode before calling <train_on_batch()>. It can be done by calling <model.train()>. ")
+        if loss_fn is not None:
+            assert callable(loss_fn)
+        assert isinstance(loss_fn_kwargs, dict)
+        for flag in (is_sample_x_at_batch_start, is_reset_optimizer_x_at_batch_start, is_reset_optimizer_p_at_batch_start,
+                     is_unwrap_inputs, is_optimize_inputs, is_log_progress, is_return_results_every_t,
+                     is_return_outputs, is_return_representations, is_return_xs):
+            assert isinstance(flag, bool)
+        if is_unwrap_inputs:
+            assert isinstance(inputs, (tuple, list, dict))
+        if is_optimize_inputs:
+            assert self.get_is_model_has_pc_layers(), "<is_optimize_inputs> should only work with models with <PCLayer>. "
+            assert not is_unwrap_inputs
+        for cb in (callback_after_backward, callback_after_t):
+            if cb is not None:
+                assert callable(cb)
+        assert isinstance(callback_after_backward_kwargs, dict)
+        assert isinstance(callback_after_t_kwargs, dict)
+        assert isinstance(debug, dict)
+        if is_log_progress:
+            slow_down_warning("PCTrainer.train_on_batch", "is_log_progress", "False")
+        if self._is_plot_progress:
+            raise NotImplementedError(
+                "plot_progress is a plotting feature of the reference (seaborn/pandas PNGs behind an input() prompt) and is out "
+                "of scope of this engine: construct the trainer with plot_progress_at=[] as every reference script does.")
+        if is_return_results_every_t:
+            slow_down_warning("PCTrainer.train_on_batch", "is_return_results_every_t", "False")
+
+        plan, why_not_fused = self._plan(inputs, loss_fn, loss_fn_kwargs, is_unwrap_inputs, is_optimize_inputs,
+                                         callback_after_backward, callback_after_t, callback_after_t_kwargs,
+                                         backward_kwargs, is_clear_energy_after_use, is_return_batchelement_loss)
+        if plan is None:
+            raise NotImplementedError("this call cannot be executed by the MCPC HIP engine: " + why_not_fused)
+        common = dict(inputs=inputs, loss_fn=loss_fn, is_sample_x_at_batch_start=is_sample_x_at_batch_start,
+                      is_reset_optimizer_x_at_batch_start=is_reset_optimizer_x_at_batch_start,
+                      is_reset_optimizer_p_at_batch_start=is_reset_optimizer_p_at_batch_start,
+                      is_return_results_every_t=is_return_results_every_t, is_return_outputs=is_return_outputs,
+                      is_return_representations=is_return_representations, is_return_xs=is_return_xs)
+        if plan["mode"] == "fused":
+            self.last_call_mode = "fused"
+            return self._run_fused(plan, **common)
+        self.last_call_mode = "stepwise"
+        return self._run_stepwise(plan, callback_after_backward=callback_after_backward,
+                                  callback_after_backward_kwargs=callback_after_backward_kwargs,
+                                  callback_after_t=callback_after_t, callback_after_t_kwargs=callback_after_t_kwargs,
+                                  is_checking_after_callback_after_t=is_checking_after_callback_after_t, **common)
+
+    # ---- recognition ------------------------------------------------------------------------------------
+    def _plan(self, inputs, loss_fn, loss_fn_kwargs, is_unwrap_inputs, is_optimize_inputs, callback_after_backward,
+              callback_after_t, callback_after_t_kwargs, backward_kwargs, is_clear_energy_after_use,
+              is_return_batchelement_loss):
+        """Returns (plan dict, "") or (None, reason).  plan['mode'] is 'fused' or 'stepwise'."""
+        net, why = recognise.describe_model(self._model)
+        if net is None:
+            return None, why
+        if is_unwrap_inputs or is_optimize_inputs:
+            return None, "is_unwrap_inputs / is_optimize_inputs are not supported"
+        if self._loss_x_fn is not None or self._loss_inputs_fn is not None:
+            return None, "loss_x_fn / loss_inputs_fn are not supported"
+        if self._energy_coefficient != 1.0:
+            return None, "energy_coefficient != 1 is not supported"
+        if self._early_stop_condition.strip() != "False":
+            return None, "early_stop_condition other than 'False' is not supported"
+        if backward_kwargs or is_clear_energy_after_use or is_return_batchelement_loss:
+            return None, "backward_kwargs / is_clear_energy_after_use / is_return_batchelement_loss are not supported"
+        if not isinstance(inputs, torch.Tensor) or inputs.dim() != 2 or inputs.shape[1] != net.n_in:
+            return None, f"inputs must be a [batch, {net.n_in}] tensor"
+        if inputs.dtype != torch.float32:
+            return None, "inputs must be float32"
+        device = net.linears[0].weight.device
+        if device.type != "cuda":
+            raise L.MCPCLibraryError(
+                "the model lives on %s: the MCPC engine runs on an MI355X only (move the model and inputs to 'cuda'); "
+                "there is no CPU path" % device)
+        if inputs.device != device:
+            return None, f"inputs on {inputs.device}, model on {device}"
+        B = inputs.shape[0]
+        loss, why = recognise.describe_loss(loss_fn, loss_fn_kwargs, net.n_out, B, device)
+        if loss is None:
+            return None, why
+        if loss.target is not None:
+            if tuple(loss.target.shape) != (B, net.n_out):
+                return None, f"_target must have shape {(B, net.n_out)}"
+        plan = dict(net=net, loss=loss, B=B, device=device)
+        # ---- can the whole loop be fused? otherwise fall to the step-wise HIP path
+        reasons = []
+        xopt, why = (None, "manual_optimizer_x_fn is set") if self._manual_optimizer_x_fn is not None else \
+            recognise.describe_x_optimizer(self._optimizer_x_fn, self._optimizer_x_kwargs)
+        if xopt is None:
+            reasons.append(why)
+        if self._x_lr_discount < 1.0 or self._x_lr_amplifier > 1.0:
+            reasons.append("dynamic x learning rate")
+        if self._update_x_at != list(range(self._T)):
+            reasons.append("update_x_at is not 'all'")
+        if self._update_p_at not in ([], [self._T - 1]):
+            reasons.append("update_p_at is neither 'never' nor 'last'")
+        if callback_after_backward is not None:
+            reasons.append("callback_after_backward is set")
+        noise_var, why = recognise.describe_callback(callback_after_t, callback_after_t_kwargs, self)
+        if why:
+            reasons.append(why)
+        if noise_var is not None and xopt is not None and xopt.kind != L.XOPT_SGD:
+            reasons.append("Langevin noise through a non-SGD x optimizer")
+        plan["xopt"], plan["noise_var"] = xopt, noise_var
+        plan["mode"] = "stepwise" if reasons else "fused"
+        plan["why_stepwise"] = "; ".join(reasons)
+        return plan, ""
+
+    # ---- engine plumbing ----------------------------------------------------------------------------------
+    def _engine_for(self, plan) -> Engine:
+        net, B, device = plan["net"], plan["B"], plan["device"]
+        key = net.key(B, device)
+        eng = _ENGINES.get(key)
+        if eng is None:
+            eng = Engine(net.sizes, net.acts, net.n_in, net.n_out, B, device=device, ecoef=net.ecoef)
+            _ENGINES[key] = eng
+        return eng
+
+    def _sync_params(self, eng: Engine, net, force=False):
+        """(Re)bind + re-pack the Linear parameters when their storage or contents changed."""
+        sig = tuple((lin.weight.data_ptr(), lin.weight._version,
+                     None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version)) for lin in net.linears)
+        sig = (id(eng),) + sig
+        if force or sig != self._param_versions:
+            for lin in net.linears:
+                if not lin.weight.is_contiguous():
+                    lin.weight.data = lin.weight.data.contiguous()
+            eng.bind_params([lin.weight.data for lin in net.linears],
+                            [None if lin.bias is None else lin.bias.data for lin in net.linears])
+            self._param_versions = sig
+
+    def _initial_state(self, plan, inputs, is_sample_x_at_batch_start):
+        """Draw / validate x exactly as the first forward of the reference does (pc_trainer.py:717-733,
+        pc_layer.py:185-233): one torch forward through the Sequential with the sampling flags set,
+        which honours arbitrary ``sample_x_fn`` callables and their RNG draw order."""
+        net = plan["net"]
+        layers = net.pc_layers
+        need = is_sample_x_at_batch_start
+        if not need:
+            # shapes are only known after Linear j; check against the expected [B, n_l]
+            for l, layer in enumerate(layers):
+                x = layer.get_x()
+                if x is None or x.device != plan["device"] or tuple(x.shape) != (plan["B"], net.sizes[l]):
+                    need = True     # the layer's own forward emits the reference's RuntimeWarning
+        if need:
+            if is_sample_x_at_batch_start:
+                for layer in layers:
+                    layer.set_is_sample_x(True)
+            with torch.no_grad():
+                self._model(inputs)
+        xs = []
+        for layer in layers:
+            x = layer.get_x()
+            if x.dtype != torch.float32:
+                raise NotImplementedError("latent state must be float32")
+            if not x.is_contiguous():
+                x.data = x.data.contiguous()
+            xs.append(x)
+        return xs
+
+    def _grad_window(self):
+        """First step whose parameter gradients survive to the end of the call (pc_trainer.py:853-862):
+        ``.grad`` is zeroed at accumulate_p_at[0] and at an update step outside accumulate_p_at, and
+        autograd adds every step after that.  None = never zeroed in this call (carries over)."""
+        T, up, acc = self._T, self._update_p_at, self._accumulate_p_at
+        start = None
+        if acc:
+            start = acc[0]
+        for t in up:
+            if t not in acc:
+                start = t if start is None else max(start, t)
+        return start
+
+    def _collect_results(self, plan, res, T, is_return_results_every_t, is_return_outputs, is_return_representations,
+                         is_return_xs, loss_fn):
+        net = plan["net"]
+        results = {"loss": [], "energy": [], "overall": []}
+        en = res.energies.cpu().numpy()            # the one host sync of the call
+        rows = range(T) if is_return_results_every_t else [0]
+        nl = len(net.sizes)
+        for r in rows:
+            if loss_fn is not None:
+                results["loss"].append(float(en[r, 0]))
+            results["energy"].append(float(en[r, 1:1 + nl].sum()))
+            results["overall"].append(float(en[r, -1]))
+        n_rec = T if is_return_results_every_t else 1
+        if is_return_outputs:
+            src = res.rec_out if net.n_out > 0 else res.rec_x[-1]
+            results["outputs"] = [src[k] for k in range(n_rec)]
+        if is_return_representations:
+            host = res.rec_x[0].cpu()
+            results["representations"] = [host[k] for k in range(n_rec)]
+        if is_return_xs:
+            hosts = [r_.cpu() for r_ in res.rec_x]
+            results["xs"] = [[h[k] for h in hosts] for k in range(n_rec)]
+        return results
+
+    def _apply_p_step(self, plan, eng, net, n_acc):
+        """Normalise (pc_trainer.py:905-913), all-reduce across shards, hand to the user's optimizer_p."""
+        B_global = self.mcpc_world_batch if self.mcpc_world_batch is not None else plan["B"]
+        scale = 1.0 / (n_acc * B_global) if n_acc > 0 else 1.0 / B_global
+        flat = eng.read_param_grads_flat(scale=scale)
+        if self.mcpc_sharded and torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(flat, group=self.mcpc_process_group)     # RCCL: one bucket per call
+        off = 0
+        for lin in net.linears:
+            n = lin.weight.numel()
+            lin.weight.grad = flat[off:off + n].view_as(lin.weight)
+            off += n
+            if lin.bias is not None:
+                lin.bias.grad = flat[off:off + lin.bias.numel()].view_as(lin.bias)
+                off += lin.bias.numel()
+        self._optimizer_p.step()
+
+    # ---- fused path ---------------------------------------------------------------------------------------
+    def _run_fused(self, plan, inputs, loss_fn, is_sample_x_at_batch_start, is_reset_optimizer_x_at_batch_start,
+                   is_reset_optimizer_p_at_batch_start, is_return_results_every_t, is_return_outputs,
+                   is_return_representations, is_return_xs):
+        net, loss, xopt, T = plan["net"], plan["loss"], plan["xopt"], self._T
+        eng = self._engine_for(plan)
+        xs = self._initial_state(plan, inputs, is_sample_x_at_batch_start)
+        if is_sample_x_at_batch_start or is_reset_optimizer_x_at_batch_start or self._optimizer_x is None:
+            self.recreate_optimize_x()          # kept for API compatibility (get_optimizer_x); never stepped here
+        if is_reset_optimizer_p_at_batch_start:
+            self.recreate_optimize_p()
+        self._sync_params(eng, net)
+        eng.bind_inputs(None if not bool(inputs.any()) else inputs.contiguous())
+        if loss.target is not None:
+            tgt = loss.target
+            if tgt.dtype != torch.float32 or not tgt.is_contiguous() or tgt.device != plan["device"]:
+                tgt = tgt.to(device=plan["device"], dtype=torch.float32).contiguous()
+            eng.bind_target(tgt)
+        eng.load_state([x.data for x in xs])
+
+        do_update = self._T - 1 in self._update_p_at
+        start = self._grad_window()
+        want_grads = do_update or self.mcpc_materialize_unused_grads
+        acc_begin, acc_end, acc_reset = 0, 0, True
+        if want_grads:
+            acc_begin, acc_end = (0 if start is None else start), T
+            acc_reset = start is not None
+        n_rec = T if is_return_results_every_t else 1
+        rec_begin = 0 if is_return_results_every_t else T - 1
+        rec_layers = [False] * len(net.sizes)
+        if is_return_xs:
+            rec_layers = [True] * len(net.sizes)
+        if is_return_representations:
+            rec_layers[0] = True
+        if is_return_outputs and net.n_out == 0:
+            rec_layers[-1] = True
+        any_rec = any(rec_layers) or (is_return_outputs and net.n_out > 0)
+        res = eng.run(
+            T, loss_kind=loss.kind, loss_var=loss.var, mask_start=loss.mask_start,
+            xopt=xopt.kind, lr=xopt.lr, betas=xopt.betas, eps=xopt.eps,
+            noise_mode=L.NOISE_PHILOX if plan["noise_var"] is not None else L.NOISE_NONE,
+            noise_var=0.0 if plan["noise_var"] is None else plan["noise_var"],
+            seed=self.mcpc_seed, step_base=_take_philox_steps(T), chain_base=self.mcpc_chain_base,
+            acc_begin=acc_begin, acc_end=acc_end, acc_reset=acc_reset,
+            energy_mode=L.ENERGY_ALL if is_return_results_every_t else L.ENERGY_LAST,
+            rec_begin=rec_begin, rec_stride=1, rec_count=n_rec if any_rec else 0,
+            rec_x=rec_layers, rec_out=is_return_outputs and net.n_out > 0)
+        eng.store_state([x.data for x in xs])
+        if do_update:
+            self._apply_p_step(plan, eng, net, len(self._accumulate_p_at))
+            self._sync_params(eng, net, force=True)
+        elif self.mcpc_materialize_unused_grads:
+            for j, lin in enumerate(net.linears):
+                if lin.weight.grad is None:
+                    lin.weight.grad = torch.zeros_like(lin.weight)
+                if lin.bias is not None and lin.bias.grad is None:
+                    lin.bias.grad = torch.zeros_like(lin.bias)
+                eng.read_param_grads(j, lin.weight.grad, None if lin.bias is None else lin.bias.grad, 1.0,
+                                     accumulate=start is None)
+        return self._collect_results(plan, res, T, is_return_results_every_t, is_return_outputs,
+                                     is_return_representations, is_return_xs, loss_fn)
+
+    # ---- step-wise path -------------------------------------------------------------------------------------
+    def _run_stepwise(self, plan, inputs, loss_fn, is_sample_x_at_batch_start, is_reset_optimizer_x_at_batch_start,
+                      is_reset_optimizer_p_at_batch_start, is_return_results_every_t, is_return_outputs,
+                      is_return_representations, is_return_xs, callback_after_backward, callback_after_backward_kwargs,
+                      callback_after_t, callback_after_t_kwargs, is_checking_after_callback_after_t):
+        """Reference control flow (pc_trainer.py:712-981) with the HIP kernel as the gradient engine."""
+        net, loss, T = plan["net"], plan["loss"], self._T
+        eng = self._engine_for(plan)
+        xs = self._initial_state(plan, inputs, is_sample_x_at_batch_start)
+        if is_sample_x_at_batch_start or is_reset_optimizer_x_at_batch_start or self._optimizer_x is None:
+            self.recreate_optimize_x()
+        if is_reset_optimizer_p_at_batch_start:
+            self.recreate_optimize_p()
+        eng.bind_inputs(None if not bool(inputs.any()) else inputs.contiguous())
+        if loss.target is not None:
+            eng.bind_target(loss.target.to(device=plan["device"], dtype=torch.float32).contiguous())
+        results = {"loss": [], "energy": [], "overall": []}
+        if is_return_outputs:
+            results["outputs"] = []
+        if is_return_representations:
+            results["representations"] = []
+        if is_return_xs:
+            results["xs"] = []
+        dynamic_lr = self._x_lr_discount < 1.0 or self._x_lr_amplifier > 1.0
+        overalls = []
+        energies = torch.zeros(T, L.ENERGY_COLS, dtype=torch.float64, device=plan["device"])
+        params = [p for lin in net.linears for p in ([lin.weight] if lin.bias is None else [lin.weight, lin.bias])]
+        nl = len(net.sizes)
+        B_global = self.mcpc_world_batch if self.mcpc_world_batch is not None else plan["B"]
+        for t in range(T):
+            self._sync_params(eng, net)
+            eng.load_state([x.data for x in xs])
+            keep = is_return_results_every_t or t == T - 1
+            res = eng.run(T, t_begin=t, n_steps=1, loss_kind=loss.kind, loss_var=loss.var, mask_start=loss.mask_start,
+                          xopt=L.XOPT_SGD, lr=1.0, update_x=False, acc_begin=t, acc_end=t + 1, acc_reset=True,
+                          energy_mode=L.ENERGY_ALL, energies_out=energies,
+                          rec_begin=t, rec_stride=1, rec_count=1 if (keep and is_return_outputs and net.n_out > 0) else 0,
+                          rec_x=False, rec_out=True)
+            if keep:
+                if is_return_outputs:
+                    results["outputs"].append(res.rec_out[0] if net.n_out > 0 else xs[-1].detach().clone())
+                if is_return_representations:
+                    results["representations"].append(self.get_model_representations().clone().detach().cpu())
+                if is_return_xs:
+                    results["xs"].append(self.get_model_xs_copy())
+                row = energies[t].cpu().numpy()
+                if loss_fn is not None:
+                    results["loss"].append(float(row[0]))
+                results["energy"].append(float(row[1:1 + nl].sum()))
+                results["overall"].append(float(row[-1]))
+            if dynamic_lr:
+                overalls.append(float(energies[t, -1]))
+            # zero_grad schedule (pc_trainer.py:848-859)
+            if t in self._update_x_at:
+                self._optimizer_x.zero_grad()
+            if (t in self._update_p_at and t not in self._accumulate_p_at) or \
+                    (self._accumulate_p_at and t == self._accumulate_p_at[0]):
+                self._optimizer_p.zero_grad()
+            # "backward": dF/dx from the kernel, dF/dtheta added into .grad like autograd does
+            for x, g in zip(xs, res.xgrad):
+                x.grad = g if x.grad is None else x.grad.add_(g)
+            for j, lin in enumerate(net.linears):
+                if lin.weight.grad is None:
+                    lin.weight.grad = torch.zeros_like(lin.weight)
+                if lin.bias is not None and lin.bias.grad is None:
+                    lin.bias.grad = torch.zeros_like(lin.bias)
+                eng.read_param_grads(j, lin.weight.grad, None if lin.bias is None else lin.bias.grad, 1.0, accumulate=True)
+            if callback_after_backward is not None:
+                callback_after_backward(t, **callback_after_backward_kwargs)
+            if t in self._update_x_at:
+                self._optimizer_x.step()
+                if dynamic_lr and len(overalls) >= 2:
+                    factor = self._x_lr_discount if not (overalls[-1] < overalls[-2]) else self._x_lr_amplifier
+                    if factor != 1.0:
+                        for group in self._optimizer_x.param_groups:
+                            group["lr"] = group["lr"] * factor
+            if t in self._update_p_at:
+                div = len(self._accumulate_p_at) * B_global if self._accumulate_p_at else B_global
+                for p in params:
+                    p.grad = p.grad / div
+                self._optimizer_p.step()
+            if callback_after_t is not None:
+                callback_after_t(t, **callback_after_t_kwargs)
+                if is_checking_after_callback_after_t:
+                    slow_down_warning("PCTrainer.train_on_batch", "is_checking_after_callback_after_t", "False")
+                    if not (self.get_is_model_training() == True):  # noqa: E712
+                        raise RuntimeError(
+                            "If you do <model.eval()> in <callback_after_t()>, you need to put model back to train mode "
+                            "when leaving <callback_after_t()>. ")
+        return results
+
+    # ---- schedules (reference :1068-1108) ---------------------------------------------------------------------
+    def _preprocess_step_index_list(self, indices: typing.Union[str, typing.List[int]], T: int) -> typing.List[int]:
+        assert isinstance(indices, (str, list))
+        assert isinstance(T, int) and T > 0
+        if isinstance(indices, str):
+            table = {"all": lambda: list(range(T)), "last": lambda: [T - 1],
+                     "last_half": lambda: list(range(T // 2, T)), "never": lambda: []}
+            if indices not in table:
+                raise NotImplementedError
+            return table[indices]()
+        for t in indices:
+            assert isinstance(t, (int, np.integer))
+            assert 0 <= t < T
+        return indices

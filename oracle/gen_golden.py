@@ -49,7 +49,7 @@ from oracle import philox  # noqa: E402
 from oracle.cases import make_case_inputs  # noqa: E402
 
 
-def build_reference_model(pc, case, W, b, X0):
+def build_reference_model(pc, case, W, b, X0, device="cpu"):
     import torch
     import torch.nn as nn
     acts = {"identity": None, "relu": nn.ReLU, "tanh": nn.Tanh}
@@ -62,7 +62,7 @@ def build_reference_model(pc, case, W, b, X0):
         lin = nn.Linear(dims[l], dims[l + 1], bias=b[l] is not None)
         mods.append(lin)
         c = case["ecoef"][l]
-        x0 = torch.from_numpy(X0[l].copy())
+        x0 = torch.from_numpy(X0[l].copy()).to(device)
         kw = dict(sample_x_fn=(lambda inp, x0=x0: x0.clone()))
         if c != 1.0:
             kw["energy_fn"] = (lambda inputs, c=c: c * 0.5 * (inputs["mu"] - inputs["x"]) ** 2)
@@ -80,17 +80,18 @@ def build_reference_model(pc, case, W, b, X0):
             if b[j] is not None:
                 lin.bias.copy_(torch.from_numpy(b[j]))
     model.train()
+    model.to(device)
     return model, lins
 
 
-def reference_loss(um, case, target):
+def reference_loss(um, case, target, device="cpu"):
     import torch
     kind = case["loss"]
     if kind == "none":
         return None, {}
     if kind == "zero":
         return um.zero_fn, {}
-    t = torch.from_numpy(target)
+    t = torch.from_numpy(target).to(device)
     if kind == "gaussian":
         return um.fe_fn, {"_target": t, "_var": case["var"]}
     if kind == "bernoulli":
@@ -104,7 +105,7 @@ def reference_loss(um, case, target):
     raise ValueError(kind)
 
 
-def run_reference_call(pc, um, model, call, inputs, target, XI, case):
+def run_reference_call(pc, um, model, call, inputs, target, XI, case, device="cpu"):
     """One ``train_on_batch`` on the reference.  Returns dict of numpy results."""
     import torch
     import torch.optim as optim
@@ -118,7 +119,7 @@ def run_reference_call(pc, um, model, call, inputs, target, XI, case):
         optimizer_p_fn=p_fn, optimizer_p_kwargs=call.get("popt_kwargs", {"lr": 0.0}),
         plot_progress_at=[],
     )
-    loss_fn, loss_kwargs = reference_loss(um, case, target)
+    loss_fn, loss_kwargs = reference_loss(um, case, target, device)
     kw = {}
     if call.get("noise", False):
         var = call.get("noise_var", 2.0)
@@ -128,13 +129,13 @@ def run_reference_call(pc, um, model, call, inputs, target, XI, case):
             optimizer = _pc_trainer.get_optimizer_x()
             std = np.sqrt(var / optimizer.defaults["lr"])
             for l, x in enumerate(xs):
-                x.grad.copy_(torch.from_numpy(XI[t][l]) * (-std))
+                x.grad.copy_(torch.from_numpy(XI[t][l]).to(device) * (-std))
             optimizer.step()
         kw = dict(callback_after_t=injected_random_step, callback_after_t_kwargs={"_pc_trainer": trainer})
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         res = trainer.train_on_batch(
-            inputs=torch.from_numpy(inputs), loss_fn=loss_fn, loss_fn_kwargs=loss_kwargs,
+            inputs=torch.from_numpy(inputs).to(device), loss_fn=loss_fn, loss_fn_kwargs=loss_kwargs,
             is_sample_x_at_batch_start=call.get("sample_x", True),
             is_log_progress=False, is_return_results_every_t=True,
             is_checking_after_callback_after_t=False,
@@ -148,10 +149,10 @@ def run_reference_call(pc, um, model, call, inputs, target, XI, case):
     nc = case.get("rec_chains", None)      # big nets: keep the first few chains only
     for t in rec:
         for l, x in enumerate(res["xs"][t]):
-            out[f"x_t{t}_l{l}"] = x.numpy()[:nc].copy()
-        out[f"out_t{t}"] = res["outputs"][t].detach().numpy()[:nc].copy()
+            out[f"x_t{t}_l{l}"] = x.cpu().numpy()[:nc].copy()
+        out[f"out_t{t}"] = res["outputs"][t].detach().cpu().numpy()[:nc].copy()
     for l, x in enumerate(trainer.get_model_xs()):
-        out[f"x_final_l{l}"] = x.detach().numpy()[:nc].copy()
+        out[f"x_final_l{l}"] = x.detach().cpu().numpy()[:nc].copy()
     return out, trainer
 
 
@@ -159,9 +160,9 @@ def param_grads(lins):
     g = {}
     for j, lin in enumerate(lins):
         if lin.weight.grad is not None:
-            g[f"gW{j}"] = lin.weight.grad.numpy().copy()
+            g[f"gW{j}"] = lin.weight.grad.cpu().numpy().copy()
         if lin.bias is not None and lin.bias.grad is not None:
-            g[f"gb{j}"] = lin.bias.grad.numpy().copy()
+            g[f"gb{j}"] = lin.bias.grad.cpu().numpy().copy()
     return g
 
 
