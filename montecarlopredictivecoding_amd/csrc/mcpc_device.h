@@ -65,7 +65,8 @@ __device__ __forceinline__ float sigmoid_f(float o) {
 // BCEWithLogits element: max(o,0) - o*y + log1p(exp(-|o|))
 __device__ __forceinline__ float bce_logits_f(float o, float y) {
     const float e = __builtin_amdgcn_exp2f(-fabsf(o) * 1.4426950408889634f);
-    return fmaxf(o, 0.0f) - o * y + log1pf(e);
+    // log1p(e), e in (0,1]: log2(1+e)*ln2 via v_log_f32 (absolute error ~1e-7 per element)
+    return fmaxf(o, 0.0f) - o * y + 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + e);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -18,7 +18,7 @@ constexpr int kCT = 32;           // chains per workgroup = 2 MFMA column tiles 
 constexpr int kWaves = 4;         // one wave per SIMD
 constexpr int kThreads = kWaves * 64;
 constexpr int kNT = 4;            // unit tiles a wave accumulates at once (forward / hidden backward)
-constexpr int kNTB = 8;           // in-unit tiles a wave holds across read-out chunks (n_L <= 512)
+constexpr int kNTB = 4;           // in-unit tiles a wave holds across read-out chunks (n_L <= 512)
 constexpr int kChunkTiles = 16;   // read-out units processed per chunk = 256
 constexpr int kLdPad = 4;         // LDS row padding (floats)
 constexpr int kEnergyCols = kMaxLatent + 2;   // loss, E_1..E_L(max), overall
@@ -84,31 +84,75 @@ struct KParams {
 //      W[u0+m][k0+4q+r] (forward) or W[k0+4q+r][i0+m] (backward), r = 0..3
 //   B: LDS rows [chain][k]: lane (c,q) reads 16 B at [c][k0+4q] -> the same k set per MFMA.
 // MFMA r pairs A.r with B.r: k-set {k0+4q+r : q=0..3}; four MFMAs cover the 16-deep block.
-template <int NTT>
-__device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][2], const f32x4* __restrict__ A,
-                                           const int (&aoff)[NTT], int nt, int nkb,
+// The fragment loads of k-block kb+1 are issued before the MFMAs of k-block kb (two named register
+// sets, loop unrolled by two) so that an L2 round trip hides behind 8*NT MFMAs.
+template <int NT, int NTT>
+__device__ __forceinline__ void mfma_block(f32x4 (&acc)[NTT][2], const f32x4 (&a)[NT], f32x4 b0, f32x4 b1) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        acc[t][0] = mfma16(a[t].x, b0.x, acc[t][0]);
+        acc[t][1] = mfma16(a[t].x, b1.x, acc[t][1]);
+        acc[t][0] = mfma16(a[t].y, b0.y, acc[t][0]);
+        acc[t][1] = mfma16(a[t].y, b1.y, acc[t][1]);
+        acc[t][0] = mfma16(a[t].z, b0.z, acc[t][0]);
+        acc[t][1] = mfma16(a[t].z, b1.z, acc[t][1]);
+        acc[t][0] = mfma16(a[t].w, b0.w, acc[t][0]);
+        acc[t][1] = mfma16(a[t].w, b1.w, acc[t][1]);
+    }
+}
+
+template <int NT, int NTT>
+__device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][2], const f32x4* __restrict__ A,
+                                           const int (&aoff)[NTT], int nkb,
                                            const float* B, int ldb, int lane) {
     const int c = lane & 15, q = lane >> 4;
     const float* b0p = B + c * ldb + 4 * q;
     const float* b1p = b0p + 16 * ldb;
-#pragma unroll 2
-    for (int kb = 0; kb < nkb; ++kb) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b0p + kb * 16);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(b1p + kb * 16);
+    f32x4 aP[NT], aQ[NT], bP0, bP1, bQ0, bQ1;
 #pragma unroll
-        for (int t = 0; t < NTT; ++t) {
-            if (t < nt) {
-                const f32x4 a = A[aoff[t] + kb * 64 + lane];
-                acc[t][0] = mfma16(a.x, b0.x, acc[t][0]);
-                acc[t][1] = mfma16(a.x, b1.x, acc[t][1]);
-                acc[t][0] = mfma16(a.y, b0.y, acc[t][0]);
-                acc[t][1] = mfma16(a.y, b1.y, acc[t][1]);
-                acc[t][0] = mfma16(a.z, b0.z, acc[t][0]);
-                acc[t][1] = mfma16(a.z, b1.z, acc[t][1]);
-                acc[t][0] = mfma16(a.w, b0.w, acc[t][0]);
-                acc[t][1] = mfma16(a.w, b1.w, acc[t][1]);
-            }
+    for (int t = 0; t < NT; ++t) aP[t] = A[aoff[t] + lane];
+    bP0 = *reinterpret_cast<const f32x4*>(b0p);
+    bP1 = *reinterpret_cast<const f32x4*>(b1p);
+    int kb = 0;
+    for (; kb + 1 < nkb; kb += 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) aQ[t] = A[aoff[t] + (kb + 1) * 64 + lane];
+        bQ0 = *reinterpret_cast<const f32x4*>(b0p + (kb + 1) * 16);
+        bQ1 = *reinterpret_cast<const f32x4*>(b1p + (kb + 1) * 16);
+        mfma_block<NT, NTT>(acc, aP, bP0, bP1);
+        if (kb + 2 < nkb) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) aP[t] = A[aoff[t] + (kb + 2) * 64 + lane];
+            bP0 = *reinterpret_cast<const f32x4*>(b0p + (kb + 2) * 16);
+            bP1 = *reinterpret_cast<const f32x4*>(b1p + (kb + 2) * 16);
         }
+        mfma_block<NT, NTT>(acc, aQ, bQ0, bQ1);
+    }
+    if (kb < nkb) mfma_block<NT, NTT>(acc, aP, bP0, bP1);
+}
+
+// nt (wave-uniform, 1..NTT) selects a straight-line instantiation: no per-tile branches in the loop
+template <int NTT>
+__device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][2], const f32x4* __restrict__ A,
+                                           const int (&aoff)[NTT], int nt, int nkb,
+                                           const float* B, int ldb, int lane) {
+    if (nkb <= 0) return;
+    switch (nt) {
+        case 1: gemm_fixed<1, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
+        case 2: gemm_fixed<2, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
+        case 3: gemm_fixed<3, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
+        case 4: gemm_fixed<4, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
+        default:
+            if constexpr (NTT > 4) {
+                switch (nt) {
+                    case 5: gemm_fixed<5, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
+                    case 6: gemm_fixed<6, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
+                    case 7: gemm_fixed<7, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
+                    case 8: gemm_fixed<8, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
+                    default: break;
+                }
+            }
+            break;
     }
 }
 
@@ -135,13 +179,13 @@ __device__ __forceinline__ f32x4 ld_unpadded(const float* base, int chain, int n
 }
 
 // Everything the owner lane of a (layer, unit tile, chain tile) quad does when x_l(t) is first
-// touched in a step: error, energy, activation to LDS, spills, trajectory record.
+// touched in a step: error, energy, activation to LDS, spills, trajectory record.  `x` was fetched
+// by the caller (ahead of the GEMM that produced `mu`).
 // Returns the energy contribution 0.5*c*sum(d^2) of the quad (0 for padded chains).
 __device__ __forceinline__ float owner_forward(const KParams& P, const KLayer& Ly, int l, float* lds,
-                                               int chain_local, int chain, int u0, f32x4 mu,
+                                               int chain_local, int chain, int u0, f32x4 x, f32x4 mu,
                                                int slot, int rec_idx) {
     const size_t row = (size_t)chain * Ly.npad + u0;
-    const f32x4 x = ld4(Ly.x + row);
     const f32x4 d = x - mu;
     const f32x4 e = d * Ly.ecoef;
     f32x4 fx;
@@ -166,16 +210,13 @@ __device__ __forceinline__ float owner_forward(const KParams& P, const KLayer& L
     return live ? 0.5f * Ly.ecoef * (dd.x + dd.y + dd.z + dd.w) : 0.0f;
 }
 
-// x_l update of one quad given the back-projected error (C layout) and its sign:
-//   g = e_l + sign * f'(x_l) * back      (sign -1: next layer is a PCLayer, +1: read-out loss, 0: none)
-__device__ __forceinline__ void owner_update(const KParams& P, const KLayer& Ly, int l, const float* lds,
-                                             int chain_local, int chain, int u0, f32x4 back, float sign,
+// x_l update of one quad given x (prefetched), its error e_l, the back-projected error (C layout)
+// and its sign:   g = e_l + sign * f'(x_l) * back
+// (sign -1: next layer is a PCLayer, +1: read-out loss, 0: nothing below)
+__device__ __forceinline__ void owner_update(const KParams& P, const KLayer& Ly, int l,
+                                             int chain, int u0, f32x4 x, f32x4 e, f32x4 back, float sign,
                                              int s, int t) {
     const size_t row = (size_t)chain * Ly.npad + u0;
-    const f32x4 x = ld4(Ly.x + row);
-    f32x4 e;
-    if (l == 0) e = (x - ld4(P.mu1 + row)) * Ly.ecoef;
-    else e = ld4(lds + Ly.lds_e + chain_local * Ly.ld + u0);
     f32x4 g;
     {
         const float fx0 = act_f(Ly.act, x.x), fx1 = act_f(Ly.act, x.y), fx2 = act_f(Ly.act, x.z), fx3 = act_f(Ly.act, x.w);
@@ -253,8 +294,10 @@ __global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     const int cl = 16 * ct + c, chain = chain0 + cl, u0 = 16 * ut + 4 * q;
-                    const f32x4 mu = ld4(P.mu1 + (size_t)chain * Ly.npad + u0);
-                    esum += owner_forward(P, Ly, 0, lds, cl, chain, u0, mu, slot, rec_idx);
+                    const size_t row = (size_t)chain * Ly.npad + u0;
+                    const f32x4 x = ld4(Ly.x + row);
+                    const f32x4 mu = ld4(P.mu1 + row);
+                    esum += owner_forward(P, Ly, 0, lds, cl, chain, u0, x, mu, slot, rec_idx);
                 }
             }
             if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[0 * kWaves + wave] = esum; }
@@ -268,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
             const int nkb = Lp.ntiles;
             float esum = 0.f;
             for (int base = 0; base < Ly.ntiles; base += kNT * kWaves) {
-                f32x4 acc[kNT][2];
+                f32x4 acc[kNT][2], xq[kNT][2], bias[kNT];
                 int aoff[kNT];
                 int nt = 0;
 #pragma unroll
@@ -276,18 +319,24 @@ __global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
                     acc[i][0] = splat(0.f); acc[i][1] = splat(0.f);
                     const int ut = base + wave + kWaves * i;
                     aoff[i] = ut * nkb * 64;
-                    if (ut < Ly.ntiles) nt = i + 1;
+                    if (ut < Ly.ntiles) {
+                        nt = i + 1;
+                        // operands of the epilogue are fetched ahead of the GEMM
+                        const int u0 = 16 * ut + 4 * q;
+                        bias[i] = ld4(Ly.bias + u0);
+                        xq[i][0] = ld4(Ly.x + (size_t)(chain0 + c) * Ly.npad + u0);
+                        xq[i][1] = ld4(Ly.x + (size_t)(chain0 + 16 + c) * Ly.npad + u0);
+                    }
                 }
                 gemm_tiles<kNT>(acc, Ly.Wf, aoff, nt, nkb, lds + Lp.lds_a, Lp.ld, lane);
 #pragma unroll
                 for (int i = 0; i < kNT; ++i) {
                     if (i < nt) {
                         const int ut = base + wave + kWaves * i, u0 = 16 * ut + 4 * q;
-                        const f32x4 bias = ld4(Ly.bias + u0);
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) {
                             const int cl = 16 * ct + c, chain = chain0 + cl;
-                            esum += owner_forward(P, Ly, l, lds, cl, chain, u0, acc[i][ct] + bias, slot, rec_idx);
+                            esum += owner_forward(P, Ly, l, lds, cl, chain, u0, xq[i][ct], acc[i][ct] + bias[i], slot, rec_idx);
                         }
                     }
                 }
@@ -315,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
             }
             for (int tile0 = 0; tile0 < H.ntiles; tile0 += kChunkTiles) {
                 const int ntc = min(kChunkTiles, H.ntiles - tile0);
-                f32x4 acc[kNT][2];
+                f32x4 acc[kNT][2], yq[kNT][2], bias[kNT];
                 int aoff[kNT];
                 int nt = 0;
 #pragma unroll
@@ -323,22 +372,29 @@ __global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
                     acc[i][0] = splat(0.f); acc[i][1] = splat(0.f);
                     const int ut = tile0 + wave + kWaves * i;
                     aoff[i] = ut * nkbF * 64;
-                    if (wave + kWaves * i < ntc) nt = i + 1;
+                    if (wave + kWaves * i < ntc) {
+                        nt = i + 1;
+                        const int u0 = 16 * ut + 4 * q;
+                        bias[i] = ld4(H.bias + u0);
+                        if (H.loss_kind != MCPC_LOSS_NONE) {
+                            yq[i][0] = ld4(H.y + (size_t)(chain0 + c) * H.npad + u0);
+                            yq[i][1] = ld4(H.y + (size_t)(chain0 + 16 + c) * H.npad + u0);
+                        }
+                    }
                 }
                 gemm_tiles<kNT>(acc, H.Wf, aoff, nt, nkbF, lds + Ll.lds_a, Ll.ld, lane);
 #pragma unroll
                 for (int i = 0; i < kNT; ++i) {
                     if (i < nt) {
                         const int ut = tile0 + wave + kWaves * i, u0 = 16 * ut + 4 * q;
-                        const f32x4 bias = ld4(H.bias + u0);
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) {
                             const int cl = 16 * ct + c, chain = chain0 + cl;
                             const bool live = chain < P.B;
-                            const f32x4 o = acc[i][ct] + bias;
+                            const f32x4 o = acc[i][ct] + bias[i];
                             f32x4 e = splat(0.f);
                             if (H.loss_kind != MCPC_LOSS_NONE) {
-                                const f32x4 y = ld4(H.y + (size_t)chain * H.npad + u0);
+                                const f32x4 y = yq[i][ct];
                                 float ov[4] = {o.x, o.y, o.z, o.w}, yv[4] = {y.x, y.y, y.z, y.w}, ev[4];
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
@@ -401,9 +457,12 @@ __global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
             if (it < Ll.ntiles) {
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    const int cl = 16 * ct + c;
-                    owner_update(P, Ll, L - 1, lds, cl, chain0 + cl, 16 * it + 4 * q, accb[i][ct],
-                                 P.has_head ? 1.0f : 0.0f, s, t);
+                    const int cl = 16 * ct + c, chain = chain0 + cl, u0 = 16 * it + 4 * q;
+                    const size_t row = (size_t)chain * Ll.npad + u0;
+                    const f32x4 x = ld4(Ll.x + row);
+                    const f32x4 e = (L == 1) ? (x - ld4(P.mu1 + row)) * Ll.ecoef
+                                             : ld4(lds + Ll.lds_e + cl * Ll.ld + u0);
+                    owner_update(P, Ll, L - 1, chain, u0, x, e, accb[i][ct], P.has_head ? 1.0f : 0.0f, s, t);
                 }
             }
         }
@@ -413,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
             const KLayer& Lp = P.layer[l - 1];
             const int nkb = Ly.ntiles;
             for (int base = 0; base < Lp.ntiles; base += kNT * kWaves) {
-                f32x4 acc[kNT][2];
+                f32x4 acc[kNT][2], xq[kNT][2], eq[kNT][2];
                 int aoff[kNT];
                 int nt = 0;
 #pragma unroll
@@ -421,7 +480,18 @@ __global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
                     acc[i][0] = splat(0.f); acc[i][1] = splat(0.f);
                     const int it = base + wave + kWaves * i;
                     aoff[i] = it * nkb * 64;
-                    if (it < Lp.ntiles) nt = i + 1;
+                    if (it < Lp.ntiles) {
+                        nt = i + 1;
+                        const int u0 = 16 * it + 4 * q;
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) {
+                            const int cl = 16 * ct + c;
+                            const size_t row = (size_t)(chain0 + cl) * Lp.npad + u0;
+                            xq[i][ct] = ld4(Lp.x + row);
+                            eq[i][ct] = (l == 1) ? (xq[i][ct] - ld4(P.mu1 + row)) * Lp.ecoef
+                                                 : ld4(lds + Lp.lds_e + cl * Lp.ld + u0);
+                        }
+                    }
                 }
                 gemm_tiles<kNT>(acc, Ly.Wb, aoff, nt, nkb, lds + Ly.lds_e, Ly.ld, lane);
 #pragma unroll
@@ -431,7 +501,7 @@ __global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct) {
                             const int cl = 16 * ct + c;
-                            owner_update(P, Lp, l - 1, lds, cl, chain0 + cl, 16 * it + 4 * q, acc[i][ct], -1.0f, s, t);
+                            owner_update(P, Lp, l - 1, chain0 + cl, 16 * it + 4 * q, xq[i][ct], eq[i][ct], acc[i][ct], -1.0f, s, t);
                         }
                     }
                 }
@@ -439,7 +509,6 @@ __global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
         }
         // no barrier here: the next step's first barrier (after the top-layer pass, which only
         // writes FX_0 and red[(s+1)&1]) orders this step's E_l / e_o readers before their next writers.
-        // FX_0 shares a buffer with FX_2 / e_o chunk only across barriers of the read-out phase.
     }
 }
 

@@ -550,7 +550,8 @@ class PCTrainer(object):
         acc_begin, acc_end, acc_reset = 0, 0, True
         if want_grads:
             acc_begin, acc_end = (0 if start is None else start), T
-            acc_reset = start is not None
+            # the engine's sums always restart; a carry from earlier calls (start is None) lives in
+            # param.grad, as in the reference, and is added when the sums are read out below
         n_rec = T if is_return_results_every_t else 1
         rec_begin = 0 if is_return_results_every_t else T - 1
         rec_layers = [False] * len(net.sizes)
