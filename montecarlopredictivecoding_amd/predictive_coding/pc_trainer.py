@@ -31,6 +31,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from .. import _lib as L
+from .. import dist
 from ..engine import Engine
 from . import recognise
 from .pc_layer import PCLayer
@@ -510,18 +511,10 @@ class PCTrainer(object):
     def _apply_p_step(self, plan, eng, net, n_acc):
         """Normalise (pc_trainer.py:905-913), all-reduce across shards, hand to the user's optimizer_p."""
         B_global = self.mcpc_world_batch if self.mcpc_world_batch is not None else plan["B"]
-        scale = 1.0 / (n_acc * B_global) if n_acc > 0 else 1.0 / B_global
-        flat = eng.read_param_grads_flat(scale=scale)
-        if self.mcpc_sharded and torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.all_reduce(flat, group=self.mcpc_process_group)     # RCCL: one bucket per call
-        off = 0
-        for lin in net.linears:
-            n = lin.weight.numel()
-            lin.weight.grad = flat[off:off + n].view_as(lin.weight)
-            off += n
-            if lin.bias is not None:
-                lin.bias.grad = flat[off:off + lin.bias.numel()].view_as(lin.bias)
-                off += lin.bias.numel()
+        flat = eng.read_param_grads_flat(scale=dist.grad_scale(n_acc, B_global))
+        if self.mcpc_sharded:
+            dist.allreduce_flat(flat, self.mcpc_process_group)     # RCCL: one bucket per call
+        dist.assign_flat_grads(net.linears, flat)
         self._optimizer_p.step()
 
     # ---- fused path ---------------------------------------------------------------------------------------

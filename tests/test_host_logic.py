@@ -1,0 +1,182 @@
+"""Host-side logic of the facade that needs no GPU: schedules, recognisers, PCLayer torch semantics,
+loud failure when no device / unsupported configuration."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import montecarlopredictivecoding_amd.predictive_coding as pc
+from montecarlopredictivecoding_amd import _lib as L
+from montecarlopredictivecoding_amd.predictive_coding import recognise
+from montecarlopredictivecoding_amd.predictive_coding.pc_layer import probe_energy_coefficient
+from montecarlopredictivecoding_amd.utils import model as um
+from montecarlopredictivecoding_amd.utils.training_evaluation import (get_mcpc_trainer, get_mcpc_trainer_one_sample,
+                                                                      get_pc_trainer)
+
+CFG = dict(input_size=5, hidden_size=12, hidden2_size=9, output_size=20, activation_fn="tanh",
+           T_pc=7, optimizer_x_fn_pc=torch.optim.Adam, optimizer_x_kwargs_pc={"lr": 0.1},
+           optimizer_p_fn=torch.optim.Adam, optimizer_p_kwargs={"lr": 0.01},
+           mixing=3, sampling=4, K=6, optimizer_x_kwargs_mcpc={"lr": 0.03},
+           optimizer_p_fn_mcpc=torch.optim.Adam, optimizer_p_kwargs_mcpc={"lr": 0.01})
+
+
+def test_schedule_strings_and_lists():
+    m = um.get_model(CFG, False)
+    tr = pc.PCTrainer(m, T=8, update_x_at="last_half", update_p_at="last", accumulate_p_at=[2, 3], plot_progress_at=[])
+    assert tr._update_x_at == [4, 5, 6, 7] and tr._update_p_at == [7] and tr._accumulate_p_at == [2, 3]
+    assert pc.PCTrainer(m, T=3, update_p_at="never", plot_progress_at=[])._update_p_at == []
+    assert pc.PCTrainer(m, T=3, plot_progress_at=[])._update_p_at == [0, 1, 2]          # default 'all'
+    with pytest.raises(AssertionError):
+        pc.PCTrainer(m, T=3, update_p_at=[3], plot_progress_at=[])
+    with pytest.raises(NotImplementedError):
+        pc.PCTrainer(m, T=3, update_p_at="sometimes", plot_progress_at=[])
+    with pytest.warns(RuntimeWarning):
+        pc.PCTrainer(m, T=2, plot_progress_at=[])       # T < num_pc_layers + 1 only warns (figure_4.py uses T_pc=1)
+
+
+def test_trainer_factories_and_grad_windows():
+    m = um.get_model(CFG, False)
+    mc = get_mcpc_trainer(m, CFG, training=True)
+    assert mc.get_T() == 7 and mc._accumulate_p_at == [3, 4, 5, 6] and mc._update_p_at == [6]
+    assert mc._grad_window() == 3                       # zeroed at accumulate_p_at[0], summed to the end
+    assert get_mcpc_trainer(m, CFG, training=False)._update_p_at == []
+    one = get_mcpc_trainer_one_sample(m, CFG, training=True)
+    assert one._grad_window() == 5                      # single Monte Carlo sample: last step only
+    mp = get_pc_trainer(m, CFG, is_mcpc=True)
+    assert mp._update_p_at == [] and mp._grad_window() is None
+    assert get_pc_trainer(m, CFG, training=True)._grad_window() == 6
+    odd = pc.PCTrainer(m, T=7, update_p_at="last", accumulate_p_at=[1, 2], plot_progress_at=[])
+    assert odd._grad_window() == 6                      # update step outside the accumulate list zeroes again
+    assert len(list(mc.get_model_parameters())) == 8 and mc.get_num_pc_layers() == 3 and mc.get_least_T() == 4
+
+
+def test_describe_model_variants():
+    net, why = recognise.describe_model(um.get_model(CFG, False))
+    assert why == "" and net.sizes == [5, 12, 9] and net.acts == [L.ACT_TANH] * 3 and net.n_in == 5 and net.n_out == 20
+    toy = nn.Sequential(nn.Linear(1, 1), pc.PCLayer(), nn.Linear(1, 1, bias=False),
+                        pc.PCLayer(energy_fn=lambda inputs: (1 / 0.5) * 0.5 * (inputs["mu"] - inputs["x"]) ** 2))
+    net, why = recognise.describe_model(toy)
+    assert net.n_out == 0 and net.ecoef == [1.0, 2.0] and net.acts == [L.ACT_IDENTITY] * 2
+    bad = nn.Sequential(nn.Linear(3, 3), pc.PCLayer(energy_fn=lambda i: (i["mu"] - i["x"]).abs()), nn.Linear(3, 2))
+    assert recognise.describe_model(bad)[0] is None
+    assert recognise.describe_model(nn.Sequential(nn.Linear(3, 3), nn.ReLU(), nn.Linear(3, 2)))[0] is None
+    assert recognise.describe_model(nn.Sequential(nn.Linear(3, 3), pc.PCLayer(M=torch.ones(3)), nn.Linear(3, 2)))[0] is None
+    assert recognise.describe_model(nn.Linear(3, 3))[0] is None
+
+
+def test_energy_probe():
+    assert probe_energy_coefficient(lambda i: 0.5 * (i["mu"] - i["x"]) ** 2) == pytest.approx(1.0)
+    assert probe_energy_coefficient(lambda i: (1 / 0.3) * 0.5 * (i["mu"] - i["x"]) ** 2) == pytest.approx(1 / 0.3)
+    assert probe_energy_coefficient(lambda i: 0.5 * (i["mu"] - i["x"].detach()) ** 2) == pytest.approx(1.0)
+    assert probe_energy_coefficient(lambda i: (i["mu"] - i["x"]).norm(2)) is None
+    assert probe_energy_coefficient(lambda i: 0.5 * (i["mu"] - i["x"]) ** 2 + i["x"] ** 2) is None
+
+
+def test_describe_loss_tags_and_probes():
+    B, n = 6, 20
+    y = (torch.rand(B, n) < 0.3).float()
+    dev = torch.device("cpu")
+    d, _ = recognise.describe_loss(None, {}, n, B, dev)
+    assert d.kind == L.LOSS_NONE and not d.returns_value
+    d, _ = recognise.describe_loss(um.zero_fn, {}, n, B, dev)
+    assert d.kind == L.LOSS_NONE and d.returns_value
+    d, _ = recognise.describe_loss(um.fe_fn, {"_target": y, "_var": 0.3}, n, B, dev)
+    assert (d.kind, d.var, d.mask_start) == (L.LOSS_GAUSSIAN, 0.3, 0)
+    d, _ = recognise.describe_loss(um.bernoulli_fn_mask, {"_target": y, "_var": None, "perc": 0.25}, n, B, dev)
+    assert (d.kind, d.mask_start) == (L.LOSS_BERNOULLI, 15)
+    d, _ = recognise.describe_loss(um.fe_fn_mask, {"_target": y, "_var": 2.0}, n, B, dev)
+    assert (d.kind, d.mask_start) == (L.LOSS_GAUSSIAN, 10)
+    # untagged callables (e.g. the reference's own functions or lambdas) are recognised by behaviour
+    d, _ = recognise.describe_loss(lambda o, _target: nn.BCEWithLogitsLoss(reduction="sum")(o[:, -5:], _target[:, -5:]),
+                                   {"_target": y}, n, B, dev)
+    assert (d.kind, d.mask_start) == (L.LOSS_BERNOULLI, 15)
+    d, _ = recognise.describe_loss(lambda o, _target, _var: (1 / _var) * 0.5 * (o - _target).pow(2).sum(),
+                                   {"_target": y, "_var": 0.7}, n, B, dev)
+    assert d.kind == L.LOSS_GAUSSIAN and d.var == pytest.approx(0.7, rel=1e-5)
+    d, why = recognise.describe_loss(lambda o, _target: (o - _target).abs().sum(), {"_target": y}, n, B, dev)
+    assert d is None and "neither" in why
+    d, why = recognise.describe_loss(um.fe_fn, {"_target": y, "_var": 1.0}, 0, B, dev)
+    assert d is None
+
+
+def test_describe_optimizer_and_callback():
+    assert recognise.describe_x_optimizer(torch.optim.SGD, {"lr": 0.03})[0].kind == L.XOPT_SGD
+    a = recognise.describe_x_optimizer(torch.optim.Adam, {"lr": 0.1, "betas": (0.8, 0.9), "eps": 1e-6})[0]
+    assert (a.kind, a.betas, a.eps) == (L.XOPT_ADAM, (0.8, 0.9), 1e-6)
+    assert recognise.describe_x_optimizer(torch.optim.SGD, {"lr": 0.1, "momentum": 0.9})[0] is None
+    assert recognise.describe_x_optimizer(torch.optim.RMSprop, {"lr": 0.1})[0] is None
+    tr = object()
+    assert recognise.describe_callback(None, {}, tr) == (None, "")
+    assert recognise.describe_callback(um.random_step, {"_pc_trainer": tr}, tr) == (2.0, "")
+    assert recognise.describe_callback(um.random_step, {"_pc_trainer": tr, "var": 0.5}, tr) == (0.5, "")
+    assert recognise.describe_callback(lambda t: None, {}, tr)[1] != ""
+
+
+def test_pclayer_torch_semantics():
+    layer = pc.PCLayer(sample_x_fn=lambda inp: inp["mu"].detach().clone() + 1.0)
+    mu = torch.randn(4, 3)
+    assert not layer.training and layer(mu) is mu                # a fresh layer is in eval mode: identity
+    layer.train()
+    with pytest.warns(RuntimeWarning):                           # no x yet: sampled with a warning
+        out = layer(mu)
+    assert out is layer.get_x() and torch.allclose(out, mu + 1.0)
+    assert float(layer.energy()) == pytest.approx(0.5 * 12)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        layer(mu)                                                # same shape: no resample, no warning
+    with pytest.warns(RuntimeWarning):
+        layer(torch.randn(5, 3))                                 # batch size changed -> resample
+    assert tuple(layer.get_x().shape) == (5, 3)
+    layer.set_is_sample_x(True)
+    layer(torch.zeros(5, 3))
+    assert torch.allclose(layer.get_x(), torch.ones(5, 3)) and not layer.get_is_sample_x()
+    keep = pc.PCLayer(is_keep_energy_per_datapoint=True)
+    keep.train()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        keep(torch.randn(4, 3))
+    assert tuple(keep.energy_per_datapoint().shape) == (4, 1)
+
+
+def test_cpu_model_fails_loudly_not_silently():
+    m = um.get_model(CFG, False)
+    tr = get_mcpc_trainer(m, CFG, training=False)
+    y = torch.zeros(4, 20)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(L.MCPCLibraryError, match="no CPU path"):
+            tr.train_on_batch(inputs=torch.zeros(4, 5), loss_fn=um.bernoulli_fn, loss_fn_kwargs={"_target": y, "_var": None},
+                              is_log_progress=False)
+        m.eval()
+        with pytest.raises(AssertionError):
+            tr.train_on_batch(inputs=torch.zeros(4, 5), is_log_progress=False)
+
+
+def test_unsupported_configurations_name_their_reason():
+    m = nn.Sequential(nn.Linear(3, 3), pc.PCLayer(M=torch.ones(3)), nn.Linear(3, 2))
+    m.train()
+    tr = pc.PCTrainer(m, T=4, plot_progress_at=[])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(NotImplementedError, match="S/M masks"):
+            tr.train_on_batch(inputs=torch.zeros(2, 3), is_log_progress=False)
+    tr2 = pc.PCTrainer(um.get_model(CFG, False), T=4)          # plot_progress_at defaults to 'all'
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(NotImplementedError, match="plot_progress"):
+            tr2.train_on_batch(inputs=torch.zeros(2, 5), is_log_progress=False)
+
+
+def test_random_step_torch_body_matches_reference_arithmetic():
+    """Executed on the step-wise path: overwrite x.grad with N(0, sqrt(var/lr)), step once more."""
+    x = nn.Parameter(torch.zeros(20000))
+
+    class T_:
+        def get_model_xs(self): return [x]
+        def get_optimizer_x(self): return opt
+    opt = torch.optim.SGD([x], lr=0.05)
+    torch.manual_seed(0)
+    um.random_step(0, T_(), var=2.0)
+    assert abs(float(x.std()) - np.sqrt(2.0 * 0.05)) < 0.01 and abs(float(x.mean())) < 0.01
