@@ -17,7 +17,8 @@ XOPT_SGD, XOPT_ADAM = 0, 1
 NOISE_NONE, NOISE_PHILOX, NOISE_EXTERNAL = 0, 1, 2
 ENERGY_NONE, ENERGY_LAST, ENERGY_ALL = 0, 1, 2
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmcpc.so")
+# MCPC_LIB: developer override to load a diagnostic build (e.g. libmcpc_stamps.so); same ABI, same kernels
+LIB_PATH = os.environ.get("MCPC_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmcpc.so")
 
 
 class MCPCLibraryError(RuntimeError):

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -55,6 +56,7 @@ struct Lin {
 struct mcpc_engine {
     mcpc_net_desc d{};
     int L = 0, Bpad = 0, nwg = 0, has_head = 0;
+    int ct = kCT;                   // chains per workgroup: 16 (two workgroups per CU) or 32
     int npad[kMaxLatent]{};
     int out_pad = 0;
     Lin lin[kMaxLatent + 1];
@@ -81,11 +83,17 @@ struct mcpc_engine {
     std::vector<float> adam_host;
     // LDS plan
     int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_bytes = 0;
+    // per-step phase table (device copy)
+    KPhase* phases = nullptr;
+    int n_phases = 0;
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     int64_t prof_steps = 0;
+#ifdef MCPC_STAMPS
+    unsigned long long* dbg = nullptr;
+#endif
 };
 
 namespace {
@@ -93,7 +101,7 @@ namespace {
 int free_all(mcpc_engine* e) {
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int l = 0; l < kMaxLatent; ++l) { F(e->x[l]); F(e->m[l]); F(e->v[l]); F(e->spill_a[l]); F(e->spill_e[l]); }
-    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef);
+    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases);
     for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     e->events.clear();
@@ -113,8 +121,9 @@ int dmalloc(T*& p, size_t count) {
 // chunk takes the buffer FX_{L-1} is NOT in, errors E_l (l>=1) get their own rows.
 int plan_lds(mcpc_engine* e) {
     int buf[2] = {0, 0};
-    for (int l = 0; l < e->L; ++l) buf[l & 1] = std::max(buf[l & 1], kCT * (e->npad[l] + kLdPad));
-    const int eo_floats = e->has_head ? kCT * (kChunkTiles * 16 + kLdPad) : 0;
+    const int CT = e->ct;
+    for (int l = 0; l < e->L; ++l) buf[l & 1] = std::max(buf[l & 1], CT * (e->npad[l] + kLdPad));
+    const int eo_floats = e->has_head ? CT * (kChunkTiles * 16 + kLdPad) : 0;
     const int eo_buf = ((e->L - 1) & 1) ^ 1;
     buf[eo_buf] = std::max(buf[eo_buf], eo_floats);
     int off = 0;
@@ -122,12 +131,77 @@ int plan_lds(mcpc_engine* e) {
     const int base1 = off; off += buf[1];
     for (int l = 0; l < e->L; ++l) e->lds_a[l] = (l & 1) ? base1 : base0;
     e->lds_eo = eo_buf ? base1 : base0;
-    for (int l = 1; l < e->L; ++l) { e->lds_e[l] = off; off += kCT * (e->npad[l] + kLdPad); }
+    for (int l = 1; l < e->L; ++l) { e->lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
     e->lds_e[0] = 0;
     e->lds_red = off; off += 2 * (kMaxLatent + 1) * kWaves;
     e->lds_bytes = off * (int)sizeof(float);
     if (e->lds_bytes > 160 * 1024)
         return fail(MCPC_ENOMEM, "network needs %d bytes of LDS per workgroup (> 163840): latent widths too large for the fused kernel", e->lds_bytes);
+    return 0;
+}
+
+// The per-step schedule: every GEMM of a Langevin step with its operands, the epilogue that follows
+// it and the barrier it needs.  Output tiles are handed out 16 at a time (4 waves x kNT tiles).
+int build_phases(mcpc_engine* e) {
+    std::vector<KPhase> ph;
+    const int L = e->L;
+    const int span = kNT * kWaves;
+    auto tiles = [&](int l) { return e->npad[l] / 16; };
+    // top latent layer: its prediction is the constant mu1, no GEMM
+    for (int base = 0; base < tiles(0); base += span) {
+        KPhase k{};
+        k.type = PH_FWD; k.layer = 0; k.tile0 = base; k.ntiles = std::min(span, tiles(0) - base);
+        k.flags = PHF_MU1 | (base + span >= tiles(0) ? PHF_SYNC : 0);
+        ph.push_back(k);
+    }
+    for (int l = 1; l < L; ++l)
+        for (int base = 0; base < tiles(l); base += span) {
+            KPhase k{};
+            k.type = PH_FWD; k.layer = l; k.tile0 = base; k.ntiles = std::min(span, tiles(l) - base);
+            k.A = (const f32x4*)e->lin[l].Wf; k.a_tile_stride = tiles(l - 1) * 64; k.nkb = tiles(l - 1);
+            k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
+            k.flags = base + span >= tiles(l) ? PHF_SYNC : 0;
+            ph.push_back(k);
+        }
+    if (e->has_head) {
+        const int ht = e->out_pad / 16;
+        for (int c0 = 0; c0 < ht; c0 += kChunkTiles) {
+            const int ntc = std::min(kChunkTiles, ht - c0);
+            KPhase f{};
+            f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c0; f.ntiles = ntc;
+            f.A = (const f32x4*)e->lin[L].Wf; f.a_tile_stride = tiles(L - 1) * 64; f.nkb = tiles(L - 1);
+            f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad; f.flags = PHF_SYNC;
+            ph.push_back(f);
+            KPhase b{};
+            b.type = PH_HEADB; b.layer = L - 1; b.tile0 = 0; b.ntiles = tiles(L - 1);
+            b.A = (const f32x4*)e->lin[L].Wb; b.a_tile_stride = ht * 64; b.a_off0 = c0 * 64; b.nkb = ntc;
+            b.b_lds = e->lds_eo; b.ldb = kChunkTiles * 16 + kLdPad;
+            b.flags = PHF_ACC_FROM_B | PHF_ACC_TO_B | PHF_SYNC;
+            ph.push_back(b);
+        }
+    }
+    { KPhase k{}; k.type = PH_ENERGY; ph.push_back(k); }
+    // x updates, bottom-up: the last latent layer first (its back-projection sits in accb)
+    for (int base = 0; base < tiles(L - 1); base += span) {
+        KPhase k{};
+        k.type = PH_BWD; k.layer = L - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(L - 1) - base);
+        k.flags = e->has_head ? PHF_ACC_FROM_B : 0;
+        k.sign = e->has_head ? 1.0f : 0.0f;
+        ph.push_back(k);
+    }
+    for (int l = L - 1; l >= 1; --l)
+        for (int base = 0; base < tiles(l - 1); base += span) {
+            KPhase k{};
+            k.type = PH_BWD; k.layer = l - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(l - 1) - base);
+            k.A = (const f32x4*)e->lin[l].Wb; k.a_tile_stride = tiles(l) * 64; k.nkb = tiles(l);
+            k.b_lds = e->lds_e[l]; k.ldb = e->npad[l] + kLdPad; k.sign = -1.0f;
+            ph.push_back(k);
+        }
+    int rc = dmalloc(e->phases, ph.size());
+    if (rc) return rc;
+    if (hipMemcpy(e->phases, ph.data(), ph.size() * sizeof(KPhase), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(MCPC_EHIP, "hipMemcpy of the phase table failed");
+    e->n_phases = (int)ph.size();
     return 0;
 }
 
@@ -159,12 +233,16 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     e->L = d->n_latent;
     e->has_head = d->n_out > 0;
     e->Bpad = (d->batch + kCT - 1) / kCT * kCT;
-    e->nwg = e->Bpad / kCT;
+    // 16 chains per workgroup lets two workgroups share a CU (LDS <= 80 KiB, <= 256 registers): one
+    // workgroup's MFMA phases cover the other's epilogues, barriers and load latencies.
+    e->ct = 16;
+    if (const char* env = getenv("MCPC_CT")) { const int v = atoi(env); if (v == 16 || v == 32) e->ct = v; }
+    e->nwg = e->Bpad / e->ct;
     for (int l = 0; l < e->L; ++l) e->npad[l] = pad16(d->sizes[l]);
     e->out_pad = pad16(d->n_out);
-    if (e->has_head && e->npad[e->L - 1] / 16 > kNTB * kWaves) {
+    if (e->has_head && e->npad[e->L - 1] / 16 > kNT * kWaves) {
         delete e;
-        return fail(MCPC_ENOMEM, "last latent layer wider than %d units is not supported by the fused read-out (kNTB tiles per wave)", kNTB * kWaves * 16);
+        return fail(MCPC_ENOMEM, "last latent layer wider than %d units is not supported by the fused read-out (kNTB tiles per wave)", kNT * kWaves * 16);
     }
     int rc = plan_lds(e);
     if (rc) { delete e; return rc; }
@@ -212,7 +290,10 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     }
     if (e->has_head && (rc = dmalloc(e->spill_eo, (size_t)e->slots * e->Bpad * e->out_pad))) return bail(rc);
 
-    hipError_t herr = hipFuncSetAttribute((const void*)mcpc_steps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
+    if ((rc = build_phases(e))) return bail(rc);
+    hipError_t herr = e->ct == 16
+        ? hipFuncSetAttribute((const void*)mcpc_steps_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes)
+        : hipFuncSetAttribute((const void*)mcpc_steps_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
     if (herr != hipSuccess) return bail(fail(MCPC_EHIP, "hipFuncSetAttribute(%d bytes LDS) failed: %s", e->lds_bytes, hipGetErrorString(herr)));
     *out = e;
     return MCPC_OK;
@@ -453,6 +534,10 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         H.lds_eo = e->lds_eo; H.ld = kChunkTiles * 16 + kLdPad;
     }
     P.mu1 = e->mu1; P.epart = e->epart;
+    P.phases = e->phases; P.n_phases = e->n_phases;
+    // tuning knobs (defaults measured on MI355X): request the epilogue operands before the GEMM
+    { const char* v = getenv("MCPC_PRO_EARLY"); P.pro_early = v ? atoi(v) : 1; }
+    { const char* v = getenv("MCPC_STAGGER"); P.stagger_cycles = v ? atoi(v) : 0; }
     P.L = e->L; P.has_head = e->has_head; P.B = e->d.batch; P.Bpad = e->Bpad; P.T = r->T;
     P.xopt = r->xopt_kind; P.update_x = r->update_x ? 1 : 0;
     P.lr = r->lr; P.beta2 = r->beta2;
@@ -464,6 +549,10 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     P.energy_mode = r->energy_mode;
     P.rec_begin = r->rec_begin; P.rec_stride = std::max(r->rec_stride, 1); P.rec_count = r->rec_count;
     P.lds_red = e->lds_red;
+#ifdef MCPC_STAMPS
+    if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * kWaves * 16); if (rc) return rc; }
+    P.dbg = e->dbg;
+#endif
 
     if (e->profiling) { e->events_used = 0; e->prof_steps = 0; }
 
@@ -489,12 +578,31 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             }
             HIP_TRY(hipEventRecord(e->events[e->events_used].first, stream));
         }
-        hipLaunchKernelGGL(mcpc_steps_kernel, dim3(e->nwg), dim3(kThreads), e->lds_bytes, stream, P);
+        if (e->ct == 16) hipLaunchKernelGGL(mcpc_steps_kernel<1>, dim3(e->nwg), dim3(kThreads), e->lds_bytes, stream, P);
+        else hipLaunchKernelGGL(mcpc_steps_kernel<2>, dim3(e->nwg), dim3(kThreads), e->lds_bytes, stream, P);
         if (e->profiling) {
             HIP_TRY(hipEventRecord(e->events[e->events_used].second, stream));
             ++e->events_used; e->prof_steps += n;
         }
         HIP_TRY(hipGetLastError());
+#ifdef MCPC_STAMPS
+        {
+            static const char* names[16] = {"FWD prologue", "FWD gemm", "FWD epilogue", "HEADF prologue", "HEADF gemm", "HEADF epilogue",
+                                            "HEADB prologue", "HEADB gemm", "HEADB (acc->b)", "BWD prologue", "BWD gemm", "BWD epilogue",
+                                            "energy", "barrier", "-", "-"};
+            HIP_TRY(hipStreamSynchronize(stream));
+            std::vector<unsigned long long> h((size_t)e->nwg * kWaves * 16);
+            HIP_TRY(hipMemcpy(h.data(), e->dbg, h.size() * 8, hipMemcpyDeviceToHost));
+            double tot = 0, sum[16] = {0}, mx[16] = {0};
+            for (size_t w = 0; w < (size_t)e->nwg * kWaves; ++w)
+                for (int i = 0; i < 16; ++i) { sum[i] += (double)h[w * 16 + i]; mx[i] = std::max(mx[i], (double)h[w * 16 + i]); }
+            for (int i = 0; i < 16; ++i) tot += sum[i];
+            fprintf(stderr, "[stamps] launch t0=%d n=%d: mean cycles/step/wave = %.0f\n", t, n, tot / (e->nwg * kWaves) / n);
+            for (int i = 0; i < 16; ++i)
+                fprintf(stderr, "[stamps]   %-16s %5.1f%%  mean %8.0f  max %8.0f cycles/step\n", names[i], 100.0 * sum[i] / tot,
+                        sum[i] / (e->nwg * kWaves) / n, mx[i] / n);
+        }
+#endif
         if (in_acc) { int rc = flush_spill(e, n, stream); if (rc) return rc; }
         t += n;
     }
@@ -572,7 +680,7 @@ int mcpc_philox_normals(int device, uint64_t seed, uint64_t step, int layer, uin
 int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg, int32_t* n_workgroups, int32_t* spill_slots) {
     if (!e) return fail(MCPC_EINVAL, "null engine");
     if (lds_bytes) *lds_bytes = e->lds_bytes;
-    if (chains_per_wg) *chains_per_wg = kCT;
+    if (chains_per_wg) *chains_per_wg = e->ct;
     if (n_workgroups) *n_workgroups = e->nwg;
     if (spill_slots) *spill_slots = e->slots;
     return MCPC_OK;

@@ -4,6 +4,9 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// same vector in the global address space: loads through it are global_load_* (counted on vmcnt only);
+// a generic pointer read from a descriptor in memory would compile to flat_load_* and force full drains
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
 
 namespace mcpc {
 

@@ -14,11 +14,10 @@
 namespace mcpc {
 
 constexpr int kMaxLatent = MCPC_MAX_LATENT;
-constexpr int kCT = 32;           // chains per workgroup = 2 MFMA column tiles of 16
+constexpr int kCT = 32;           // max chains per workgroup = 2 MFMA column tiles of 16 (CTT = 1 or 2)
 constexpr int kWaves = 4;         // one wave per SIMD
 constexpr int kThreads = kWaves * 64;
 constexpr int kNT = 4;            // unit tiles a wave accumulates at once (forward / hidden backward)
-constexpr int kNTB = 4;           // in-unit tiles a wave holds across read-out chunks (n_L <= 512)
 constexpr int kChunkTiles = 16;   // read-out units processed per chunk = 256
 constexpr int kLdPad = 4;         // LDS row padding (floats)
 constexpr int kEnergyCols = kMaxLatent + 2;   // loss, E_1..E_L(max), overall
@@ -57,9 +56,30 @@ struct KHead {
     int ld;                // its row stride = kChunkTiles*16 + kLdPad
 };
 
+// One entry of the per-step phase table (built on the host, identical for every step):
+//   [prologue loads] -> acc = (from accb | 0) -> GEMM over nkb k-blocks -> [acc -> accb] -> epilogue -> [barrier]
+enum : int { PH_FWD = 0, PH_HEADF = 1, PH_HEADB = 2, PH_BWD = 3, PH_ENERGY = 4 };
+enum : int { PHF_ACC_FROM_B = 1, PHF_ACC_TO_B = 2, PHF_SYNC = 4, PHF_MU1 = 8 };
+struct KPhase {
+    const f32x4* A;        // packed weight fragments of this GEMM (unused when nkb == 0)
+    int type;              // PH_*
+    int layer;             // FWD: layer whose prediction error is produced; BWD: layer whose x is updated
+    int tile0, ntiles;     // output unit tiles of the phase; wave w owns tiles tile0 + w + 4 i
+    int a_tile_stride;     // f32x4 units between the fragments of consecutive output tiles
+    int a_off0;            // f32x4 offset of the first k-block of the k-window
+    int nkb;               // k-blocks of 16 (0: no GEMM -- top-layer pass, update without back-projection)
+    int b_lds, ldb;        // B operand: LDS float offset and row stride
+    int flags;             // PHF_*
+    float sign;            // BWD: g = e + sign * f'(x) * back
+};
+
 struct KParams {
     KLayer layer[kMaxLatent];
     KHead head;
+    const KPhase* phases;  // [n_phases] in device memory
+    int n_phases;
+    int pro_early;         // 1: request epilogue operands before the GEMM instead of after its last fragment load
+    int stagger_cycles;    // workgroups >= 256 (the second resident on a CU) start this many cycles late
     const float* mu1;      // prediction of the top latent layer [Bpad][npad_0] (inputs W0^T + b0)
     const float* adam_coef;// [n_steps][2]: step_size = lr/(1-b1^t), 1/sqrt(1-b2^t)
     double* epart;         // [energy rows][nWG][kEnergyCols] per-workgroup partial sums
@@ -75,6 +95,9 @@ struct KParams {
     int energy_mode;
     int rec_begin, rec_stride, rec_count;
     int lds_red;           // float offset of the energy reduction scratch [2][kMaxLatent+1][kWaves]
+#ifdef MCPC_STAMPS
+    unsigned long long* dbg;   // diagnostic build only: [nwg][kWaves][16] cycle sums per phase
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -86,79 +109,201 @@ struct KParams {
 // MFMA r pairs A.r with B.r: k-set {k0+4q+r : q=0..3}; four MFMAs cover the 16-deep block.
 // The fragment loads of k-block kb+1 are issued before the MFMAs of k-block kb (two named register
 // sets, loop unrolled by two) so that an L2 round trip hides behind 8*NT MFMAs.
-template <int NT, int NTT>
-__device__ __forceinline__ void mfma_block(f32x4 (&acc)[NTT][2], const f32x4 (&a)[NT], f32x4 b0, f32x4 b1) {
+template <int NT, int NTT, int CTT>
+__device__ __forceinline__ void mfma_block(f32x4 (&acc)[NTT][CTT], const f32x4 (&a)[NT], const f32x4 (&b)[CTT]) {
+    // round-robin over every accumulator of the wave: a given accumulator is touched again only after
+    // NT*CTT other MFMAs (the dependent-accumulate latency of v_mfma_f32_16x16x4_f32 is not hidden by
+    // alternating just two accumulators)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        acc[t][0] = mfma16(a[t].x, b0.x, acc[t][0]);
-        acc[t][1] = mfma16(a[t].x, b1.x, acc[t][1]);
-        acc[t][0] = mfma16(a[t].y, b0.y, acc[t][0]);
-        acc[t][1] = mfma16(a[t].y, b1.y, acc[t][1]);
-        acc[t][0] = mfma16(a[t].z, b0.z, acc[t][0]);
-        acc[t][1] = mfma16(a[t].z, b1.z, acc[t][1]);
-        acc[t][0] = mfma16(a[t].w, b0.w, acc[t][0]);
-        acc[t][1] = mfma16(a[t].w, b1.w, acc[t][1]);
-    }
-}
-
-template <int NT, int NTT>
-__device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][2], const f32x4* __restrict__ A,
-                                           const int (&aoff)[NTT], int nkb,
-                                           const float* B, int ldb, int lane) {
-    const int c = lane & 15, q = lane >> 4;
-    const float* b0p = B + c * ldb + 4 * q;
-    const float* b1p = b0p + 16 * ldb;
-    f32x4 aP[NT], aQ[NT], bP0, bP1, bQ0, bQ1;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) aP[t] = A[aoff[t] + lane];
-    bP0 = *reinterpret_cast<const f32x4*>(b0p);
-    bP1 = *reinterpret_cast<const f32x4*>(b1p);
-    int kb = 0;
-    for (; kb + 1 < nkb; kb += 2) {
+        for (int ct = 0; ct < CTT; ++ct) acc[t][ct] = mfma16(a[t].x, b[ct].x, acc[t][ct]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) aQ[t] = A[aoff[t] + (kb + 1) * 64 + lane];
-        bQ0 = *reinterpret_cast<const f32x4*>(b0p + (kb + 1) * 16);
-        bQ1 = *reinterpret_cast<const f32x4*>(b1p + (kb + 1) * 16);
-        mfma_block<NT, NTT>(acc, aP, bP0, bP1);
-        if (kb + 2 < nkb) {
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) aP[t] = A[aoff[t] + (kb + 2) * 64 + lane];
-            bP0 = *reinterpret_cast<const f32x4*>(b0p + (kb + 2) * 16);
-            bP1 = *reinterpret_cast<const f32x4*>(b1p + (kb + 2) * 16);
-        }
-        mfma_block<NT, NTT>(acc, aQ, bQ0, bQ1);
-    }
-    if (kb < nkb) mfma_block<NT, NTT>(acc, aP, bP0, bP1);
-}
-
-// nt (wave-uniform, 1..NTT) selects a straight-line instantiation: no per-tile branches in the loop
-template <int NTT>
-__device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][2], const f32x4* __restrict__ A,
-                                           const int (&aoff)[NTT], int nt, int nkb,
-                                           const float* B, int ldb, int lane) {
-    if (nkb <= 0) return;
-    switch (nt) {
-        case 1: gemm_fixed<1, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
-        case 2: gemm_fixed<2, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
-        case 3: gemm_fixed<3, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
-        case 4: gemm_fixed<4, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
-        default:
-            if constexpr (NTT > 4) {
-                switch (nt) {
-                    case 5: gemm_fixed<5, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
-                    case 6: gemm_fixed<6, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
-                    case 7: gemm_fixed<7, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
-                    case 8: gemm_fixed<8, NTT>(acc, A, aoff, nkb, B, ldb, lane); break;
-                    default: break;
-                }
-            }
-            break;
-    }
+        for (int ct = 0; ct < CTT; ++ct) acc[t][ct] = mfma16(a[t].y, b[ct].y, acc[t][ct]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) acc[t][ct] = mfma16(a[t].z, b[ct].z, acc[t][ct]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) acc[t][ct] = mfma16(a[t].w, b[ct].w, acc[t][ct]);
 }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// streamed once per step (state, targets, spills): nontemporal, so the per-XCD L2 (4 MiB) keeps the
+// 2.2 MB of packed weights every workgroup re-reads instead of cycling 4 MB of chain data through it
+__device__ __forceinline__ f32x4 ld4s(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+__device__ __forceinline__ void st4s(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 __device__ __forceinline__ f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return r; }
+
+
+// Request the operands of a phase's epilogue (x, targets, mu1: streamed from HBM/MALL; bias, E from
+// L2/LDS) into pa/pb.  Called by the GEMM right after its LAST fragment load: vmcnt retires in order,
+// so a slow streamed load issued earlier would stall every later counted wait on the fast fragments.
+template <int CTT>
+__device__ __forceinline__ void issue_epilogue_loads(const KParams& P, const KPhase& ph, const float* lds, int nt, int wave,
+                                                     int lane, int chain0, f32x4 (&pa)[kNT][CTT], f32x4 (&pb)[kNT][CTT]) {
+    const KLayer& Ly = P.layer[ph.layer];
+    const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) {
+        if (i < nt) {
+            const int u0 = 16 * (ph.tile0 + wave + kWaves * i) + 4 * q;
+            if (ph.type == PH_FWD) {
+                const f32x4 bias = (ph.flags & PHF_MU1) ? splat(0.f) : ld4(Ly.bias + u0);
+#pragma unroll
+                for (int ct = 0; ct < CTT; ++ct) {
+                    const size_t row = (size_t)(chain0 + 16 * ct + c) * Ly.npad + u0;
+                    pa[i][ct] = ld4s(Ly.x + row);
+                    pb[i][ct] = (ph.flags & PHF_MU1) ? ld4s(P.mu1 + row) : bias;
+                }
+            } else if (ph.type == PH_HEADF) {
+                const f32x4 bias = ld4(P.head.bias + u0);
+#pragma unroll
+                for (int ct = 0; ct < CTT; ++ct) {
+                    pb[i][ct] = bias;
+                    if (P.head.loss_kind != MCPC_LOSS_NONE)
+                        pa[i][ct] = ld4s(P.head.y + (size_t)(chain0 + 16 * ct + c) * P.head.npad + u0);
+                }
+            } else if (ph.type == PH_BWD) {
+#pragma unroll
+                for (int ct = 0; ct < CTT; ++ct) {
+                    const int cl = 16 * ct + c;
+                    const size_t row = (size_t)(chain0 + cl) * Ly.npad + u0;
+                    pa[i][ct] = ld4s(Ly.x + row);
+                    pb[i][ct] = (ph.layer == 0) ? (pa[i][ct] - ld4s(P.mu1 + row)) * Ly.ecoef
+                                                : ld4(lds + Ly.lds_e + cl * Ly.ld + u0);
+                }
+            }
+        }
+    }
+}
+
+#ifdef MCPC_EXP_NOLOAD   // timing experiment only (wrong results): every fragment load re-reads k-block 0 -> L1 hits
+#define MCPC_KSEL(k_) 0
+#else
+#define MCPC_KSEL(k_) (k_)
+#endif
+#define MCPC_PRO_PARAMS const KParams& P, const KPhase& ph, const float* lds, int nt_all, int wave, int chain0, \
+                        f32x4 (&pa)[kNT][CTT], f32x4 (&pb)[kNT][CTT]
+#define MCPC_PRO_ARGS P, ph, lds, nt_all, wave, chain0, pa, pb
+template <int NT, int NTT, int CTT>
+__device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4* __restrict__ A,
+                                           const int (&aoff)[NTT], int nkb,
+                                           const float* B, int ldb, int lane,
+                                           const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT], MCPC_PRO_PARAMS) {
+    // `pro` requests the operands of the epilogue (x, targets ... streamed from HBM/MALL).  It runs
+    // right after the LAST fragment load of this GEMM: vmcnt retires in order, so a slow streamed load
+    // issued any earlier would stall every later counted wait on the (fast, L2-resident) fragments.
+    // Three named register sets, fragment loads issued TWO k-blocks ahead of their MFMAs: with one
+    // wave per SIMD (or two) the loads in flight per CU, not the issue rate, bound the L2 stream.
+    // The fragments of k-blocks 0 and 1 were requested by the caller during the previous phase.
+    const int c = lane & 15, q = lane >> 4;
+    const float* bp = B + c * ldb + 4 * q;
+    f32x4 aP[NT], aQ[NT], aR[NT], bP[CTT], bQ[CTT], bR[CTT];
+#define MCPC_LOAD_B(b_, k_)                                                                         \
+    do {                                                                                            \
+        _Pragma("unroll") for (int ct = 0; ct < CTT; ++ct)                                          \
+            b_[ct] = *reinterpret_cast<const f32x4*>(bp + ct * 16 * ldb + (k_) * 16);               \
+    } while (0)
+#define MCPC_LOAD_SET(a_, b_, k_)                                                                   \
+    do {                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) a_[t] = A[aoff[t] + MCPC_KSEL(k_) * 64 + lane]; \
+        MCPC_LOAD_B(b_, k_);                                                                        \
+    } while (0)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { aP[t] = pre0[t]; aQ[t] = pre1[t]; }
+    MCPC_LOAD_B(bP, 0);
+    if (nkb > 1) MCPC_LOAD_B(bQ, 1);
+    // Steady state: NO conditional loads inside the loop.  hipcc counts vmcnt exactly only across
+    // straight-line code; a branch around a load makes it fall back to draining every outstanding
+    // load before the next MFMA block (guide section 5, "Three .s-level traps" (c)).
+    int kb = 0;
+    for (; kb + 5 <= nkb; kb += 3) {
+        // sched_barrier pins "request set k+2, then compute set k": left alone, the machine scheduler
+        // sinks the loads next to their consumers and the two-block prefetch distance is lost
+        MCPC_LOAD_SET(aR, bR, kb + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<NT, NTT, CTT>(acc, aP, bP);
+        __builtin_amdgcn_sched_barrier(0);
+        MCPC_LOAD_SET(aP, bP, kb + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
+        __builtin_amdgcn_sched_barrier(0);
+        MCPC_LOAD_SET(aQ, bQ, kb + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<NT, NTT, CTT>(acc, aR, bR);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // tail: 0..4 k-blocks left, sets P (kb) and Q (kb+1) are loaded when they exist
+    const int rem = nkb - kb;
+    if (rem == 4) {
+        MCPC_LOAD_SET(aR, bR, kb + 2);
+        mfma_block<NT, NTT, CTT>(acc, aP, bP);
+        MCPC_LOAD_SET(aP, bP, kb + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_epilogue_loads<CTT>(P, ph, lds, nt_all, wave, lane, chain0, pa, pb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
+        mfma_block<NT, NTT, CTT>(acc, aR, bR);
+        mfma_block<NT, NTT, CTT>(acc, aP, bP);
+    } else if (rem == 3) {
+        MCPC_LOAD_SET(aR, bR, kb + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_epilogue_loads<CTT>(P, ph, lds, nt_all, wave, lane, chain0, pa, pb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<NT, NTT, CTT>(acc, aP, bP);
+        mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
+        mfma_block<NT, NTT, CTT>(acc, aR, bR);
+    } else if (rem == 2) {
+        issue_epilogue_loads<CTT>(P, ph, lds, nt_all, wave, lane, chain0, pa, pb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block<NT, NTT, CTT>(acc, aP, bP);
+        mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
+    } else {
+        issue_epilogue_loads<CTT>(P, ph, lds, nt_all, wave, lane, chain0, pa, pb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rem == 1) mfma_block<NT, NTT, CTT>(acc, aP, bP);
+    }
+#undef MCPC_LOAD_SET
+#undef MCPC_LOAD_B
+}
+
+// nt (wave-uniform, 1..NTT) selects a straight-line instantiation: no per-tile branches in the loop
+template <int NTT, int CTT>
+__device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const gf32x4* __restrict__ A,
+                                           const int (&aoff)[NTT], int nt, int nkb,
+                                           const float* B, int ldb, int lane,
+                                           const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT], MCPC_PRO_PARAMS) {
+    switch (nt) {
+        case 1: gemm_fixed<1, NTT, CTT>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1, MCPC_PRO_ARGS); break;
+        case 2: gemm_fixed<2, NTT, CTT>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1, MCPC_PRO_ARGS); break;
+        case 3: gemm_fixed<3, NTT, CTT>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1, MCPC_PRO_ARGS); break;
+        default: gemm_fixed<4, NTT, CTT>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1, MCPC_PRO_ARGS); break;
+    }
+}
+
+// request the fragments of k-blocks 0 and 1 of a phase's GEMM (issued one phase early: weights do not
+// depend on any barrier, so their L2 round trip hides behind the previous epilogue)
+__device__ __forceinline__ void prefetch_first_blocks(const KPhase& ph, int wave, int lane, int& nt, int (&aoff)[kNT],
+                                                      f32x4 (&pre0)[kNT], f32x4 (&pre1)[kNT]) {
+    nt = (ph.ntiles - wave + kWaves - 1) / kWaves;
+    nt = nt < 0 ? 0 : (nt > kNT ? kNT : nt);
+    if (ph.type == PH_ENERGY) nt = 0;
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) {
+        aoff[i] = (ph.tile0 + wave + kWaves * i) * ph.a_tile_stride + ph.a_off0;
+        if (i < nt && ph.nkb > 0) {
+            const gf32x4* A = (const gf32x4*)ph.A;      // weights live in global memory: global_load, not flat_load
+            pre0[i] = A[aoff[i] + lane];
+            if (ph.nkb > 1) pre1[i] = A[aoff[i] + 64 + lane];
+        }
+    }
+}
 
 // guarded scalar store of a C-layout quad into an unpadded [B][n] tensor row
 __device__ __forceinline__ void st_unpadded(float* base, int chain, int n, int u0, f32x4 v) {
@@ -178,101 +323,286 @@ __device__ __forceinline__ f32x4 ld_unpadded(const float* base, int chain, int n
     return v;
 }
 
-// Everything the owner lane of a (layer, unit tile, chain tile) quad does when x_l(t) is first
-// touched in a step: error, energy, activation to LDS, spills, trajectory record.  `x` was fetched
-// by the caller (ahead of the GEMM that produced `mu`).
-// Returns the energy contribution 0.5*c*sum(d^2) of the quad (0 for padded chains).
-__device__ __forceinline__ float owner_forward(const KParams& P, const KLayer& Ly, int l, float* lds,
-                                               int chain_local, int chain, int u0, f32x4 x, f32x4 mu,
-                                               int slot, int rec_idx) {
-    const size_t row = (size_t)chain * Ly.npad + u0;
-    const f32x4 d = x - mu;
-    const f32x4 e = d * Ly.ecoef;
-    f32x4 fx;
-    fx.x = act_f(Ly.act, x.x); fx.y = act_f(Ly.act, x.y); fx.z = act_f(Ly.act, x.z); fx.w = act_f(Ly.act, x.w);
-    const bool live = chain < P.B;
-    st4(lds + Ly.lds_a + chain_local * Ly.ld + u0, fx);
-    if (l > 0) st4(lds + Ly.lds_e + chain_local * Ly.ld + u0, e);
-    if (slot >= 0) {
-        const f32x4 z = splat(0.f);
-        const size_t srow = ((size_t)slot * P.Bpad + chain) * Ly.npad + u0;
-        st4(Ly.spill_a + srow, live ? fx : z);
-        if (l > 0) {
-            st4(Ly.spill_e + srow, live ? e : z);
-        } else if (live) {        // Linear 0: only sum_t e_1 is needed (its input is constant)
-            float* s = Ly.spill_e + row;
-            st4(s, ld4(s) + e);
-        }
-    }
-    if (rec_idx >= 0 && Ly.rec != nullptr && live)
-        st_unpadded(Ly.rec + (size_t)rec_idx * P.B * Ly.n, chain, Ly.n, u0, x);
-    const f32x4 dd = d * d;
-    return live ? 0.5f * Ly.ecoef * (dd.x + dd.y + dd.z + dd.w) : 0.0f;
+#ifdef MCPC_STAMPS
+// Diagnostic build (never shipped): s_memtime deltas per phase type, summed per wave (guide section 7,
+// "In-kernel stamps"); read the SHARES, the fences change the absolute time.
+#define STAMP_DECL unsigned long long st_sum[16] = {0}; unsigned long long st_last = mcpc_stamp();
+#define STAMP(i) do { const unsigned long long st_now = mcpc_stamp(); st_sum[i] += st_now - st_last; st_last = st_now; } while (0)
+__device__ __forceinline__ unsigned long long mcpc_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+// static slot per phase type (a runtime-indexed st_sum[] would live in scratch and distort the shares)
+#define STAMP_T(b, ty) do { if ((ty) == 0) STAMP(b); else if ((ty) == 1) STAMP(3 + b); else if ((ty) == 2) STAMP(6 + b); else STAMP(9 + b); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i) do {} while (0)
+#define STAMP_T(b, ty) do {} while (0)
+#endif
+
+template <int ACT> __device__ __forceinline__ float actf(float x) {
+    if constexpr (ACT == MCPC_ACT_RELU) return fmaxf(x, 0.0f);
+    else if constexpr (ACT == MCPC_ACT_TANH) return tanh_f(x);
+    else return x;
+}
+template <int ACT> __device__ __forceinline__ float actd(float x, float fx) {
+    if constexpr (ACT == MCPC_ACT_RELU) return x > 0.0f ? 1.0f : 0.0f;
+    else if constexpr (ACT == MCPC_ACT_TANH) return 1.0f - fx * fx;
+    else return 1.0f;
 }
 
-// x_l update of one quad given x (prefetched), its error e_l, the back-projected error (C layout)
-// and its sign:   g = e_l + sign * f'(x_l) * back
-// (sign -1: next layer is a PCLayer, +1: read-out loss, 0: nothing below)
-__device__ __forceinline__ void owner_update(const KParams& P, const KLayer& Ly, int l,
-                                             int chain, int u0, f32x4 x, f32x4 e, f32x4 back, float sign,
-                                             int s, int t) {
-    const size_t row = (size_t)chain * Ly.npad + u0;
-    f32x4 g;
-    {
-        const float fx0 = act_f(Ly.act, x.x), fx1 = act_f(Ly.act, x.y), fx2 = act_f(Ly.act, x.z), fx3 = act_f(Ly.act, x.w);
-        g.x = e.x + sign * act_d(Ly.act, x.x, fx0) * back.x;
-        g.y = e.y + sign * act_d(Ly.act, x.y, fx1) * back.y;
-        g.z = e.z + sign * act_d(Ly.act, x.z, fx2) * back.z;
-        g.w = e.w + sign * act_d(Ly.act, x.w, fx3) * back.w;
-    }
-    const bool live = chain < P.B;
-    if (!P.update_x) {
-        if (live && Ly.xgrad != nullptr) st_unpadded(Ly.xgrad, chain, Ly.n, u0, g);
-        return;
-    }
-    f32x4 xn;
-    if (P.xopt == MCPC_XOPT_SGD) {
-        xn = x - g * P.lr;
-    } else {
-        // torch.optim.Adam single-tensor path: lerp_, mul_/addcmul_, sqrt/bias2 + eps, addcdiv_
-        f32x4 m = ld4(Ly.m + row), v = ld4(Ly.v + row);
-        m = m + (g - m) * P.omb1;
-        v = v * P.beta2 + (g * g) * P.omb2;
-        st4(Ly.m + row, m);
-        st4(Ly.v + row, v);
-        const float step_size = P.adam_coef[2 * s], inv_bc2 = P.adam_coef[2 * s + 1];
-        f32x4 den;
-        den.x = __builtin_sqrtf(v.x) * inv_bc2 + P.eps; den.y = __builtin_sqrtf(v.y) * inv_bc2 + P.eps;
-        den.z = __builtin_sqrtf(v.z) * inv_bc2 + P.eps; den.w = __builtin_sqrtf(v.w) * inv_bc2 + P.eps;
-        xn.x = x.x - step_size * (m.x / den.x); xn.y = x.y - step_size * (m.y / den.y);
-        xn.z = x.z - step_size * (m.z / den.z); xn.w = x.w - step_size * (m.w / den.w);
-    }
-    if (P.noise_mode == MCPC_NOISE_PHILOX) {
-        const f32x4 z = normals4(P.seed, P.step_base + (uint64_t)t, (uint32_t)l,
-                                 (uint32_t)(P.chain_base + (uint64_t)chain), (uint32_t)(u0 >> 2));
-        xn = xn + z * P.noise_scale;
-    } else if (P.noise_mode == MCPC_NOISE_EXTERNAL) {
-        if (live) {
-            const f32x4 z = ld_unpadded(Ly.ext_noise + (size_t)s * P.B * Ly.n, chain, Ly.n, u0);
-            xn = xn + z * P.noise_scale;
+// copy tile i (wave-uniform index) of the register-resident per-tile arrays into named locals:
+// a scalar branch + a few v_mov instead of unrolling the (large) epilogue body per tile
+template <int CTT>
+__device__ __forceinline__ void pick_tile(int i, const f32x4 (&acc)[kNT][CTT], const f32x4 (&pa)[kNT][CTT],
+                                          const f32x4 (&pb)[kNT][CTT], f32x4 (&a)[CTT], f32x4 (&xa)[CTT], f32x4 (&xb)[CTT]) {
+    // select chain on the wave-uniform tile index: v_cndmask on registers (a `switch` here is turned
+    // into a dynamically indexed stack array by the optimizer)
+#pragma unroll
+    for (int ct = 0; ct < CTT; ++ct) {
+        f32x4 va = acc[0][ct], vx = pa[0][ct], vb = pb[0][ct];
+#pragma unroll
+        for (int k = 1; k < kNT; ++k) {
+            const bool hit = (i == k);
+            va = hit ? acc[k][ct] : va;
+            vx = hit ? pa[k][ct] : vx;
+            vb = hit ? pb[k][ct] : vb;
         }
+        a[ct] = va; xa[ct] = vx; xb[ct] = vb;
     }
-    // padded units stay exactly zero (their gradient is zero; only the noise must be masked)
-    if (u0 + 0 >= Ly.n) xn.x = 0.f;
-    if (u0 + 1 >= Ly.n) xn.y = 0.f;
-    if (u0 + 2 >= Ly.n) xn.z = 0.f;
-    if (u0 + 3 >= Ly.n) xn.w = 0.f;
-    st4(Ly.x + row, xn);
 }
 
-__global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
+// ---- FWD epilogue: prediction errors, energies, activations to LDS, spills, trajectory records -------
+template <int CTT, int ACT>
+__device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph, float* lds, int nt, int wave, int lane,
+                                              int chain0, const f32x4 (&acc)[kNT][CTT], const f32x4 (&pa)[kNT][CTT],
+                                              const f32x4 (&pb)[kNT][CTT], int slot, int rec_idx) {
+    const KLayer& Ly = P.layer[ph.layer];
+    const int c = lane & 15, q = lane >> 4;
+    const int l = ph.layer, npad = Ly.npad, n = Ly.n, ld = Ly.ld, B = P.B, Bpad = P.Bpad;
+    const float ecoef = Ly.ecoef;
+    float* const fx_lds = lds + Ly.lds_a;
+    float* const e_lds = lds + Ly.lds_e;
+    float* const spill_a = Ly.spill_a;
+    float* const spill_e = Ly.spill_e;
+    float* const rec = (rec_idx >= 0 && Ly.rec != nullptr) ? Ly.rec + (size_t)rec_idx * B * n : nullptr;
+    float esum = 0.f;
+    // unrolled over the wave's tiles: independent quads give the scheduler ILP to cover the
+    // transcendental / LDS / global latencies of a single wave (a rolled loop serialises them)
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) {
+        if (i >= nt) break;
+        f32x4 a[CTT], xa[CTT], xb[CTT];
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) { a[ct] = acc[i][ct]; xa[ct] = pa[i][ct]; xb[ct] = pb[i][ct]; }
+        const int u0 = 16 * (ph.tile0 + wave + kWaves * i) + 4 * q;
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) {
+            const int cl = 16 * ct + c, chain = chain0 + cl;
+            const bool live = chain < B;
+            const f32x4 x = xa[ct];
+            const f32x4 d = x - (a[ct] + xb[ct]);                 // x - mu
+            const f32x4 e = d * ecoef;
+            f32x4 fx;
+            fx.x = actf<ACT>(x.x); fx.y = actf<ACT>(x.y); fx.z = actf<ACT>(x.z); fx.w = actf<ACT>(x.w);
+            st4(fx_lds + cl * ld + u0, fx);
+            if (l > 0) st4(e_lds + cl * ld + u0, e);
+            if (slot >= 0) {
+                const f32x4 z = splat(0.f);
+                const size_t srow = ((size_t)slot * Bpad + chain) * npad + u0;
+                st4s(spill_a + srow, live ? fx : z);
+                if (l > 0) {
+                    st4s(spill_e + srow, live ? e : z);
+                } else if (live) {    // Linear 0 sees a constant input: only sum_t e_1 is needed
+                    float* sp = spill_e + (size_t)chain * npad + u0;
+                    st4s(sp, ld4s(sp) + e);
+                }
+            }
+            if (rec != nullptr && live) st_unpadded(rec, chain, n, u0, x);
+            const f32x4 dd = d * d;
+            esum += live ? 0.5f * ecoef * (dd.x + dd.y + dd.z + dd.w) : 0.0f;
+        }
+    }
+    return esum;
+}
+
+// ---- HEADF epilogue: read-out, loss error e_o into the LDS chunk, loss value, spills, output records ----
+template <int CTT>
+__device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& ph, float* lds, int nt, int wave, int lane,
+                                                int chain0, const f32x4 (&acc)[kNT][CTT], const f32x4 (&pa)[kNT][CTT],
+                                                const f32x4 (&pb)[kNT][CTT], int slot, int rec_idx, bool do_energy) {
+    const KHead& H = P.head;
+    const int c = lane & 15, q = lane >> 4;
+    const int npad = H.npad, n = H.n, ld = H.ld, B = P.B, Bpad = P.Bpad, mask_start = H.mask_start, kind = H.loss_kind;
+    const float inv_var = H.inv_var;
+    float* const eo_lds = lds + H.lds_eo;
+    float* const spill = H.spill_e;
+    float* const rec = (rec_idx >= 0 && H.rec_out != nullptr) ? H.rec_out + (size_t)rec_idx * B * n : nullptr;
+    float lsum = 0.f;
+    // unrolled over the wave's tiles: independent quads give the scheduler ILP to cover the
+    // transcendental / LDS / global latencies of a single wave (a rolled loop serialises them)
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) {
+        if (i >= nt) break;
+        f32x4 a[CTT], xa[CTT], xb[CTT];
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) { a[ct] = acc[i][ct]; xa[ct] = pa[i][ct]; xb[ct] = pb[i][ct]; }
+        const int ut = ph.tile0 + wave + kWaves * i;
+        const int u0 = 16 * ut + 4 * q;
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) {
+            const int cl = 16 * ct + c, chain = chain0 + cl;
+            const bool live = chain < B;
+            const f32x4 o = a[ct] + xb[ct];
+            f32x4 e = splat(0.f);
+            if (kind != MCPC_LOSS_NONE) {
+                const f32x4 y = xa[ct];
+                const float ov[4] = {o.x, o.y, o.z, o.w}, yv[4] = {y.x, y.y, y.z, y.w};
+                float ev[4];
+                if (kind == MCPC_LOSS_GAUSSIAN) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool on = live && (u0 + r) >= mask_start && (u0 + r) < n;
+                        const float dlt = ov[r] - yv[r];
+                        ev[r] = on ? inv_var * dlt : 0.f;
+                        lsum += on ? 0.5f * inv_var * dlt * dlt : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool on = live && (u0 + r) >= mask_start && (u0 + r) < n;
+                        ev[r] = on ? sigmoid_f(ov[r]) - yv[r] : 0.f;
+                    }
+                    if (do_energy) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool on = live && (u0 + r) >= mask_start && (u0 + r) < n;
+                            lsum += on ? bce_logits_f(ov[r], yv[r]) : 0.f;
+                        }
+                    }
+                }
+                e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
+            }
+            st4(eo_lds + cl * ld + (u0 - 16 * ph.tile0), e);
+            if (slot >= 0) st4s(spill + ((size_t)slot * Bpad + chain) * npad + u0, e);
+            if (rec != nullptr && live) st_unpadded(rec, chain, n, u0, o);
+        }
+    }
+    return lsum;
+}
+
+// ---- BWD epilogue: x update of the phase's layer --------------------------------------------------------
+//   g = e + sign * f'(x) * back ;  MODE 1: SGD, no noise   MODE 2: SGD + fused Philox kick   MODE 0: everything
+//   else (Adam, external noise, gradients-only) behind wave-uniform branches.
+template <int CTT, int ACT, int MODE>
+__device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph, int nt, int wave, int lane, int chain0,
+                                             const f32x4 (&acc)[kNT][CTT], const f32x4 (&pa)[kNT][CTT],
+                                             const f32x4 (&pb)[kNT][CTT], int s, int t) {
+    const KLayer& Ly = P.layer[ph.layer];
+    const int c = lane & 15, q = lane >> 4;
+    const int l = ph.layer, npad = Ly.npad, n = Ly.n, B = P.B;
+    const float sign = ph.sign, lr = P.lr, nscale = P.noise_scale;
+    float* const xptr = Ly.x;
+    const uint64_t seed = P.seed, step = P.step_base + (uint64_t)t, chain_base = P.chain_base;
+    // unrolled over the wave's tiles: independent quads give the scheduler ILP to cover the
+    // transcendental / LDS / global latencies of a single wave (a rolled loop serialises them)
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) {
+        if (i >= nt) break;
+        f32x4 a[CTT], xa[CTT], xb[CTT];
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) { a[ct] = acc[i][ct]; xa[ct] = pa[i][ct]; xb[ct] = pb[i][ct]; }
+        const int u0 = 16 * (ph.tile0 + wave + kWaves * i) + 4 * q;
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) {
+            const int chain = chain0 + 16 * ct + c;
+            const size_t row = (size_t)chain * npad + u0;
+            const f32x4 x = xa[ct], e = xb[ct], back = a[ct];
+            f32x4 g;
+            g.x = e.x + sign * actd<ACT>(x.x, actf<ACT>(x.x)) * back.x;
+            g.y = e.y + sign * actd<ACT>(x.y, actf<ACT>(x.y)) * back.y;
+            g.z = e.z + sign * actd<ACT>(x.z, actf<ACT>(x.z)) * back.z;
+            g.w = e.w + sign * actd<ACT>(x.w, actf<ACT>(x.w)) * back.w;
+            f32x4 xn;
+            if constexpr (MODE == 0) {
+                const bool live = chain < B;
+                if (!P.update_x) {
+                    if (live && Ly.xgrad != nullptr) st_unpadded(Ly.xgrad, chain, n, u0, g);
+                    continue;
+                }
+                if (P.xopt == MCPC_XOPT_SGD) {
+                    xn = x - g * lr;
+                } else {
+                    // torch.optim.Adam single-tensor path: lerp_, mul_/addcmul_, sqrt/bias2 + eps, addcdiv_
+                    f32x4 m = ld4s(Ly.m + row), v = ld4s(Ly.v + row);
+                    m = m + (g - m) * P.omb1;
+                    v = v * P.beta2 + (g * g) * P.omb2;
+                    st4s(Ly.m + row, m);
+                    st4s(Ly.v + row, v);
+                    const float step_size = P.adam_coef[2 * s], inv_bc2 = P.adam_coef[2 * s + 1], eps = P.eps;
+                    xn.x = x.x - step_size * (m.x / (__builtin_sqrtf(v.x) * inv_bc2 + eps));
+                    xn.y = x.y - step_size * (m.y / (__builtin_sqrtf(v.y) * inv_bc2 + eps));
+                    xn.z = x.z - step_size * (m.z / (__builtin_sqrtf(v.z) * inv_bc2 + eps));
+                    xn.w = x.w - step_size * (m.w / (__builtin_sqrtf(v.w) * inv_bc2 + eps));
+                }
+                if (P.noise_mode == MCPC_NOISE_PHILOX) {
+                    xn = xn + normals4(seed, step, (uint32_t)l, (uint32_t)(chain_base + (uint64_t)chain), (uint32_t)(u0 >> 2)) * nscale;
+                } else if (P.noise_mode == MCPC_NOISE_EXTERNAL && live) {
+                    xn = xn + ld_unpadded(Ly.ext_noise + (size_t)s * B * n, chain, n, u0) * nscale;
+                }
+            } else {
+                xn = x - g * lr;
+                if constexpr (MODE == 2)
+                    xn = xn + normals4(seed, step, (uint32_t)l, (uint32_t)(chain_base + (uint64_t)chain), (uint32_t)(u0 >> 2)) * nscale;
+            }
+            // padded units stay exactly zero (their gradient is zero; only the noise must be masked)
+            if (u0 + 0 >= n) xn.x = 0.f;
+            if (u0 + 1 >= n) xn.y = 0.f;
+            if (u0 + 2 >= n) xn.z = 0.f;
+            if (u0 + 3 >= n) xn.w = 0.f;
+            st4s(xptr + row, xn);
+        }
+    }
+}
+
+template <int CTT, int ACT>
+__device__ __forceinline__ void bwd_epilogue_mode(const KParams& P, const KPhase& ph, int nt, int wave, int lane, int chain0,
+                                                  const f32x4 (&acc)[kNT][CTT], const f32x4 (&pa)[kNT][CTT],
+                                                  const f32x4 (&pb)[kNT][CTT], int s, int t, int mode) {
+    if (mode == 2) bwd_epilogue<CTT, ACT, 2>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
+    else if (mode == 1) bwd_epilogue<CTT, ACT, 1>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
+    else bwd_epilogue<CTT, ACT, 0>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
+}
+
+template <int CTT>
+__global__ __launch_bounds__(kThreads, CTT == 1 ? 2 : 1) void mcpc_steps_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, q = lane >> 4;
-    const int chain0 = blockIdx.x * kCT;
+    const int chain0 = blockIdx.x * (16 * CTT);
     const int L = P.L;
+    // fused fast paths of the x update (wave-uniform, fixed for the launch)
+    const int upd_mode = (P.update_x && P.xopt == MCPC_XOPT_SGD)
+                             ? (P.noise_mode == MCPC_NOISE_PHILOX ? 2 : (P.noise_mode == MCPC_NOISE_NONE ? 1 : 0)) : 0;
+    if (P.stagger_cycles > 0 && blockIdx.x >= 256) {
+        // two workgroups share a CU: start the second one out of phase so that its GEMMs overlap the
+        // first one's epilogues / barriers instead of competing for the matrix pipe in lockstep
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)P.stagger_cycles;
+        while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(32);
+    }
+    STAMP_DECL
+    // software pipeline over phases: descriptor + first two weight k-blocks of the upcoming phase
+    KPhase ph_next = P.phases[0];
+    int nt_next, aoff_next[kNT];
+    f32x4 pre0_next[kNT], pre1_next[kNT];
+#pragma unroll
+    for (int i = 0; i < kNT; ++i) { pre0_next[i] = splat(0.f); pre1_next[i] = splat(0.f); }
+    prefetch_first_blocks(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
 
     for (int s = 0; s < P.n_steps; ++s) {
         const int t = P.t0 + s;
@@ -284,232 +614,100 @@ __global__ __launch_bounds__(kThreads) void mcpc_steps_kernel(const KParams P) {
             const int k = (t - P.rec_begin) / P.rec_stride;
             if (k < P.rec_count && P.rec_begin + k * P.rec_stride == t) rec_idx = k;
         }
+        // per-wave energy partials of this step; two copies alternate so that a wave running ahead
+        // into the next step never touches slots a slower wave is still reading
         float* red = lds + P.lds_red + (s & 1) * (kMaxLatent + 1) * kWaves;
+        if (do_energy && lane <= kMaxLatent) red[lane * kWaves + wave] = 0.f;
 
-        // ---- top latent layer: prediction is the constant mu1 ---------------------------------
-        {
-            const KLayer& Ly = P.layer[0];
-            float esum = 0.f;
-            for (int ut = wave; ut < Ly.ntiles; ut += kWaves) {
+        f32x4 accb[kNT][CTT];
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const int cl = 16 * ct + c, chain = chain0 + cl, u0 = 16 * ut + 4 * q;
-                    const size_t row = (size_t)chain * Ly.npad + u0;
-                    const f32x4 x = ld4(Ly.x + row);
-                    const f32x4 mu = ld4(P.mu1 + row);
-                    esum += owner_forward(P, Ly, 0, lds, cl, chain, u0, x, mu, slot, rec_idx);
-                }
-            }
-            if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[0 * kWaves + wave] = esum; }
-        }
-        __syncthreads();
+        for (int i = 0; i < kNT; ++i)
+#pragma unroll
+            for (int ct = 0; ct < CTT; ++ct) accb[i][ct] = splat(0.f);
 
-        // ---- hidden predictions mu_l = f(x_{l-1}) W_l^T + b_l, errors e_l ----------------------
-        for (int l = 1; l < L; ++l) {
-            const KLayer& Ly = P.layer[l];
-            const KLayer& Lp = P.layer[l - 1];
-            const int nkb = Lp.ntiles;
-            float esum = 0.f;
-            for (int base = 0; base < Ly.ntiles; base += kNT * kWaves) {
-                f32x4 acc[kNT][2], xq[kNT][2], bias[kNT];
-                int aoff[kNT];
-                int nt = 0;
+#pragma unroll 1
+        for (int p = 0; p < P.n_phases; ++p) {
+            const KPhase ph = ph_next;
+            const int nt = nt_next;
+            int aoff[kNT];
+            f32x4 pre0[kNT], pre1[kNT];
 #pragma unroll
-                for (int i = 0; i < kNT; ++i) {
-                    acc[i][0] = splat(0.f); acc[i][1] = splat(0.f);
-                    const int ut = base + wave + kWaves * i;
-                    aoff[i] = ut * nkb * 64;
-                    if (ut < Ly.ntiles) {
-                        nt = i + 1;
-                        // operands of the epilogue are fetched ahead of the GEMM
-                        const int u0 = 16 * ut + 4 * q;
-                        bias[i] = ld4(Ly.bias + u0);
-                        xq[i][0] = ld4(Ly.x + (size_t)(chain0 + c) * Ly.npad + u0);
-                        xq[i][1] = ld4(Ly.x + (size_t)(chain0 + 16 + c) * Ly.npad + u0);
-                    }
-                }
-                gemm_tiles<kNT>(acc, Ly.Wf, aoff, nt, nkb, lds + Lp.lds_a, Lp.ld, lane);
+            for (int i = 0; i < kNT; ++i) { aoff[i] = aoff_next[i]; pre0[i] = pre0_next[i]; pre1[i] = pre1_next[i]; }
+            // descriptor of the phase after this one (wraps into the next step)
+            const bool has_next = (p + 1 < P.n_phases) || (s + 1 < P.n_steps);
+            if (has_next) ph_next = P.phases[p + 1 < P.n_phases ? p + 1 : 0];
+            if (ph.type == PH_ENERGY) {
+                if (do_energy) {
+                    __syncthreads();   // uniform branch: publishes every wave's red[] entries of this step
+                    if (tid <= kMaxLatent) {
+                        double v = 0.0;
+                        const bool used = (tid < L) || (tid == kMaxLatent && P.has_head);
+                        if (used) {
 #pragma unroll
-                for (int i = 0; i < kNT; ++i) {
-                    if (i < nt) {
-                        const int ut = base + wave + kWaves * i, u0 = 16 * ut + 4 * q;
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            const int cl = 16 * ct + c, chain = chain0 + cl;
-                            esum += owner_forward(P, Ly, l, lds, cl, chain, u0, xq[i][ct], acc[i][ct] + bias[i], slot, rec_idx);
+                            for (int w = 0; w < kWaves; ++w) v += (double)red[tid * kWaves + w];
                         }
+                        const int erow = (P.energy_mode == MCPC_ENERGY_ALL) ? t : 0;
+                        P.epart[((size_t)erow * gridDim.x + blockIdx.x) * (kMaxLatent + 1) + tid] = v;
                     }
                 }
+                if (has_next) prefetch_first_blocks(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
+                STAMP(12);
+                continue;
             }
-            if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[l * kWaves + wave] = esum; }
-            __syncthreads();
+            f32x4 acc[kNT][CTT], pa[kNT][CTT], pb[kNT][CTT];
+            const KLayer& Ly = P.layer[ph.layer];
+            // ---- accumulators; the epilogue's operands are requested by `prologue`, which the GEMM
+            //      invokes after its last fragment load (or which runs directly when there is no GEMM)
+#pragma unroll
+            for (int i = 0; i < kNT; ++i)
+#pragma unroll
+                for (int ct = 0; ct < CTT; ++ct) {
+                    acc[i][ct] = (ph.flags & PHF_ACC_FROM_B) ? accb[i][ct] : splat(0.f);
+                    pa[i][ct] = splat(0.f); pb[i][ct] = splat(0.f);
+                }
+            STAMP_T(0, ph.type);
+            // ---- GEMM ------------------------------------------------------------------------------------
+            const bool early = P.pro_early || !(nt > 0 && ph.nkb > 0);
+            if (early) issue_epilogue_loads<CTT>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
+            if (nt > 0 && ph.nkb > 0)
+                gemm_tiles<kNT, CTT>(acc, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1,
+                                     P, ph, lds, early ? 0 : nt, wave, chain0, pa, pb);
+            // the next phase's first weight fragments travel while this phase's epilogue runs
+            if (has_next) prefetch_first_blocks(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
+            if (ph.flags & PHF_ACC_TO_B) {
+#pragma unroll
+                for (int i = 0; i < kNT; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < CTT; ++ct) accb[i][ct] = acc[i][ct];
+            }
+            STAMP_T(1, ph.type);
+            // ---- epilogue --------------------------------------------------------------------------------
+            if (ph.type == PH_FWD) {
+                float esum;
+                if (Ly.act == MCPC_ACT_RELU) esum = fwd_epilogue<CTT, MCPC_ACT_RELU>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
+                else if (Ly.act == MCPC_ACT_TANH) esum = fwd_epilogue<CTT, MCPC_ACT_TANH>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
+                else esum = fwd_epilogue<CTT, MCPC_ACT_IDENTITY>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
+                if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[ph.layer * kWaves + wave] += esum; }
+            } else if (ph.type == PH_HEADF) {
+                float lsum = headf_epilogue<CTT>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx, do_energy);
+                if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[kMaxLatent * kWaves + wave] += lsum; }
+            } else if (ph.type == PH_BWD) {
+                if (Ly.act == MCPC_ACT_RELU) bwd_epilogue_mode<CTT, MCPC_ACT_RELU>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
+                else if (Ly.act == MCPC_ACT_TANH) bwd_epilogue_mode<CTT, MCPC_ACT_TANH>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
+                else bwd_epilogue_mode<CTT, MCPC_ACT_IDENTITY>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
+            }
+            STAMP_T(2, ph.type);
+            if (ph.flags & PHF_SYNC) __syncthreads();
+            STAMP(13);
         }
-
-        // ---- read-out: out = f(x_L) W^T + b, loss error e_o, back-projection into x_L ----------
-        const KLayer& Ll = P.layer[L - 1];
-        f32x4 accb[kNTB][2];
-#pragma unroll
-        for (int i = 0; i < kNTB; ++i) { accb[i][0] = splat(0.f); accb[i][1] = splat(0.f); }
-        if (P.has_head) {
-            const KHead& H = P.head;
-            const int nkbF = Ll.ntiles;
-            float lsum = 0.f;
-            int boff[kNTB];
-            int ntb = 0;
-#pragma unroll
-            for (int i = 0; i < kNTB; ++i) {
-                const int it = wave + kWaves * i;
-                boff[i] = it * H.ntiles * 64;
-                if (it < Ll.ntiles) ntb = i + 1;
-            }
-            for (int tile0 = 0; tile0 < H.ntiles; tile0 += kChunkTiles) {
-                const int ntc = min(kChunkTiles, H.ntiles - tile0);
-                f32x4 acc[kNT][2], yq[kNT][2], bias[kNT];
-                int aoff[kNT];
-                int nt = 0;
-#pragma unroll
-                for (int i = 0; i < kNT; ++i) {
-                    acc[i][0] = splat(0.f); acc[i][1] = splat(0.f);
-                    const int ut = tile0 + wave + kWaves * i;
-                    aoff[i] = ut * nkbF * 64;
-                    if (wave + kWaves * i < ntc) {
-                        nt = i + 1;
-                        const int u0 = 16 * ut + 4 * q;
-                        bias[i] = ld4(H.bias + u0);
-                        if (H.loss_kind != MCPC_LOSS_NONE) {
-                            yq[i][0] = ld4(H.y + (size_t)(chain0 + c) * H.npad + u0);
-                            yq[i][1] = ld4(H.y + (size_t)(chain0 + 16 + c) * H.npad + u0);
-                        }
-                    }
-                }
-                gemm_tiles<kNT>(acc, H.Wf, aoff, nt, nkbF, lds + Ll.lds_a, Ll.ld, lane);
-#pragma unroll
-                for (int i = 0; i < kNT; ++i) {
-                    if (i < nt) {
-                        const int ut = tile0 + wave + kWaves * i, u0 = 16 * ut + 4 * q;
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            const int cl = 16 * ct + c, chain = chain0 + cl;
-                            const bool live = chain < P.B;
-                            const f32x4 o = acc[i][ct] + bias[i];
-                            f32x4 e = splat(0.f);
-                            if (H.loss_kind != MCPC_LOSS_NONE) {
-                                const f32x4 y = yq[i][ct];
-                                float ov[4] = {o.x, o.y, o.z, o.w}, yv[4] = {y.x, y.y, y.z, y.w}, ev[4];
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const int u = u0 + r;
-                                    const bool on = live && u >= H.mask_start && u < H.n;
-                                    float er = 0.f, lv = 0.f;
-                                    if (H.loss_kind == MCPC_LOSS_GAUSSIAN) {
-                                        const float dlt = ov[r] - yv[r];
-                                        er = H.inv_var * dlt;
-                                        lv = 0.5f * H.inv_var * dlt * dlt;
-                                    } else {
-                                        er = sigmoid_f(ov[r]) - yv[r];
-                                        if (do_energy) lv = bce_logits_f(ov[r], yv[r]);
-                                    }
-                                    ev[r] = on ? er : 0.f;
-                                    lsum += on ? lv : 0.f;
-                                }
-                                e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
-                            }
-                            st4(lds + H.lds_eo + cl * H.ld + (u0 - 16 * tile0), e);
-                            if (slot >= 0)
-                                st4(H.spill_e + ((size_t)slot * P.Bpad + chain) * H.npad + u0, e);
-                            if (rec_idx >= 0 && H.rec_out != nullptr && live)
-                                st_unpadded(H.rec_out + (size_t)rec_idx * P.B * H.n, chain, H.n, u0, o);
-                        }
-                    }
-                }
-                __syncthreads();
-                // back-projection of this chunk: accb[it] += W[chunk units][it]^T e_o[chunk]
-                {
-                    int boffc[kNTB];
-#pragma unroll
-                    for (int i = 0; i < kNTB; ++i) boffc[i] = boff[i] + tile0 * 64;
-                    gemm_tiles<kNTB>(accb, H.Wb, boffc, ntb, ntc, lds + H.lds_eo, H.ld, lane);
-                }
-                __syncthreads();
-            }
-            if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[kMaxLatent * kWaves + wave] = lsum; }
-        }
-
-        // ---- energies of this step -> per-workgroup partials (deterministic final reduce on host side kernel)
-        if (do_energy) {
-            __syncthreads();   // uniform branch: publishes every wave's red[] entries of this step
-            if (tid <= kMaxLatent) {
-                double v = 0.0;
-                const bool used = (tid < L) || (tid == kMaxLatent && P.has_head);
-                if (used) {
-#pragma unroll
-                    for (int w = 0; w < kWaves; ++w) v += (double)red[tid * kWaves + w];
-                }
-                const int erow = (P.energy_mode == MCPC_ENERGY_ALL) ? t : 0;
-                P.epart[((size_t)erow * gridDim.x + blockIdx.x) * (kMaxLatent + 1) + tid] = v;
-            }
-        }
-
-        // ---- x updates, bottom-up: x_L first (needs the read-out back-projection) ---------------
-#pragma unroll
-        for (int i = 0; i < kNTB; ++i) {
-            const int it = wave + kWaves * i;
-            if (it < Ll.ntiles) {
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const int cl = 16 * ct + c, chain = chain0 + cl, u0 = 16 * it + 4 * q;
-                    const size_t row = (size_t)chain * Ll.npad + u0;
-                    const f32x4 x = ld4(Ll.x + row);
-                    const f32x4 e = (L == 1) ? (x - ld4(P.mu1 + row)) * Ll.ecoef
-                                             : ld4(lds + Ll.lds_e + cl * Ll.ld + u0);
-                    owner_update(P, Ll, L - 1, chain, u0, x, e, accb[i][ct], P.has_head ? 1.0f : 0.0f, s, t);
-                }
-            }
-        }
-        for (int l = L - 1; l >= 1; --l) {
-            // back-projection through Linear l into layer l-1: back = e_l W_l
-            const KLayer& Ly = P.layer[l];
-            const KLayer& Lp = P.layer[l - 1];
-            const int nkb = Ly.ntiles;
-            for (int base = 0; base < Lp.ntiles; base += kNT * kWaves) {
-                f32x4 acc[kNT][2], xq[kNT][2], eq[kNT][2];
-                int aoff[kNT];
-                int nt = 0;
-#pragma unroll
-                for (int i = 0; i < kNT; ++i) {
-                    acc[i][0] = splat(0.f); acc[i][1] = splat(0.f);
-                    const int it = base + wave + kWaves * i;
-                    aoff[i] = it * nkb * 64;
-                    if (it < Lp.ntiles) {
-                        nt = i + 1;
-                        const int u0 = 16 * it + 4 * q;
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            const int cl = 16 * ct + c;
-                            const size_t row = (size_t)(chain0 + cl) * Lp.npad + u0;
-                            xq[i][ct] = ld4(Lp.x + row);
-                            eq[i][ct] = (l == 1) ? (xq[i][ct] - ld4(P.mu1 + row)) * Lp.ecoef
-                                                 : ld4(lds + Lp.lds_e + cl * Lp.ld + u0);
-                        }
-                    }
-                }
-                gemm_tiles<kNT>(acc, Ly.Wb, aoff, nt, nkb, lds + Ly.lds_e, Ly.ld, lane);
-#pragma unroll
-                for (int i = 0; i < kNT; ++i) {
-                    if (i < nt) {
-                        const int it = base + wave + kWaves * i;
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            const int cl = 16 * ct + c;
-                            owner_update(P, Lp, l - 1, chain0 + cl, 16 * it + 4 * q, xq[i][ct], eq[i][ct], acc[i][ct], -1.0f, s, t);
-                        }
-                    }
-                }
-            }
-        }
-        // no barrier here: the next step's first barrier (after the top-layer pass, which only
-        // writes FX_0 and red[(s+1)&1]) orders this step's E_l / e_o readers before their next writers.
+        // no barrier at the end of a step: the first barrier of the next step (after the top-layer
+        // pass, which only writes FX_0 and the other copy of red[]) orders this step's readers of
+        // E_l / e_o before their next writers.
     }
+#ifdef MCPC_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * kWaves + wave) * 16 + i] = st_sum[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

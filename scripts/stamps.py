@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Developer tool: run cfg-M on the diagnostic library (make -C montecarlopredictivecoding_amd/csrc stamps)
+and print the per-phase cycle shares the kernel stamps report.  MCPC_LIB must point at libmcpc_stamps.so."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import make_problem, SIZES, N_OUT  # noqa: E402
+from montecarlopredictivecoding_amd import _lib as L  # noqa: E402
+from montecarlopredictivecoding_amd.engine import Engine  # noqa: E402
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
+dev = torch.device("cuda", 0)
+W, b, y, xs = make_problem(B, 30, dev)
+eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=dev)
+eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y); eng.load_state(xs)
+eng.run(K, loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=1, energy_mode=L.ENERGY_ALL)
+torch.cuda.synchronize()
