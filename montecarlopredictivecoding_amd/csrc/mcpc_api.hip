@@ -68,8 +68,11 @@ struct mcpc_engine {
     float* ypad = nullptr;
     bool target_bound = false;
     const float* inputs = nullptr;
-    // Hebbian spill ring
-    int slots = 0;
+    // Hebbian spill ring: two halves, the flush of one half runs on `aux` while the step kernel fills the other
+    int slots = 0, half_slots = 0;
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_steps[2] = {nullptr, nullptr}, ev_flush[2] = {nullptr, nullptr};
+    bool flush_pending[2] = {false, false};
     float* spill_a[kMaxLatent]{};
     float* spill_e[kMaxLatent]{};
     float* spill_eo = nullptr;
@@ -104,6 +107,8 @@ int free_all(mcpc_engine* e) {
     F(e->e0sum); F(e->mu1); F(e->ypad); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases);
     for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (int h = 0; h < 2; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
+    if (e->aux) { (void)hipStreamDestroy(e->aux); e->aux = nullptr; }
     e->events.clear();
     return 0;
 }
@@ -283,6 +288,17 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     per_slot *= sizeof(float);
     const int64_t budget = d->spill_budget_bytes > 0 ? d->spill_budget_bytes : (int64_t)2 << 30;
     e->slots = (int)std::max<int64_t>(1, std::min<int64_t>(64, budget / (int64_t)per_slot));
+    if (e->slots >= 2) { e->slots &= ~1; e->half_slots = e->slots / 2; } else { e->half_slots = 1; }
+    if (getenv("MCPC_NO_OVERLAP")) e->half_slots = e->slots;       // tuning knob: serial flushes on the caller's stream
+    if (e->half_slots < e->slots) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least urgent
+        if (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, lo) != hipSuccess) return bail(fail(MCPC_EHIP, "hipStreamCreateWithPriority failed"));
+        for (int h = 0; h < 2; ++h)
+            if (hipEventCreateWithFlags(&e->ev_steps[h], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&e->ev_flush[h], hipEventDisableTiming) != hipSuccess)
+                return bail(fail(MCPC_EHIP, "hipEventCreate failed"));
+    }
     for (int l = 0; l < e->L; ++l) {
         const size_t n = (size_t)e->slots * e->Bpad * e->npad[l];
         if ((rc = dmalloc(e->spill_a[l], n))) return bail(rc);
@@ -387,35 +403,36 @@ int mcpc_store_state(mcpc_engine* e, float* const* x, void* stream_) {
 namespace {
 
 // One Hebbian flush: fold `n_slots` spilled steps into the gradient sums of every Linear j >= 1.
-int flush_spill(mcpc_engine* e, int n_slots, hipStream_t stream) {
+int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
     const int rows = n_slots * e->Bpad;
     const int nlin = e->L + (e->has_head ? 1 : 0);
     for (int j = 1; j < nlin; ++j) {
         Lin& ln = e->lin[j];
-        const float* E = j < e->L ? e->spill_e[j] : e->spill_eo;
-        const float* A = e->spill_a[j - 1];
         const int ne = ln.out_pad, na = ln.in_pad;
+        const float* E = (j < e->L ? e->spill_e[j] : e->spill_eo) + (size_t)slot0 * e->Bpad * ne;
+        const float* A = e->spill_a[j - 1] + (size_t)slot0 * e->Bpad * na;
         const int wave_tiles = ((ne + 63) / 64) * ((na + 63) / 64);
-        int ksplit = std::max(1, std::min(2048 / wave_tiles, rows / 64));
-        int rps = ((rows + ksplit - 1) / ksplit + 3) / 4 * 4;
+        // enough K-splits for ~4096 waves (3 resident per SIMD at ~150 registers): the kernel streams the
+        // spill from HBM, and occupancy + the two-block prefetch hide its latency
+        int ksplit = std::max(1, std::min(4096 / wave_tiles, rows / 64));
+        int rps = ((rows + ksplit - 1) / ksplit + 15) / 16 * 16;
         ksplit = (rows + rps - 1) / rps;
-        const size_t need = std::max((size_t)ksplit * ne * std::max(na, 1), (size_t)64 * ne);
+        const size_t g_floats = (size_t)ksplit * ne * na, b_floats = (size_t)ksplit * ne;
+        const size_t need = g_floats + b_floats;
         if (need > e->slab_floats) {
             if (e->slab) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(e->slab)); e->slab = nullptr; }
             int rc = dmalloc(e->slab, need);
             if (rc) return rc;
             e->slab_floats = need;
         }
-        hipLaunchKernelGGL(mcpc_dw_kernel, dim3((wave_tiles + 3) / 4, ksplit), dim3(256), 0, stream, E, A, e->slab, rows, ne, na, rps);
+        float* slab_b = e->slab + g_floats;
+        hipLaunchKernelGGL(mcpc_dw_kernel, dim3((wave_tiles + 3) / 4, ksplit), dim3(256), 0, stream, E, A, e->slab, slab_b,
+                           rows, ne, na, rps);
+        const float sign = j < e->L ? -1.0f : 1.0f;
         hipLaunchKernelGGL(mcpc_reduce_slabs_kernel, dim3(grid_for((size_t)ne * na)), dim3(256), 0, stream, e->slab, ln.G,
-                           (size_t)ne * na, ksplit, j < e->L ? -1.0f : 1.0f, 1);
-        // bias: column sums of E (slab reused: ksplit_b * ne floats <= need)
-        int ksb = std::max(1, std::min(64, rows / 256));
-        int rpsb = ((rows + ksb - 1) / ksb + 3) / 4 * 4;
-        ksb = (rows + rpsb - 1) / rpsb;
-        hipLaunchKernelGGL(mcpc_colsum_kernel, dim3((ne + 63) / 64, ksb), dim3(256), 0, stream, E, e->slab, rows, ne, rpsb);
-        hipLaunchKernelGGL(mcpc_reduce_slabs_kernel, dim3(grid_for((size_t)ne)), dim3(256), 0, stream, e->slab, ln.Gb,
-                           (size_t)ne, ksb, j < e->L ? -1.0f : 1.0f, 1);
+                           (size_t)ne * na, ksplit, sign, 1);
+        hipLaunchKernelGGL(mcpc_reduce_slabs_kernel, dim3(grid_for((size_t)ne)), dim3(256), 0, stream, slab_b, ln.Gb,
+                           (size_t)ne, ksplit, sign, 1);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -560,16 +577,29 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     //      stretches are cut at the spill ring's capacity and followed by a Hebbian flush ----------
     int t = r->t_begin;
     const int end = r->t_begin + r->n_steps;
+    const bool overlap = e->aux != nullptr;
+    int half = 0;
     while (t < end) {
         const bool in_acc = t >= acc_b && t < acc_e;
         int n;
-        if (in_acc) n = std::min(std::min(end, acc_e) - t, e->slots);
+        if (in_acc) n = std::min(std::min(end, acc_e) - t, e->half_slots);
         else n = (t < acc_b ? std::min(end, acc_b) : end) - t;
+        const int slot0 = in_acc && overlap ? half * e->half_slots : 0;
         P.t0 = t; P.n_steps = n; P.spill_t0 = t;
         const int s0 = t - r->t_begin;
         P.adam_coef = r->xopt_kind == MCPC_XOPT_ADAM ? e->adam_coef + 2 * (size_t)s0 : nullptr;
         if (r->noise_mode == MCPC_NOISE_EXTERNAL)
             for (int l = 0; l < e->L; ++l) P.layer[l].ext_noise = r->ext_noise[l] + (size_t)s0 * e->d.batch * e->d.sizes[l];
+        if (in_acc) {
+            for (int l = 0; l < e->L; ++l) {
+                const size_t off = (size_t)slot0 * e->Bpad * e->npad[l];
+                P.layer[l].spill_a = e->spill_a[l] + off;
+                if (l >= 1) P.layer[l].spill_e = e->spill_e[l] + off;
+            }
+            if (e->has_head) P.head.spill_e = e->spill_eo + (size_t)slot0 * e->Bpad * e->out_pad;
+            // this half of the ring may still be read by the flush that was started two segments ago
+            if (overlap && e->flush_pending[half]) { HIP_TRY(hipStreamWaitEvent(stream, e->ev_flush[half], 0)); e->flush_pending[half] = false; }
+        }
         if (e->profiling) {
             if (e->events_used == e->events.size()) {
                 hipEvent_t a, b;
@@ -603,9 +633,26 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
                         sum[i] / (e->nwg * kWaves) / n, mx[i] / n);
         }
 #endif
-        if (in_acc) { int rc = flush_spill(e, n, stream); if (rc) return rc; }
+        if (in_acc) {
+            if (overlap) {
+                // the Hebbian GEMMs of this half run on the low-priority stream while the next segment steps
+                HIP_TRY(hipEventRecord(e->ev_steps[half], stream));
+                HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_steps[half], 0));
+                int rc = flush_spill(e, n, slot0, e->aux);
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(e->ev_flush[half], e->aux));
+                e->flush_pending[half] = true;
+                half ^= 1;
+            } else {
+                int rc = flush_spill(e, n, 0, stream);
+                if (rc) return rc;
+            }
+        }
         t += n;
     }
+    // everything that follows on the caller's stream (dw0, gradient read-out, the next run) sees finished sums
+    for (int h = 0; h < 2; ++h)
+        if (overlap && e->flush_pending[h]) { HIP_TRY(hipStreamWaitEvent(stream, e->ev_flush[h], 0)); e->flush_pending[h] = false; }
     if (run_accumulates) {
         // Linear 0 sees a constant input: fold sum_t e_1 now, then clear the running sum
         Lin& l0 = e->lin[0];

@@ -779,9 +779,9 @@ __global__ void mcpc_mu1_kernel(const float* __restrict__ inputs, const float* _
 // feeds component j to MFMA tile j whose rows/cols are the columns {base + 4*lane16 + j}: the
 // column permutation lives only in the epilogue index, loads stay 256 B-contiguous per row.
 // Wave tile = 64 x 64 outputs (4x4 MFMA tiles), one wave tile per wave, 4 waves per workgroup.
-__global__ __launch_bounds__(256) void mcpc_dw_kernel(const float* __restrict__ E, const float* __restrict__ A,
-                                                      float* __restrict__ slab, int rows, int ne, int na,
-                                                      int rows_per_split) {
+__global__ __launch_bounds__(256, 2) void mcpc_dw_kernel(const float* __restrict__ E, const float* __restrict__ A,
+                                                      float* __restrict__ slab, float* __restrict__ slab_b,
+                                                      int rows, int ne, int na, int rows_per_split) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles_a = (na + 63) / 64, tiles_e = (ne + 63) / 64;
@@ -791,24 +791,64 @@ __global__ __launch_bounds__(256) void mcpc_dw_kernel(const float* __restrict__ 
     const int m = lane & 15, q = lane >> 4;
     const int ue = 64 * te + 4 * m, ua = 64 * ta + 4 * m;      // this lane's 4 columns of E / A
     const bool ve = ue < ne, va = ua < na;
+    const bool with_bias = (ta == 0);                           // wave-uniform: these waves also sum E's columns
     const int r0 = blockIdx.y * rows_per_split;
     const int r1 = min(rows, r0 + rows_per_split);
-    f32x4 acc[4][4];
+    if (r0 >= r1) return;
+    f32x4 acc[4][4], accb[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = splat(0.f);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = splat(0.f);
-    const f32x4 z = splat(0.f);
-#pragma unroll 4
-    for (int r = r0; r < r1; r += 4) {
-        const f32x4 e = ve ? ld4(E + (size_t)(r + q) * ne + ue) : z;
-        const f32x4 a = va ? ld4(A + (size_t)(r + q) * na + ua) : z;
-        const float ev[4] = {e.x, e.y, e.z, e.w}, av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(ev[i], av[j], acc[i][j]);
     }
+    const f32x4 z = splat(0.f);
+    const float* Ep = E + (size_t)q * ne + ue;
+    const float* Ap = A + (size_t)q * na + ua;
+    // one block = 16 spilled rows = 4 MFMA k-steps; operands of block b+1 are requested before the 64 MFMAs
+    // of block b (two named register sets, steady-state loop free of conditional loads)
+    f32x4 eA[4], aA[4], eB[4], aB[4];
+#define DW_LOAD(e_, a_, r_)                                                                     \
+    do {                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                         \
+            e_[k] = ve ? ld4s(Ep + (size_t)((r_) + 4 * k) * ne) : z;                            \
+            a_[k] = va ? ld4s(Ap + (size_t)((r_) + 4 * k) * na) : z;                            \
+        }                                                                                       \
+    } while (0)
+#define DW_COMPUTE(e_, a_)                                                                      \
+    do {                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                         \
+            const float ev[4] = {e_[k].x, e_[k].y, e_[k].z, e_[k].w};                           \
+            const float av[4] = {a_[k].x, a_[k].y, a_[k].z, a_[k].w};                           \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                       \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(ev[i], av[j], acc[i][j]); \
+            if (with_bias) {                                                                    \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) accb[i] = mfma16(ev[i], 1.0f, accb[i]); \
+            }                                                                                   \
+        }                                                                                       \
+    } while (0)
+    const int nblk = (r1 - r0) / 16;      // rows_per_split and rows are multiples of 16
+    DW_LOAD(eA, aA, r0);
+    int b = 0;
+    for (; b + 2 < nblk; b += 2) {
+        DW_LOAD(eB, aB, r0 + 16 * (b + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        DW_COMPUTE(eA, aA);
+        __builtin_amdgcn_sched_barrier(0);
+        DW_LOAD(eA, aA, r0 + 16 * (b + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        DW_COMPUTE(eB, aB);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nblk - b == 2) {
+        DW_LOAD(eB, aB, r0 + 16 * (b + 1));
+        DW_COMPUTE(eA, aA);
+        DW_COMPUTE(eB, aB);
+    } else {
+        DW_COMPUTE(eA, aA);
+    }
+#undef DW_LOAD
+#undef DW_COMPUTE
     // C layout of tile (i,j): row 4q+reg -> E column 64te + 4(4q+reg) + i ; col m -> A column 64ta + 4m + j
     float* out = slab + (size_t)blockIdx.y * ne * na;
 #pragma unroll
@@ -821,6 +861,8 @@ __global__ __launch_bounds__(256) void mcpc_dw_kernel(const float* __restrict__ 
                 v.x = acc[i][0][reg]; v.y = acc[i][1][reg]; v.z = acc[i][2][reg]; v.w = acc[i][3][reg];
                 st4(out + (size_t)u * na + ua, v);
             }
+            // bias partial: every column of accb[i] holds sum_r E[r][u]; column 0 (m == 0) writes it
+            if (with_bias && m == 0 && u < ne) slab_b[(size_t)blockIdx.y * ne + u] = accb[i][reg];
         }
     }
 }
@@ -845,8 +887,17 @@ __global__ __launch_bounds__(256) void mcpc_colsum_kernel(const float* __restric
 __global__ void mcpc_reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dst, size_t n, int ksplit,
                                          float sign, int accumulate) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        // fixed summation order (k ascending, groups of 8 independent loads in flight)
         float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += slab[(size_t)k * n + idx];
+        int k = 0;
+        for (; k + 8 <= ksplit; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(slab + (size_t)(k + j) * n + idx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; k < ksplit; ++k) s += slab[(size_t)k * n + idx];
         dst[idx] = accumulate ? dst[idx] + sign * s : sign * s;
     }
 }
