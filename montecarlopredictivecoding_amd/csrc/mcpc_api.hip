@@ -57,6 +57,7 @@ struct mcpc_engine {
     mcpc_net_desc d{};
     int L = 0, Bpad = 0, nwg = 0, has_head = 0;
     int ct = kCT;                   // chains per workgroup: 16 (two workgroups per CU) or 32
+    int nw = kWaves;                // waves per workgroup: 4, or 8 with 32 chains (two waves per SIMD, one workgroup per CU)
     int npad[kMaxLatent]{};
     int out_pad = 0;
     Lin lin[kMaxLatent + 1];
@@ -138,7 +139,7 @@ int plan_lds(mcpc_engine* e) {
     e->lds_eo = eo_buf ? base1 : base0;
     for (int l = 1; l < e->L; ++l) { e->lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
     e->lds_e[0] = 0;
-    e->lds_red = off; off += 2 * (kMaxLatent + 1) * kWaves;
+    e->lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
     e->lds_bytes = off * (int)sizeof(float);
     if (e->lds_bytes > 160 * 1024)
         return fail(MCPC_ENOMEM, "network needs %d bytes of LDS per workgroup (> 163840): latent widths too large for the fused kernel", e->lds_bytes);
@@ -240,8 +241,9 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     e->Bpad = (d->batch + kCT - 1) / kCT * kCT;
     // 16 chains per workgroup lets two workgroups share a CU (LDS <= 80 KiB, <= 256 registers): one
     // workgroup's MFMA phases cover the other's epilogues, barriers and load latencies.
-    e->ct = 16;
+    e->ct = 16; e->nw = 4;
     if (const char* env = getenv("MCPC_CT")) { const int v = atoi(env); if (v == 16 || v == 32) e->ct = v; }
+    if (const char* env = getenv("MCPC_NW")) { const int v = atoi(env); if (v == 4 || (v == 8 && e->ct == 32)) e->nw = v; }
     e->nwg = e->Bpad / e->ct;
     for (int l = 0; l < e->L; ++l) e->npad[l] = pad16(d->sizes[l]);
     e->out_pad = pad16(d->n_out);
@@ -307,9 +309,9 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if (e->has_head && (rc = dmalloc(e->spill_eo, (size_t)e->slots * e->Bpad * e->out_pad))) return bail(rc);
 
     if ((rc = build_phases(e))) return bail(rc);
-    hipError_t herr = e->ct == 16
-        ? hipFuncSetAttribute((const void*)mcpc_steps_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes)
-        : hipFuncSetAttribute((const void*)mcpc_steps_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
+    const void* kfn = e->ct == 16 ? (const void*)mcpc_steps_kernel<1, 4>
+                      : (e->nw == 8 ? (const void*)mcpc_steps_kernel<2, 8> : (const void*)mcpc_steps_kernel<2, 4>);
+    hipError_t herr = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
     if (herr != hipSuccess) return bail(fail(MCPC_EHIP, "hipFuncSetAttribute(%d bytes LDS) failed: %s", e->lds_bytes, hipGetErrorString(herr)));
     *out = e;
     return MCPC_OK;
@@ -552,8 +554,6 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     }
     P.mu1 = e->mu1; P.epart = e->epart;
     P.phases = e->phases; P.n_phases = e->n_phases;
-    // tuning knobs (defaults measured on MI355X): request the epilogue operands before the GEMM
-    { const char* v = getenv("MCPC_PRO_EARLY"); P.pro_early = v ? atoi(v) : 1; }
     { const char* v = getenv("MCPC_STAGGER"); P.stagger_cycles = v ? atoi(v) : 0; }
     P.L = e->L; P.has_head = e->has_head; P.B = e->d.batch; P.Bpad = e->Bpad; P.T = r->T;
     P.xopt = r->xopt_kind; P.update_x = r->update_x ? 1 : 0;
@@ -567,7 +567,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     P.rec_begin = r->rec_begin; P.rec_stride = std::max(r->rec_stride, 1); P.rec_count = r->rec_count;
     P.lds_red = e->lds_red;
 #ifdef MCPC_STAMPS
-    if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * kWaves * 16); if (rc) return rc; }
+    if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * kMaxWaves * 16); if (rc) return rc; }
     P.dbg = e->dbg;
 #endif
 
@@ -608,8 +608,9 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             }
             HIP_TRY(hipEventRecord(e->events[e->events_used].first, stream));
         }
-        if (e->ct == 16) hipLaunchKernelGGL(mcpc_steps_kernel<1>, dim3(e->nwg), dim3(kThreads), e->lds_bytes, stream, P);
-        else hipLaunchKernelGGL(mcpc_steps_kernel<2>, dim3(e->nwg), dim3(kThreads), e->lds_bytes, stream, P);
+        if (e->ct == 16) hipLaunchKernelGGL((mcpc_steps_kernel<1, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
+        else if (e->nw == 8) hipLaunchKernelGGL((mcpc_steps_kernel<2, 8>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
+        else hipLaunchKernelGGL((mcpc_steps_kernel<2, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
         if (e->profiling) {
             HIP_TRY(hipEventRecord(e->events[e->events_used].second, stream));
             ++e->events_used; e->prof_steps += n;
@@ -621,16 +622,16 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
                                             "HEADB prologue", "HEADB gemm", "HEADB (acc->b)", "BWD prologue", "BWD gemm", "BWD epilogue",
                                             "energy", "barrier", "-", "-"};
             HIP_TRY(hipStreamSynchronize(stream));
-            std::vector<unsigned long long> h((size_t)e->nwg * kWaves * 16);
+            std::vector<unsigned long long> h((size_t)e->nwg * e->nw * 16);
             HIP_TRY(hipMemcpy(h.data(), e->dbg, h.size() * 8, hipMemcpyDeviceToHost));
             double tot = 0, sum[16] = {0}, mx[16] = {0};
-            for (size_t w = 0; w < (size_t)e->nwg * kWaves; ++w)
+            for (size_t w = 0; w < (size_t)e->nwg * e->nw; ++w)
                 for (int i = 0; i < 16; ++i) { sum[i] += (double)h[w * 16 + i]; mx[i] = std::max(mx[i], (double)h[w * 16 + i]); }
             for (int i = 0; i < 16; ++i) tot += sum[i];
-            fprintf(stderr, "[stamps] launch t0=%d n=%d: mean cycles/step/wave = %.0f\n", t, n, tot / (e->nwg * kWaves) / n);
+            fprintf(stderr, "[stamps] launch t0=%d n=%d: mean cycles/step/wave = %.0f\n", t, n, tot / (e->nwg * e->nw) / n);
             for (int i = 0; i < 16; ++i)
                 fprintf(stderr, "[stamps]   %-16s %5.1f%%  mean %8.0f  max %8.0f cycles/step\n", names[i], 100.0 * sum[i] / tot,
-                        sum[i] / (e->nwg * kWaves) / n, mx[i] / n);
+                        sum[i] / (e->nwg * e->nw) / n, mx[i] / n);
         }
 #endif
         if (in_acc) {

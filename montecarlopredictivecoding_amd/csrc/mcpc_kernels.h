@@ -15,9 +15,10 @@ namespace mcpc {
 
 constexpr int kMaxLatent = MCPC_MAX_LATENT;
 constexpr int kCT = 32;           // max chains per workgroup = 2 MFMA column tiles of 16 (CTT = 1 or 2)
-constexpr int kWaves = 4;         // one wave per SIMD
+constexpr int kWaves = 4;         // waves per workgroup of the default variant; kMaxWaves bounds the LDS scratch
+constexpr int kMaxWaves = 8;
 constexpr int kThreads = kWaves * 64;
-constexpr int kNT = 4;            // unit tiles a wave accumulates at once (forward / hidden backward)
+constexpr int kNT = 4;            // unit tiles per wave per phase with 4 waves (2 with 8 waves): a phase hands out 16 tiles
 constexpr int kChunkTiles = 16;   // read-out units processed per chunk = 256
 constexpr int kLdPad = 4;         // LDS row padding (floats)
 constexpr int kEnergyCols = kMaxLatent + 2;   // loss, E_1..E_L(max), overall
@@ -78,7 +79,6 @@ struct KParams {
     KHead head;
     const KPhase* phases;  // [n_phases] in device memory
     int n_phases;
-    int pro_early;         // 1: request epilogue operands before the GEMM instead of after its last fragment load
     int stagger_cycles;    // workgroups >= 256 (the second resident on a CU) start this many cycles late
     const float* mu1;      // prediction of the top latent layer [Bpad][npad_0] (inputs W0^T + b0)
     const float* adam_coef;// [n_steps][2]: step_size = lr/(1-b1^t), 1/sqrt(1-b2^t)
@@ -141,18 +141,18 @@ __device__ __forceinline__ void st4s(float* p, f32x4 v) { __builtin_nontemporal_
 __device__ __forceinline__ f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return r; }
 
 
+#define NTW (16 / NW)
 // Request the operands of a phase's epilogue (x, targets, mu1: streamed from HBM/MALL; bias, E from
-// L2/LDS) into pa/pb.  Called by the GEMM right after its LAST fragment load: vmcnt retires in order,
-// so a slow streamed load issued earlier would stall every later counted wait on the fast fragments.
-template <int CTT>
+// L2/LDS) into pa/pb, ahead of the phase's GEMM.
+template <int CTT, int NW>
 __device__ __forceinline__ void issue_epilogue_loads(const KParams& P, const KPhase& ph, const float* lds, int nt, int wave,
-                                                     int lane, int chain0, f32x4 (&pa)[kNT][CTT], f32x4 (&pb)[kNT][CTT]) {
+                                                     int lane, int chain0, f32x4 (&pa)[NTW][CTT], f32x4 (&pb)[NTW][CTT]) {
     const KLayer& Ly = P.layer[ph.layer];
     const int c = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < kNT; ++i) {
+    for (int i = 0; i < NTW; ++i) {
         if (i < nt) {
-            const int u0 = 16 * (ph.tile0 + wave + kWaves * i) + 4 * q;
+            const int u0 = 16 * (ph.tile0 + wave + NW * i) + 4 * q;
             if (ph.type == PH_FWD) {
                 const f32x4 bias = (ph.flags & PHF_MU1) ? splat(0.f) : ld4(Ly.bias + u0);
 #pragma unroll
@@ -188,17 +188,11 @@ __device__ __forceinline__ void issue_epilogue_loads(const KParams& P, const KPh
 #else
 #define MCPC_KSEL(k_) (k_)
 #endif
-#define MCPC_PRO_PARAMS const KParams& P, const KPhase& ph, const float* lds, int nt_all, int wave, int chain0, \
-                        f32x4 (&pa)[kNT][CTT], f32x4 (&pb)[kNT][CTT]
-#define MCPC_PRO_ARGS P, ph, lds, nt_all, wave, chain0, pa, pb
-template <int NT, int NTT, int CTT>
+template <int NT, int NTT, int CTT, int NW>
 __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4* __restrict__ A,
                                            const int (&aoff)[NTT], int nkb,
                                            const float* B, int ldb, int lane,
-                                           const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT], MCPC_PRO_PARAMS) {
-    // `pro` requests the operands of the epilogue (x, targets ... streamed from HBM/MALL).  It runs
-    // right after the LAST fragment load of this GEMM: vmcnt retires in order, so a slow streamed load
-    // issued any earlier would stall every later counted wait on the (fast, L2-resident) fragments.
+                                           const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT]) {
     // Three named register sets, fragment loads issued TWO k-blocks ahead of their MFMAs: with one
     // wave per SIMD (or two) the loads in flight per CU, not the issue rate, bound the L2 stream.
     // The fragments of k-blocks 0 and 1 were requested by the caller during the previous phase.
@@ -245,28 +239,18 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4*
         MCPC_LOAD_SET(aR, bR, kb + 2);
         mfma_block<NT, NTT, CTT>(acc, aP, bP);
         MCPC_LOAD_SET(aP, bP, kb + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_epilogue_loads<CTT>(P, ph, lds, nt_all, wave, lane, chain0, pa, pb);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
         mfma_block<NT, NTT, CTT>(acc, aR, bR);
         mfma_block<NT, NTT, CTT>(acc, aP, bP);
     } else if (rem == 3) {
         MCPC_LOAD_SET(aR, bR, kb + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_epilogue_loads<CTT>(P, ph, lds, nt_all, wave, lane, chain0, pa, pb);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_block<NT, NTT, CTT>(acc, aP, bP);
         mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
         mfma_block<NT, NTT, CTT>(acc, aR, bR);
     } else if (rem == 2) {
-        issue_epilogue_loads<CTT>(P, ph, lds, nt_all, wave, lane, chain0, pa, pb);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_block<NT, NTT, CTT>(acc, aP, bP);
         mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
     } else {
-        issue_epilogue_loads<CTT>(P, ph, lds, nt_all, wave, lane, chain0, pa, pb);
-        __builtin_amdgcn_sched_barrier(0);
         if (rem == 1) mfma_block<NT, NTT, CTT>(acc, aP, bP);
     }
 #undef MCPC_LOAD_SET
@@ -274,29 +258,35 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4*
 }
 
 // nt (wave-uniform, 1..NTT) selects a straight-line instantiation: no per-tile branches in the loop
-template <int NTT, int CTT>
+template <int NTT, int CTT, int NW>
 __device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const gf32x4* __restrict__ A,
                                            const int (&aoff)[NTT], int nt, int nkb,
                                            const float* B, int ldb, int lane,
-                                           const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT], MCPC_PRO_PARAMS) {
-    switch (nt) {
-        case 1: gemm_fixed<1, NTT, CTT>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1, MCPC_PRO_ARGS); break;
-        case 2: gemm_fixed<2, NTT, CTT>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1, MCPC_PRO_ARGS); break;
-        case 3: gemm_fixed<3, NTT, CTT>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1, MCPC_PRO_ARGS); break;
-        default: gemm_fixed<4, NTT, CTT>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1, MCPC_PRO_ARGS); break;
+                                           const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT]) {
+    if constexpr (NTT >= 4) {
+        switch (nt) {
+            case 1: gemm_fixed<1, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1); break;
+            case 2: gemm_fixed<2, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1); break;
+            case 3: gemm_fixed<3, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1); break;
+            default: gemm_fixed<4, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1); break;
+        }
+    } else {
+        if (nt == 1) gemm_fixed<1, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1);
+        else gemm_fixed<2, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1);
     }
 }
 
 // request the fragments of k-blocks 0 and 1 of a phase's GEMM (issued one phase early: weights do not
 // depend on any barrier, so their L2 round trip hides behind the previous epilogue)
-__device__ __forceinline__ void prefetch_first_blocks(const KPhase& ph, int wave, int lane, int& nt, int (&aoff)[kNT],
-                                                      f32x4 (&pre0)[kNT], f32x4 (&pre1)[kNT]) {
-    nt = (ph.ntiles - wave + kWaves - 1) / kWaves;
-    nt = nt < 0 ? 0 : (nt > kNT ? kNT : nt);
+template <int NW>
+__device__ __forceinline__ void prefetch_first_blocks(const KPhase& ph, int wave, int lane, int& nt, int (&aoff)[NTW],
+                                                      f32x4 (&pre0)[NTW], f32x4 (&pre1)[NTW]) {
+    nt = (ph.ntiles - wave + NW - 1) / NW;
+    nt = nt < 0 ? 0 : (nt > NTW ? NTW : nt);
     if (ph.type == PH_ENERGY) nt = 0;
 #pragma unroll
-    for (int i = 0; i < kNT; ++i) {
-        aoff[i] = (ph.tile0 + wave + kWaves * i) * ph.a_tile_stride + ph.a_off0;
+    for (int i = 0; i < NTW; ++i) {
+        aoff[i] = (ph.tile0 + wave + NW * i) * ph.a_tile_stride + ph.a_off0;
         if (i < nt && ph.nkb > 0) {
             const gf32x4* A = (const gf32x4*)ph.A;      // weights live in global memory: global_load, not flat_load
             pre0[i] = A[aoff[i] + lane];
@@ -354,32 +344,11 @@ template <int ACT> __device__ __forceinline__ float actd(float x, float fx) {
     else return 1.0f;
 }
 
-// copy tile i (wave-uniform index) of the register-resident per-tile arrays into named locals:
-// a scalar branch + a few v_mov instead of unrolling the (large) epilogue body per tile
-template <int CTT>
-__device__ __forceinline__ void pick_tile(int i, const f32x4 (&acc)[kNT][CTT], const f32x4 (&pa)[kNT][CTT],
-                                          const f32x4 (&pb)[kNT][CTT], f32x4 (&a)[CTT], f32x4 (&xa)[CTT], f32x4 (&xb)[CTT]) {
-    // select chain on the wave-uniform tile index: v_cndmask on registers (a `switch` here is turned
-    // into a dynamically indexed stack array by the optimizer)
-#pragma unroll
-    for (int ct = 0; ct < CTT; ++ct) {
-        f32x4 va = acc[0][ct], vx = pa[0][ct], vb = pb[0][ct];
-#pragma unroll
-        for (int k = 1; k < kNT; ++k) {
-            const bool hit = (i == k);
-            va = hit ? acc[k][ct] : va;
-            vx = hit ? pa[k][ct] : vx;
-            vb = hit ? pb[k][ct] : vb;
-        }
-        a[ct] = va; xa[ct] = vx; xb[ct] = vb;
-    }
-}
-
 // ---- FWD epilogue: prediction errors, energies, activations to LDS, spills, trajectory records -------
-template <int CTT, int ACT>
+template <int CTT, int NW, int ACT>
 __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph, float* lds, int nt, int wave, int lane,
-                                              int chain0, const f32x4 (&acc)[kNT][CTT], const f32x4 (&pa)[kNT][CTT],
-                                              const f32x4 (&pb)[kNT][CTT], int slot, int rec_idx) {
+                                              int chain0, const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
+                                              const f32x4 (&pb)[NTW][CTT], int slot, int rec_idx) {
     const KLayer& Ly = P.layer[ph.layer];
     const int c = lane & 15, q = lane >> 4;
     const int l = ph.layer, npad = Ly.npad, n = Ly.n, ld = Ly.ld, B = P.B, Bpad = P.Bpad;
@@ -393,12 +362,12 @@ __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph
     // unrolled over the wave's tiles: independent quads give the scheduler ILP to cover the
     // transcendental / LDS / global latencies of a single wave (a rolled loop serialises them)
 #pragma unroll
-    for (int i = 0; i < kNT; ++i) {
+    for (int i = 0; i < NTW; ++i) {
         if (i >= nt) break;
         f32x4 a[CTT], xa[CTT], xb[CTT];
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) { a[ct] = acc[i][ct]; xa[ct] = pa[i][ct]; xb[ct] = pb[i][ct]; }
-        const int u0 = 16 * (ph.tile0 + wave + kWaves * i) + 4 * q;
+        const int u0 = 16 * (ph.tile0 + wave + NW * i) + 4 * q;
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
             const int cl = 16 * ct + c, chain = chain0 + cl;
@@ -430,10 +399,10 @@ __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph
 }
 
 // ---- HEADF epilogue: read-out, loss error e_o into the LDS chunk, loss value, spills, output records ----
-template <int CTT>
+template <int CTT, int NW>
 __device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& ph, float* lds, int nt, int wave, int lane,
-                                                int chain0, const f32x4 (&acc)[kNT][CTT], const f32x4 (&pa)[kNT][CTT],
-                                                const f32x4 (&pb)[kNT][CTT], int slot, int rec_idx, bool do_energy) {
+                                                int chain0, const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
+                                                const f32x4 (&pb)[NTW][CTT], int slot, int rec_idx, bool do_energy) {
     const KHead& H = P.head;
     const int c = lane & 15, q = lane >> 4;
     const int npad = H.npad, n = H.n, ld = H.ld, B = P.B, Bpad = P.Bpad, mask_start = H.mask_start, kind = H.loss_kind;
@@ -445,12 +414,12 @@ __device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& 
     // unrolled over the wave's tiles: independent quads give the scheduler ILP to cover the
     // transcendental / LDS / global latencies of a single wave (a rolled loop serialises them)
 #pragma unroll
-    for (int i = 0; i < kNT; ++i) {
+    for (int i = 0; i < NTW; ++i) {
         if (i >= nt) break;
         f32x4 a[CTT], xa[CTT], xb[CTT];
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) { a[ct] = acc[i][ct]; xa[ct] = pa[i][ct]; xb[ct] = pb[i][ct]; }
-        const int ut = ph.tile0 + wave + kWaves * i;
+        const int ut = ph.tile0 + wave + NW * i;
         const int u0 = 16 * ut + 4 * q;
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
@@ -497,10 +466,10 @@ __device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& 
 // ---- BWD epilogue: x update of the phase's layer --------------------------------------------------------
 //   g = e + sign * f'(x) * back ;  MODE 1: SGD, no noise   MODE 2: SGD + fused Philox kick   MODE 0: everything
 //   else (Adam, external noise, gradients-only) behind wave-uniform branches.
-template <int CTT, int ACT, int MODE>
+template <int CTT, int NW, int ACT, int MODE>
 __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph, int nt, int wave, int lane, int chain0,
-                                             const f32x4 (&acc)[kNT][CTT], const f32x4 (&pa)[kNT][CTT],
-                                             const f32x4 (&pb)[kNT][CTT], int s, int t) {
+                                             const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
+                                             const f32x4 (&pb)[NTW][CTT], int s, int t) {
     const KLayer& Ly = P.layer[ph.layer];
     const int c = lane & 15, q = lane >> 4;
     const int l = ph.layer, npad = Ly.npad, n = Ly.n, B = P.B;
@@ -510,12 +479,12 @@ __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph,
     // unrolled over the wave's tiles: independent quads give the scheduler ILP to cover the
     // transcendental / LDS / global latencies of a single wave (a rolled loop serialises them)
 #pragma unroll
-    for (int i = 0; i < kNT; ++i) {
+    for (int i = 0; i < NTW; ++i) {
         if (i >= nt) break;
         f32x4 a[CTT], xa[CTT], xb[CTT];
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) { a[ct] = acc[i][ct]; xa[ct] = pa[i][ct]; xb[ct] = pb[i][ct]; }
-        const int u0 = 16 * (ph.tile0 + wave + kWaves * i) + 4 * q;
+        const int u0 = 16 * (ph.tile0 + wave + NW * i) + 4 * q;
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
             const int chain = chain0 + 16 * ct + c;
@@ -568,17 +537,17 @@ __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph,
     }
 }
 
-template <int CTT, int ACT>
+template <int CTT, int NW, int ACT>
 __device__ __forceinline__ void bwd_epilogue_mode(const KParams& P, const KPhase& ph, int nt, int wave, int lane, int chain0,
-                                                  const f32x4 (&acc)[kNT][CTT], const f32x4 (&pa)[kNT][CTT],
-                                                  const f32x4 (&pb)[kNT][CTT], int s, int t, int mode) {
-    if (mode == 2) bwd_epilogue<CTT, ACT, 2>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
-    else if (mode == 1) bwd_epilogue<CTT, ACT, 1>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
-    else bwd_epilogue<CTT, ACT, 0>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
+                                                  const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
+                                                  const f32x4 (&pb)[NTW][CTT], int s, int t, int mode) {
+    if (mode == 2) bwd_epilogue<CTT, NW, ACT, 2>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
+    else if (mode == 1) bwd_epilogue<CTT, NW, ACT, 1>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
+    else bwd_epilogue<CTT, NW, ACT, 0>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
 }
 
-template <int CTT>
-__global__ __launch_bounds__(kThreads, CTT == 1 ? 2 : 1) void mcpc_steps_kernel(const KParams P) {
+template <int CTT, int NW>
+__global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_steps_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -598,11 +567,11 @@ __global__ __launch_bounds__(kThreads, CTT == 1 ? 2 : 1) void mcpc_steps_kernel(
     STAMP_DECL
     // software pipeline over phases: descriptor + first two weight k-blocks of the upcoming phase
     KPhase ph_next = P.phases[0];
-    int nt_next, aoff_next[kNT];
-    f32x4 pre0_next[kNT], pre1_next[kNT];
+    int nt_next, aoff_next[NTW];
+    f32x4 pre0_next[NTW], pre1_next[NTW];
 #pragma unroll
-    for (int i = 0; i < kNT; ++i) { pre0_next[i] = splat(0.f); pre1_next[i] = splat(0.f); }
-    prefetch_first_blocks(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
+    for (int i = 0; i < NTW; ++i) { pre0_next[i] = splat(0.f); pre1_next[i] = splat(0.f); }
+    prefetch_first_blocks<NW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
 
     for (int s = 0; s < P.n_steps; ++s) {
         const int t = P.t0 + s;
@@ -616,12 +585,12 @@ __global__ __launch_bounds__(kThreads, CTT == 1 ? 2 : 1) void mcpc_steps_kernel(
         }
         // per-wave energy partials of this step; two copies alternate so that a wave running ahead
         // into the next step never touches slots a slower wave is still reading
-        float* red = lds + P.lds_red + (s & 1) * (kMaxLatent + 1) * kWaves;
-        if (do_energy && lane <= kMaxLatent) red[lane * kWaves + wave] = 0.f;
+        float* red = lds + P.lds_red + (s & 1) * (kMaxLatent + 1) * NW;
+        if (do_energy && lane <= kMaxLatent) red[lane * NW + wave] = 0.f;
 
-        f32x4 accb[kNT][CTT];
+        f32x4 accb[NTW][CTT];
 #pragma unroll
-        for (int i = 0; i < kNT; ++i)
+        for (int i = 0; i < NTW; ++i)
 #pragma unroll
             for (int ct = 0; ct < CTT; ++ct) accb[i][ct] = splat(0.f);
 
@@ -629,10 +598,10 @@ __global__ __launch_bounds__(kThreads, CTT == 1 ? 2 : 1) void mcpc_steps_kernel(
         for (int p = 0; p < P.n_phases; ++p) {
             const KPhase ph = ph_next;
             const int nt = nt_next;
-            int aoff[kNT];
-            f32x4 pre0[kNT], pre1[kNT];
+            int aoff[NTW];
+            f32x4 pre0[NTW], pre1[NTW];
 #pragma unroll
-            for (int i = 0; i < kNT; ++i) { aoff[i] = aoff_next[i]; pre0[i] = pre0_next[i]; pre1[i] = pre1_next[i]; }
+            for (int i = 0; i < NTW; ++i) { aoff[i] = aoff_next[i]; pre0[i] = pre0_next[i]; pre1[i] = pre1_next[i]; }
             // descriptor of the phase after this one (wraps into the next step)
             const bool has_next = (p + 1 < P.n_phases) || (s + 1 < P.n_steps);
             if (has_next) ph_next = P.phases[p + 1 < P.n_phases ? p + 1 : 0];
@@ -644,22 +613,22 @@ __global__ __launch_bounds__(kThreads, CTT == 1 ? 2 : 1) void mcpc_steps_kernel(
                         const bool used = (tid < L) || (tid == kMaxLatent && P.has_head);
                         if (used) {
 #pragma unroll
-                            for (int w = 0; w < kWaves; ++w) v += (double)red[tid * kWaves + w];
+                            for (int w = 0; w < NW; ++w) v += (double)red[tid * NW + w];
                         }
                         const int erow = (P.energy_mode == MCPC_ENERGY_ALL) ? t : 0;
                         P.epart[((size_t)erow * gridDim.x + blockIdx.x) * (kMaxLatent + 1) + tid] = v;
                     }
                 }
-                if (has_next) prefetch_first_blocks(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
+                if (has_next) prefetch_first_blocks<NW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
                 STAMP(12);
                 continue;
             }
-            f32x4 acc[kNT][CTT], pa[kNT][CTT], pb[kNT][CTT];
+            f32x4 acc[NTW][CTT], pa[NTW][CTT], pb[NTW][CTT];
             const KLayer& Ly = P.layer[ph.layer];
             // ---- accumulators; the epilogue's operands are requested by `prologue`, which the GEMM
             //      invokes after its last fragment load (or which runs directly when there is no GEMM)
 #pragma unroll
-            for (int i = 0; i < kNT; ++i)
+            for (int i = 0; i < NTW; ++i)
 #pragma unroll
                 for (int ct = 0; ct < CTT; ++ct) {
                     acc[i][ct] = (ph.flags & PHF_ACC_FROM_B) ? accb[i][ct] : splat(0.f);
@@ -667,16 +636,16 @@ __global__ __launch_bounds__(kThreads, CTT == 1 ? 2 : 1) void mcpc_steps_kernel(
                 }
             STAMP_T(0, ph.type);
             // ---- GEMM ------------------------------------------------------------------------------------
-            const bool early = P.pro_early || !(nt > 0 && ph.nkb > 0);
-            if (early) issue_epilogue_loads<CTT>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
+            // operands of the epilogue (x, targets: streamed; bias, E: L2/LDS) are requested ahead of the GEMM.
+            // (Requesting them after the GEMM's last fragment load was measured slower on MI355X.)
+            issue_epilogue_loads<CTT, NW>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
             if (nt > 0 && ph.nkb > 0)
-                gemm_tiles<kNT, CTT>(acc, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1,
-                                     P, ph, lds, early ? 0 : nt, wave, chain0, pa, pb);
+                gemm_tiles<NTW, CTT, NW>(acc, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
             // the next phase's first weight fragments travel while this phase's epilogue runs
-            if (has_next) prefetch_first_blocks(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
+            if (has_next) prefetch_first_blocks<NW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
             if (ph.flags & PHF_ACC_TO_B) {
 #pragma unroll
-                for (int i = 0; i < kNT; ++i)
+                for (int i = 0; i < NTW; ++i)
 #pragma unroll
                     for (int ct = 0; ct < CTT; ++ct) accb[i][ct] = acc[i][ct];
             }
@@ -684,17 +653,17 @@ __global__ __launch_bounds__(kThreads, CTT == 1 ? 2 : 1) void mcpc_steps_kernel(
             // ---- epilogue --------------------------------------------------------------------------------
             if (ph.type == PH_FWD) {
                 float esum;
-                if (Ly.act == MCPC_ACT_RELU) esum = fwd_epilogue<CTT, MCPC_ACT_RELU>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
-                else if (Ly.act == MCPC_ACT_TANH) esum = fwd_epilogue<CTT, MCPC_ACT_TANH>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
-                else esum = fwd_epilogue<CTT, MCPC_ACT_IDENTITY>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
-                if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[ph.layer * kWaves + wave] += esum; }
+                if (Ly.act == MCPC_ACT_RELU) esum = fwd_epilogue<CTT, NW, MCPC_ACT_RELU>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
+                else if (Ly.act == MCPC_ACT_TANH) esum = fwd_epilogue<CTT, NW, MCPC_ACT_TANH>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
+                else esum = fwd_epilogue<CTT, NW, MCPC_ACT_IDENTITY>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
+                if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[ph.layer * NW + wave] += esum; }
             } else if (ph.type == PH_HEADF) {
-                float lsum = headf_epilogue<CTT>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx, do_energy);
-                if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[kMaxLatent * kWaves + wave] += lsum; }
+                float lsum = headf_epilogue<CTT, NW>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx, do_energy);
+                if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[kMaxLatent * NW + wave] += lsum; }
             } else if (ph.type == PH_BWD) {
-                if (Ly.act == MCPC_ACT_RELU) bwd_epilogue_mode<CTT, MCPC_ACT_RELU>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
-                else if (Ly.act == MCPC_ACT_TANH) bwd_epilogue_mode<CTT, MCPC_ACT_TANH>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
-                else bwd_epilogue_mode<CTT, MCPC_ACT_IDENTITY>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
+                if (Ly.act == MCPC_ACT_RELU) bwd_epilogue_mode<CTT, NW, MCPC_ACT_RELU>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
+                else if (Ly.act == MCPC_ACT_TANH) bwd_epilogue_mode<CTT, NW, MCPC_ACT_TANH>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
+                else bwd_epilogue_mode<CTT, NW, MCPC_ACT_IDENTITY>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
             }
             STAMP_T(2, ph.type);
             if (ph.flags & PHF_SYNC) __syncthreads();
@@ -706,10 +675,11 @@ __global__ __launch_bounds__(kThreads, CTT == 1 ? 2 : 1) void mcpc_steps_kernel(
     }
 #ifdef MCPC_STAMPS
     if (lane == 0)
-        for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * kWaves + wave) * 16 + i] = st_sum[i];
+        for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * NW + wave) * 16 + i] = st_sum[i];
 #endif
 }
 
+#undef NTW
 // ------------------------------------------------------------------------------------------------
 // Weight packing into MFMA fragment order (run once per parameter change).
 //   forward : Wf[ut][kb][lane][r] = W[16ut + (lane&15)][16kb + 4(lane>>4) + r]
