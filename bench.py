@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--batch", type=int, default=6000, help="chains per GPU")
     ap.add_argument("--mode", choices=["learning", "inference"], default="learning")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed second call (other mode); used for clean PMC passes")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -162,7 +163,7 @@ def main():
 
     # secondary figure: the same K steps without Hebbian accumulation (training=False call)
     other = None
-    if world == 1:
+    if world == 1 and not args.no_secondary:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         one_call(K, not learning)
@@ -173,11 +174,19 @@ def main():
     finite = all(abs(v) < 1e30 for v in en)
     if rank == 0:
         q = eng.query()
-        flops_per_step = 4.0 * S_MACS * B    # algorithmic FLOPs: forward 2*S + back-projection 2*S per chain-step (BASELINE.md s5)
         avg_launch_s = kernel_ms * 1e-3 / max(n_launch, 1)
         steps_per_launch = n_ksteps / max(n_launch, 1)
+        flops_per_step = 4.0 * S_MACS * B    # algorithmic FLOPs: forward 2*S + back-projection 2*S per chain-step (BASELINE.md s5)
         achieved_tf = flops_per_step * steps_per_launch / avg_launch_s / 1e12
         bytes_per_step = 7472.0 * B
+        # HBM traffic of K1 per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled as the
+        # gfx950 guide prescribes, + WRITE_SIZE), stored by scripts/collect_traffic.py; None if never collected
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath) and B == 6000 and learning:
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic = tj.get("bytes_per_step", 0.0) * steps_per_launch if tj.get("bytes_per_step") else None
         out = {
             "metric": "Langevin inference steps/sec (whole node), MNIST MCPC 784-256-256-30, batch 6000",
             "value": world * K / dt,
@@ -206,7 +215,7 @@ def main():
                 "bound": "mfma",
                 "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP32_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
                 "flop_per_chain_step": 4 * S_MACS, "launches": n_launch, "steps_per_launch": steps_per_launch,
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "hbm_side": {"achieved": bytes_per_step * steps_per_launch / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS,
