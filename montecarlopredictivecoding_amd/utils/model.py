@@ -100,3 +100,54 @@ def get_model(config, use_cuda, sample_x_fn=sample_x_fn):
     if use_cuda:
         gen_pc.cuda()
     return gen_pc
+
+
+# ---- representations for down-stream probes (reference utils/model.py:71-163) ----------------------------
+def get_representations(gen_pc, config, trainers, loader, rep_type="MAP", use_cuda=False, n=None):
+    """Top-latent-layer representations of every batch of ``loader`` as a ``TensorDataset``.
+
+    rep_type "MAP"          x_1 after PC (MAP) inference with ``trainers[0]``;
+             "expectation"  mean of x_1 over ALL recorded Langevin steps of ``trainers[1]`` (started from the MAP state);
+             "full"         every ``sampling/n``-th sample after the mixing phase, labels repeated ``n`` times.
+    The Langevin trajectories come back from the engine's device-side record buffer in one copy.
+    """
+    from torch.utils.data import TensorDataset
+    device = next(gen_pc.parameters()).device
+    input_size = len(gen_pc[0].bias)
+    reps, labels = [], []
+    if rep_type != "MAP":
+        if len(trainers) != 2:
+            raise NotImplementedError
+        assert rep_type in ("full", "expectation")
+    pc_trainer = trainers[0]
+    stride = 1
+    if rep_type == "full":
+        if n is not None:
+            stride = int(config["sampling"] / n)
+        else:
+            n = config["sampling"]
+    for data, label in loader:
+        pseudo_input = torch.zeros(data.shape[0], input_size, device=device)
+        data, label = data.to(device), label.to(device)
+        kw = dict(inputs=pseudo_input, loss_fn=config["loss_fn"],
+                  loss_fn_kwargs={"_target": data, "_var": config["input_var"]},
+                  is_return_results_every_t=False, is_checking_after_callback_after_t=False)
+        pc_trainer.train_on_batch(is_log_progress=(rep_type == "MAP"), **kw)
+        if rep_type == "MAP":
+            reps.append(gen_pc[1].get_x().detach().clone())
+            labels.append(label)
+            continue
+        mcpc_trainer = trainers[1]
+        kw["is_return_results_every_t"] = True
+        results = mcpc_trainer.train_on_batch(
+            callback_after_t=random_step, callback_after_t_kwargs={"_pc_trainer": mcpc_trainer},
+            is_log_progress=False, is_sample_x_at_batch_start=False, is_return_representations=True, **kw)
+        traj = torch.stack(results["representations"]).to(device)          # [T, B, n_1]
+        if rep_type == "expectation":
+            reps.append(traj.mean(0))
+            labels.append(label)
+        else:
+            kept = traj[config["mixing"]::stride]
+            reps.append(kept.reshape(-1, traj.shape[2]))
+            labels.append(label.repeat(n))
+    return TensorDataset(torch.cat(reps, dim=0), torch.cat(labels, dim=0))

@@ -41,3 +41,75 @@ def get_mcpc_trainer_one_sample(gen_pc, config, training=True):
         optimizer_p_fn=config["optimizer_p_fn_mcpc"] if training else optim.SGD,
         optimizer_p_kwargs=config["optimizer_p_kwargs_mcpc"] if training else {"lr": 0.0},
         plot_progress_at=[])
+
+
+# ---- ancestral sampler and evaluators (reference utils/training_evaluation.py:72-100,140-206) -------------
+def sample_pc(num_samples, model, config, use_cuda=False, is_return_hidden=False):
+    """Ancestral sample of the generative model: unit-variance Gaussian noise is added at every PCLayer
+    (the prior of a PC layer with the default energy), the read-out is sampled from the sensory
+    distribution (Gaussian with ``input_var`` / Bernoulli of the logits) unless ``is_return_hidden``."""
+    import torch
+    from ..utils.model import bernoulli_fn, fe_fn
+    device = next(model.parameters()).device
+    temp = torch.zeros(num_samples, config["input_size"], device=device)
+    with torch.no_grad():
+        for module in model:
+            if isinstance(module, pc.PCLayer):
+                temp = temp + torch.randn_like(temp)
+            else:
+                temp = module(temp)
+        if is_return_hidden:
+            return temp.detach()
+        if config["loss_fn"] is fe_fn:
+            temp = temp + (config["input_var"] ** 0.5) * torch.randn_like(temp)
+        elif config["loss_fn"] is bernoulli_fn:
+            temp = (torch.rand_like(temp) <= temp.sigmoid()).double()
+    return temp.detach()
+
+
+def get_mse_rec(gen_pc, config, dataloader, use_cuda):
+    """Masked-reconstruction error: infer (MAP) from the bottom half of each image, score the top half."""
+    import torch
+    from ..utils.model import bernoulli_fn, bernoulli_fn_mask, fe_fn, fe_fn_mask
+    loss_fn = {fe_fn: fe_fn_mask, bernoulli_fn: bernoulli_fn_mask}[config["loss_fn"]]
+    gen_pc.train()
+    device = next(gen_pc.parameters()).device
+    pc_trainer = get_pc_trainer(gen_pc, config, training=False, is_mcpc=True)
+    mse, n_data = 0.0, 0
+    for data, _ in dataloader:
+        data = data.to(device)
+        pseudo_input = torch.zeros(data.shape[0], config["input_size"], device=device)
+        pc_trainer.train_on_batch(inputs=pseudo_input, loss_fn=loss_fn,
+                                  loss_fn_kwargs={"_target": data, "_var": config["input_var"]},
+                                  is_log_progress=False, is_return_results_every_t=False,
+                                  is_checking_after_callback_after_t=False)
+        with torch.no_grad():
+            img = gen_pc[-1](gen_pc[-2](gen_pc[-3].get_x().detach()))
+            if config["loss_fn"] is bernoulli_fn:
+                img = (img > 0).type_as(img)          # logits: threshold at 0
+            half = round(data.shape[1] / 2)
+            mse += float(((img[:, :-half] - data[:, :-half]) ** 2).mean(1).sum())
+        n_data += data.shape[0]
+    return mse / n_data
+
+
+def get_marginal_likelihood(gen_pc, config, dataloader, use_cuda, n_samples=5000):
+    """Importance-sampled log marginal likelihood per datum (Bernoulli read-out), samples from the prior."""
+    import torch
+    from ..utils.model import bernoulli_fn
+    if config["loss_fn"] is not bernoulli_fn:
+        raise NotImplementedError("the reference implements the Bernoulli read-out only (training_evaluation.py:196)")
+    logits = sample_pc(n_samples, gen_pc, config, use_cuda=use_cuda, is_return_hidden=True).clamp(-20, 20)   # [S, n0]
+    softplus = torch.nn.functional.softplus
+    sp = softplus(logits).sum(1)                                                                           # sum_j log(1+e^o)
+    total, count = 0.0, 0
+    with torch.no_grad():
+        for data, _ in dataloader:
+            data = data.to(logits.device).to(logits.dtype)
+            # BCE(o, y) summed over pixels = sum softplus(o) - y.o
+            nll = sp.unsqueeze(0) - data @ logits.t()                                                       # [B, S]
+            m = nll.min(1).values
+            p = torch.exp(-(nll - m.unsqueeze(1))).mean(1)
+            total += float((torch.log(p) - m).sum())
+            count += data.shape[0]
+    return total / count
