@@ -249,7 +249,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     e->out_pad = pad16(d->n_out);
     if (e->has_head && e->npad[e->L - 1] / 16 > kNT * kWaves) {
         delete e;
-        return fail(MCPC_ENOMEM, "last latent layer wider than %d units is not supported by the fused read-out (kNTB tiles per wave)", kNT * kWaves * 16);
+        return fail(MCPC_ENOMEM, "last latent layer wider than %d units is not supported by the fused read-out (its back-projection is held in 16 register tiles per workgroup)", kNT * kWaves * 16);
     }
     int rc = plan_lds(e);
     if (rc) { delete e; return rc; }

@@ -1,0 +1,191 @@
+"""Full-size (cfg-M: 30-256-256-784, B = 6000) checks through size-independent properties, plus edge cases.
+
+The oracle cannot run 6000 chains x thousands of steps in seconds, so at full size the tests use what the
+domain offers: chains are independent (a subset can be replayed on the oracle with the NumPy twin of the
+device noise), trajectories must not depend on how chains are sharded or on how a call is cut into launches,
+the deterministic PC path must be bitwise reproducible, overall = loss + sum of layer energies, and plain
+gradient descent on F (no noise, small lr) must not increase F.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mcpc_oracle as mo
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+SIZES, N_OUT, B = [30, 256, 256], 784, 6000
+
+
+def _problem(batch=B, seed=30):
+    from bench import make_problem
+    return make_problem(batch, seed, DEV)
+
+
+def _engine(batch, W, b, y, **kw):
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, batch, device=DEV, **kw)
+    eng.bind_params(W, b)
+    eng.bind_inputs(None)
+    eng.bind_target(y)
+    return eng
+
+
+def _run(eng, xs, T, **kw):
+    from montecarlopredictivecoding_amd import _lib as L
+    eng.load_state(xs)
+    args = dict(loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=77, step_base=1000,
+                energy_mode=L.ENERGY_ALL)
+    args.update(kw)
+    res = eng.run(T, **args)
+    out = [torch.empty_like(x) for x in xs]
+    eng.store_state(out)
+    torch.cuda.synchronize()
+    return res, out
+
+
+def test_full_size_subset_matches_oracle_and_energy_identity():
+    W, b, y, xs = _problem()
+    eng = _engine(B, W, b, y)
+    T = 20
+    res, out = _run(eng, xs, T, acc_begin=5, acc_end=T)
+    en = res.energies.cpu().numpy()
+    np.testing.assert_allclose(en[:, -1], en[:, 0] + en[:, 1:4].sum(1), rtol=1e-12)      # overall = loss + energies
+    assert np.all(np.isfinite(en)) and np.all(en[:, 4:7] == 0)
+    # chains are independent: replay chains 4000..4031 on the oracle with the NumPy twin of the device noise
+    lo, n = 4000, 32
+    Wn, bn = [w.cpu().numpy() for w in W], [x.cpu().numpy() for x in b]
+    net = mo.NetSpec(sizes=SIZES, acts=[mo.ACT_RELU] * 3, W=Wn, b=bn)
+    ref = mo.run(net, np.zeros((n, 30), np.float32), [x[lo:lo + n].cpu().numpy() for x in xs],
+                 mo.LossSpec(mo.LOSS_BERNOULLI, y[lo:lo + n].cpu().numpy()), mo.XOpt(mo.OPT_SGD, 0.03), T,
+                 noise=lambda t, l: philox.layer_normals(77, 1000 + t, l, lo, n, SIZES[l]))
+    for l in range(3):
+        np.testing.assert_allclose(out[l][lo:lo + n].cpu().numpy(), ref.xs[l], rtol=0, atol=2e-3)
+    eng.close()
+
+
+def test_sharding_and_launch_slicing_do_not_change_trajectories():
+    """Global chain ids feed the Philox counter: 6000 chains as one shard, as two shards of 3000, or one shard
+    advanced in three launches give bit-identical states; the Hebbian sums agree up to summation order."""
+    W, b, y, xs = _problem()
+    T = 12
+    eng = _engine(B, W, b, y)
+    res, whole = _run(eng, xs, T, acc_begin=4, acc_end=T)
+    flat_whole = eng.read_param_grads_flat().cpu().numpy()
+    # (a) three launches of the same call
+    from montecarlopredictivecoding_amd import _lib as L
+    eng.load_state(xs)
+    for t0, n in ((0, 5), (5, 3), (8, 4)):
+        eng.run(T, t_begin=t0, n_steps=n, loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=77,
+                step_base=1000, acc_begin=4, acc_end=T, acc_reset=(t0 <= 4 < t0 + n))
+    sliced = [torch.empty_like(x) for x in xs]
+    eng.store_state(sliced)
+    flat_sliced = eng.read_param_grads_flat().cpu().numpy()
+    for a, c in zip(whole, sliced):
+        assert torch.equal(a, c)
+    np.testing.assert_allclose(flat_sliced, flat_whole, rtol=1e-4, atol=1e-6 * np.abs(flat_whole).max())   # summation order only
+    eng.close()
+    # (b) two shards with global chain ids
+    flat_sum = 0.0
+    for lo in (0, 3000):
+        e2 = _engine(3000, W, b, y[lo:lo + 3000].contiguous())
+        _, part = _run(e2, [x[lo:lo + 3000].contiguous() for x in xs], T, acc_begin=4, acc_end=T, chain_base=lo)
+        for l in range(3):
+            assert torch.equal(part[l], whole[l][lo:lo + 3000])
+        flat_sum = flat_sum + e2.read_param_grads_flat().cpu().numpy()
+        e2.close()
+    np.testing.assert_allclose(flat_sum, flat_whole, rtol=1e-4, atol=1e-6 * np.abs(flat_whole).max())
+
+
+def test_pc_path_is_bitwise_reproducible_and_descends():
+    """cfg-PC: noise = 0.  Two runs are bit-identical (energies included: fixed-order reductions, no float atomics),
+    and F = loss + energy never increases under plain gradient descent with a small step."""
+    from montecarlopredictivecoding_amd import _lib as L
+    W, b, y, xs = _problem()
+    eng = _engine(B, W, b, y)
+    xs_small = [x * 0.1 for x in xs]
+    runs = []
+    for _ in range(2):
+        res, out = _run(eng, xs_small, 40, noise_mode=L.NOISE_NONE, lr=0.01, acc_begin=0, acc_end=40)
+        runs.append((res.energies.cpu().numpy().copy(), [o.cpu().numpy() for o in out],
+                     eng.read_param_grads_flat().cpu().numpy()))
+    assert np.array_equal(runs[0][0], runs[1][0])
+    for a, c in zip(runs[0][1], runs[1][1]):
+        assert np.array_equal(a, c)
+    assert np.array_equal(runs[0][2], runs[1][2])            # Hebbian sums: slab reduction in a fixed order
+    F = runs[0][0][:, -1]
+    assert np.all(np.diff(F) <= 1e-6 * np.abs(F[:-1]))
+    # Adam on x (the MAP warm-up of every figure script): deterministic too
+    a1, _ = _run(eng, xs_small, 25, noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.1)
+    a2, _ = _run(eng, xs_small, 25, noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.1)
+    assert torch.equal(a1.energies, a2.energies)
+    eng.close()
+
+
+def test_workgroup_variants_agree():
+    """16-chain / 32-chain workgroups (MCPC_CT, MCPC_NW) are different schedules of the same arithmetic."""
+    import os
+    W, b, y, xs = _problem(640)
+    outs = []
+    for ct, nw in (("16", "4"), ("32", "8"), ("32", "4")):
+        os.environ["MCPC_CT"], os.environ["MCPC_NW"] = ct, nw
+        try:
+            eng = _engine(640, W, b, y)
+            assert eng.query()["chains_per_wg"] == int(ct)
+            res, out = _run(eng, xs, 15, acc_begin=3, acc_end=15)
+            outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], eng.read_param_grads_flat().cpu().numpy()))
+            eng.close()
+        finally:
+            del os.environ["MCPC_CT"], os.environ["MCPC_NW"]
+    for k in (1, 2):
+        np.testing.assert_allclose(outs[k][0], outs[0][0], rtol=1e-6)      # per-wave fp32 partial sums differ in grouping
+        for a, c in zip(outs[k][1], outs[0][1]):
+            assert np.array_equal(a, c)            # same k-order per chain: identical fp32 results
+        np.testing.assert_allclose(outs[k][2], outs[0][2], rtol=1e-4, atol=1e-6 * np.abs(outs[0][2]).max())
+
+
+@pytest.mark.parametrize("batch,sizes,n_out,T", [(1, [20, 128, 128], 784, 7), (3, [1], 1, 1), (33, [5], 0, 4),
+                                                 (17, [2, 3, 4, 5, 6, 7], 9, 3)])
+def test_edge_shapes_against_oracle(batch, sizes, n_out, T):
+    """Single chain (figure_3b), T = 1 (figure_4.py T_pc), no read-out, six latent layers, ragged everything."""
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    from oracle.cases import make_case_inputs
+    case = dict(sizes=sizes, acts=["tanh"] * len(sizes), ecoef=[1.0 + 0.5 * i for i in range(len(sizes))], n_in=sizes[0],
+                n_out=n_out, loss="gaussian" if n_out else "none", var=0.7, perc=0.5, B=batch, seed=4242, x0_range=1.5,
+                calls=[dict(T=T)])
+    W, b, X0, inputs, target = make_case_inputs(case)
+    net = mo.NetSpec(sizes=sizes, acts=[mo.ACT_TANH] * len(sizes), W=W, b=b, ecoef=case["ecoef"], has_head=bool(n_out))
+    loss = mo.LossSpec(mo.LOSS_GAUSSIAN, target, 0.7) if n_out else mo.LossSpec()
+    ref = mo.run(net, inputs, X0, loss, mo.XOpt(mo.OPT_SGD, 0.05), T,
+                 noise=lambda t, l: philox.layer_normals(9, t, l, 0, batch, sizes[l]), accumulate_p_at=list(range(T)))
+    eng = Engine(sizes, [L.ACT_TANH] * len(sizes), sizes[0], n_out, batch, device=DEV, ecoef=case["ecoef"])
+    eng.bind_params([torch.from_numpy(w).to(DEV) for w in W], [torch.from_numpy(x).to(DEV) for x in b])
+    eng.bind_inputs(None)
+    if n_out:
+        eng.bind_target(torch.from_numpy(target).to(DEV))
+    xs = [torch.from_numpy(x).to(DEV) for x in X0]
+    eng.load_state(xs)
+    res = eng.run(T, loss_kind=L.LOSS_GAUSSIAN if n_out else L.LOSS_NONE, loss_var=0.7, lr=0.05, noise_mode=L.NOISE_PHILOX,
+                  seed=9, step_base=0, acc_begin=0, acc_end=T, energy_mode=L.ENERGY_ALL)
+    eng.store_state(xs)
+    np.testing.assert_allclose(res.energies.cpu().numpy()[:, -1], ref.overall, rtol=5e-5, atol=1e-6)
+    for l in range(len(sizes)):
+        np.testing.assert_allclose(xs[l].cpu().numpy(), ref.xs[l], rtol=0, atol=3e-4)
+    flat = eng.read_param_grads_flat().cpu().numpy()
+    want = np.concatenate([np.concatenate([gw.reshape(-1), gb.reshape(-1)]) for gw, gb in zip(ref.gW, ref.gb)])
+    np.testing.assert_allclose(flat, want, rtol=3e-4, atol=3e-4 * max(1.0, np.abs(want).max()))
+    eng.close()
+
+
+def test_oversized_networks_are_rejected_not_miscomputed():
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    with pytest.raises(L.MCPCError, match="LDS"):
+        Engine([64, 4096, 4096], [1, 1, 1], 64, 0, 32, device=DEV)
+    with pytest.raises(L.MCPCError, match="last latent layer"):
+        Engine([32, 384], [1, 1], 32, 100, 32, device=DEV)
+    with pytest.raises(ValueError):
+        Engine([4] * 7, [0] * 7, 4, 0, 8, device=DEV)
