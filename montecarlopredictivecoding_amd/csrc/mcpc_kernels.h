@@ -72,6 +72,8 @@ struct KPhase {
     int b_lds, ldb;        // B operand: LDS float offset and row stride
     int flags;             // PHF_*
     float sign;            // BWD: g = e + sign * f'(x) * back
+    int out_lds, out_ld;   // HEADF: LDS offset / row stride of the e_o chunk this phase writes
+    int dep_e, dep_g;      // wave-specialised kernel: entry whose completion by all E / all G waves must precede (-1: none)
 };
 
 struct KParams {
@@ -94,7 +96,9 @@ struct KParams {
     int acc_begin, acc_end, spill_t0;   // spill slot of step t = t - spill_t0 when acc_begin <= t < acc_end
     int energy_mode;
     int rec_begin, rec_stride, rec_count;
-    int lds_red;           // float offset of the energy reduction scratch [2][kMaxLatent+1][kWaves]
+    int lds_red;           // float offset of the energy reduction scratch [2][kMaxLatent+1][kMaxWaves]
+    int lds_ws_sync, lds_ws_stage;   // wave-specialised kernel: progress counters / accumulator staging slots
+    int ws_prio;                     // 1: epilogue waves run at raised static priority
 #ifdef MCPC_STAMPS
     unsigned long long* dbg;   // diagnostic build only: [nwg][kWaves][16] cycle sums per phase
 #endif
@@ -141,10 +145,9 @@ __device__ __forceinline__ void st4s(float* p, f32x4 v) { __builtin_nontemporal_
 __device__ __forceinline__ f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return r; }
 
 
-#define NTW (16 / NW)
 // Request the operands of a phase's epilogue (x, targets, mu1: streamed from HBM/MALL; bias, E from
 // L2/LDS) into pa/pb, ahead of the phase's GEMM.
-template <int CTT, int NW>
+template <int CTT, int NW, int NTW>
 __device__ __forceinline__ void issue_epilogue_loads(const KParams& P, const KPhase& ph, const float* lds, int nt, int wave,
                                                      int lane, int chain0, f32x4 (&pa)[NTW][CTT], f32x4 (&pb)[NTW][CTT]) {
     const KLayer& Ly = P.layer[ph.layer];
@@ -278,7 +281,7 @@ __device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const gf32x4*
 
 // request the fragments of k-blocks 0 and 1 of a phase's GEMM (issued one phase early: weights do not
 // depend on any barrier, so their L2 round trip hides behind the previous epilogue)
-template <int NW>
+template <int NW, int NTW>
 __device__ __forceinline__ void prefetch_first_blocks(const KPhase& ph, int wave, int lane, int& nt, int (&aoff)[NTW],
                                                       f32x4 (&pre0)[NTW], f32x4 (&pre1)[NTW]) {
     nt = (ph.ntiles - wave + NW - 1) / NW;
@@ -345,7 +348,7 @@ template <int ACT> __device__ __forceinline__ float actd(float x, float fx) {
 }
 
 // ---- FWD epilogue: prediction errors, energies, activations to LDS, spills, trajectory records -------
-template <int CTT, int NW, int ACT>
+template <int CTT, int NW, int NTW, int ACT>
 __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph, float* lds, int nt, int wave, int lane,
                                               int chain0, const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
                                               const f32x4 (&pb)[NTW][CTT], int slot, int rec_idx) {
@@ -399,15 +402,15 @@ __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph
 }
 
 // ---- HEADF epilogue: read-out, loss error e_o into the LDS chunk, loss value, spills, output records ----
-template <int CTT, int NW>
+template <int CTT, int NW, int NTW>
 __device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& ph, float* lds, int nt, int wave, int lane,
                                                 int chain0, const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
                                                 const f32x4 (&pb)[NTW][CTT], int slot, int rec_idx, bool do_energy) {
     const KHead& H = P.head;
     const int c = lane & 15, q = lane >> 4;
-    const int npad = H.npad, n = H.n, ld = H.ld, B = P.B, Bpad = P.Bpad, mask_start = H.mask_start, kind = H.loss_kind;
+    const int npad = H.npad, n = H.n, ld = ph.out_ld, B = P.B, Bpad = P.Bpad, mask_start = H.mask_start, kind = H.loss_kind;
     const float inv_var = H.inv_var;
-    float* const eo_lds = lds + H.lds_eo;
+    float* const eo_lds = lds + ph.out_lds;
     float* const spill = H.spill_e;
     float* const rec = (rec_idx >= 0 && H.rec_out != nullptr) ? H.rec_out + (size_t)rec_idx * B * n : nullptr;
     float lsum = 0.f;
@@ -439,18 +442,20 @@ __device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& 
                         ev[r] = on ? inv_var * dlt : 0.f;
                         lsum += on ? 0.5f * inv_var * dlt * dlt : 0.f;
                     }
+                } else if (do_energy) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool on = live && (u0 + r) >= mask_start && (u0 + r) < n;
+                        float sg, bc;
+                        sigmoid_bce_f(ov[r], yv[r], sg, bc);
+                        ev[r] = on ? sg - yv[r] : 0.f;
+                        lsum += on ? bc : 0.f;
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool on = live && (u0 + r) >= mask_start && (u0 + r) < n;
                         ev[r] = on ? sigmoid_f(ov[r]) - yv[r] : 0.f;
-                    }
-                    if (do_energy) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const bool on = live && (u0 + r) >= mask_start && (u0 + r) < n;
-                            lsum += on ? bce_logits_f(ov[r], yv[r]) : 0.f;
-                        }
                     }
                 }
                 e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
@@ -466,7 +471,7 @@ __device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& 
 // ---- BWD epilogue: x update of the phase's layer --------------------------------------------------------
 //   g = e + sign * f'(x) * back ;  MODE 1: SGD, no noise   MODE 2: SGD + fused Philox kick   MODE 0: everything
 //   else (Adam, external noise, gradients-only) behind wave-uniform branches.
-template <int CTT, int NW, int ACT, int MODE>
+template <int CTT, int NW, int NTW, int ACT, int MODE>
 __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph, int nt, int wave, int lane, int chain0,
                                              const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
                                              const f32x4 (&pb)[NTW][CTT], int s, int t) {
@@ -537,17 +542,18 @@ __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph,
     }
 }
 
-template <int CTT, int NW, int ACT>
+template <int CTT, int NW, int NTW, int ACT>
 __device__ __forceinline__ void bwd_epilogue_mode(const KParams& P, const KPhase& ph, int nt, int wave, int lane, int chain0,
                                                   const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
                                                   const f32x4 (&pb)[NTW][CTT], int s, int t, int mode) {
-    if (mode == 2) bwd_epilogue<CTT, NW, ACT, 2>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
-    else if (mode == 1) bwd_epilogue<CTT, NW, ACT, 1>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
-    else bwd_epilogue<CTT, NW, ACT, 0>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
+    if (mode == 2) bwd_epilogue<CTT, NW, NTW, ACT, 2>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
+    else if (mode == 1) bwd_epilogue<CTT, NW, NTW, ACT, 1>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
+    else bwd_epilogue<CTT, NW, NTW, ACT, 0>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
 }
 
 template <int CTT, int NW>
 __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_steps_kernel(const KParams P) {
+    constexpr int NTW = 16 / NW;     // unit tiles per wave per phase (a phase hands out 16 tiles)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
     f32x4 pre0_next[NTW], pre1_next[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) { pre0_next[i] = splat(0.f); pre1_next[i] = splat(0.f); }
-    prefetch_first_blocks<NW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
+    prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
 
     for (int s = 0; s < P.n_steps; ++s) {
         const int t = P.t0 + s;
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
                         P.epart[((size_t)erow * gridDim.x + blockIdx.x) * (kMaxLatent + 1) + tid] = v;
                     }
                 }
-                if (has_next) prefetch_first_blocks<NW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
+                if (has_next) prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
                 STAMP(12);
                 continue;
             }
@@ -638,11 +644,11 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
             // ---- GEMM ------------------------------------------------------------------------------------
             // operands of the epilogue (x, targets: streamed; bias, E: L2/LDS) are requested ahead of the GEMM.
             // (Requesting them after the GEMM's last fragment load was measured slower on MI355X.)
-            issue_epilogue_loads<CTT, NW>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
+            issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
             if (nt > 0 && ph.nkb > 0)
                 gemm_tiles<NTW, CTT, NW>(acc, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
             // the next phase's first weight fragments travel while this phase's epilogue runs
-            if (has_next) prefetch_first_blocks<NW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
+            if (has_next) prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
             if (ph.flags & PHF_ACC_TO_B) {
 #pragma unroll
                 for (int i = 0; i < NTW; ++i)
@@ -653,17 +659,17 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
             // ---- epilogue --------------------------------------------------------------------------------
             if (ph.type == PH_FWD) {
                 float esum;
-                if (Ly.act == MCPC_ACT_RELU) esum = fwd_epilogue<CTT, NW, MCPC_ACT_RELU>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
-                else if (Ly.act == MCPC_ACT_TANH) esum = fwd_epilogue<CTT, NW, MCPC_ACT_TANH>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
-                else esum = fwd_epilogue<CTT, NW, MCPC_ACT_IDENTITY>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
+                if (Ly.act == MCPC_ACT_RELU) esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_RELU>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
+                else if (Ly.act == MCPC_ACT_TANH) esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_TANH>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
+                else esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_IDENTITY>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx);
                 if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[ph.layer * NW + wave] += esum; }
             } else if (ph.type == PH_HEADF) {
-                float lsum = headf_epilogue<CTT, NW>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx, do_energy);
+                float lsum = headf_epilogue<CTT, NW, NTW>(P, ph, lds, nt, wave, lane, chain0, acc, pa, pb, slot, rec_idx, do_energy);
                 if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[kMaxLatent * NW + wave] += lsum; }
             } else if (ph.type == PH_BWD) {
-                if (Ly.act == MCPC_ACT_RELU) bwd_epilogue_mode<CTT, NW, MCPC_ACT_RELU>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
-                else if (Ly.act == MCPC_ACT_TANH) bwd_epilogue_mode<CTT, NW, MCPC_ACT_TANH>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
-                else bwd_epilogue_mode<CTT, NW, MCPC_ACT_IDENTITY>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
+                if (Ly.act == MCPC_ACT_RELU) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_RELU>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
+                else if (Ly.act == MCPC_ACT_TANH) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_TANH>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
+                else bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_IDENTITY>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, upd_mode);
             }
             STAMP_T(2, ph.type);
             if (ph.flags & PHF_SYNC) __syncthreads();
@@ -679,7 +685,6 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
 #endif
 }
 
-#undef NTW
 // ------------------------------------------------------------------------------------------------
 // Weight packing into MFMA fragment order (run once per parameter change).
 //   forward : Wf[ut][kb][lane][r] = W[16ut + (lane&15)][16kb + 4(lane>>4) + r]
@@ -940,3 +945,5 @@ __global__ void mcpc_philox_kernel(uint64_t seed, uint64_t step, int layer, uint
 }
 
 }  // namespace mcpc
+
+#include "mcpc_steps_ws.h"
