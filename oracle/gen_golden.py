@@ -112,8 +112,11 @@ def run_reference_call(pc, um, model, call, inputs, target, XI, case, device="cp
     T = call["T"]
     xfn = optim.SGD if call["xopt"] == "sgd" else optim.Adam
     p_fn = {"sgd": optim.SGD, "adam": optim.Adam}[call.get("popt", "sgd")]
+    xkw = {"lr": call["lr"]}
+    xkw.update(call.get("xopt_extra", {}))            # e.g. SGD momentum: not fusable -> step-wise path
     trainer = pc.PCTrainer(
-        model, T=T, update_x_at="all", optimizer_x_fn=xfn, optimizer_x_kwargs={"lr": call["lr"]},
+        model, T=T, update_x_at=call.get("update_x_at", "all"), optimizer_x_fn=xfn, optimizer_x_kwargs=xkw,
+        x_lr_discount=call.get("x_lr_discount", 1.0), x_lr_amplifier=call.get("x_lr_amplifier", 1.0),
         update_p_at=call.get("update_p_at", "never"),
         accumulate_p_at=call.get("accumulate_p_at", "never"),
         optimizer_p_fn=p_fn, optimizer_p_kwargs=call.get("popt_kwargs", {"lr": 0.0}),
@@ -132,6 +135,13 @@ def run_reference_call(pc, um, model, call, inputs, target, XI, case, device="cp
                 x.grad.copy_(torch.from_numpy(XI[t][l]).to(device) * (-std))
             optimizer.step()
         kw = dict(callback_after_t=injected_random_step, callback_after_t_kwargs={"_pc_trainer": trainer})
+    if "clip_x_grad" in call:       # a user callback between backward and the x step (pc_trainer.py:865-866)
+        clip = call["clip_x_grad"]
+
+        def clip_grads(t, _pc_trainer):
+            for x in _pc_trainer.get_model_xs():
+                x.grad.clamp_(-clip, clip)
+        kw.update(callback_after_backward=clip_grads, callback_after_backward_kwargs={"_pc_trainer": trainer})
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         res = trainer.train_on_batch(
@@ -289,6 +299,19 @@ def all_cases():
         calls=[dict(T=25, xopt="sgd", lr=0.03, noise=True, update_p_at="last",
                     accumulate_p_at=list(range(10, 25)), popt="sgd", popt_kwargs={"lr": 0.0},
                     record_at=[0, 24])])
+    # G9: generic API features that run on the step-wise HIP path
+    base9 = dict(sizes=[6, 16, 16], acts=["tanh"] * 3, ecoef=[1.0] * 3, n_in=6, n_out=24, loss="gaussian", var=0.5,
+                 perc=0.5, B=8, x0_range=2.0)
+    cases["g9_update_p_all"] = dict(base9, seed=9001, calls=[dict(
+        T=6, xopt="sgd", lr=0.03, noise=True, update_p_at="all", popt="sgd", popt_kwargs={"lr": 0.01}, record_at=[0, 5])])
+    cases["g9_x_lr_discount"] = dict(base9, seed=9002, calls=[dict(
+        T=15, xopt="sgd", lr=0.4, noise=False, x_lr_discount=0.7, record_at=[0, 14])])
+    cases["g9_clip_after_backward"] = dict(base9, seed=9003, x0_range=6.0, calls=[dict(
+        T=10, xopt="sgd", lr=0.05, noise=True, clip_x_grad=0.8, record_at=[0, 9])])
+    cases["g9_sgd_momentum_x"] = dict(base9, seed=9004, calls=[dict(
+        T=10, xopt="sgd", lr=0.03, noise=False, xopt_extra={"momentum": 0.5}, record_at=[0, 9])])
+    cases["g9_update_x_last_half"] = dict(base9, seed=9005, calls=[dict(
+        T=10, xopt="sgd", lr=0.05, noise=False, update_x_at="last_half", record_at=[0, 4, 5, 9])])
     return cases
 
 
@@ -305,8 +328,14 @@ def cfg_m_case():
 def main():
     pc, um = import_reference()
     made = []
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
     for name, case in all_cases().items():
+        if only and not name.startswith(only):
+            continue
         made.append(gen_case(pc, um, name, case))
+    if only:
+        print("wrote", made)
+        return
     made.append(gen_case(pc, um, "g2_cfgM_b64", cfg_m_case(), store_inputs=False, grad_samples=7))
     total = sum(os.path.getsize(p) for p in made)
     print(f"wrote {len(made)} fixtures, {total/1024:.0f} KiB total -> {GOLDEN}")

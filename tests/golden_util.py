@@ -13,8 +13,12 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ACT = {"identity": mo.ACT_IDENTITY, "relu": mo.ACT_RELU, "tanh": mo.ACT_TANH}
 
 
-def fixture_names(prefix=""):
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+def fixture_names(prefix="", exclude=()):
+    """Fixture names; ``exclude`` drops prefixes (g9_* exercise trainer control flow -- per-step parameter updates,
+    dynamic x learning rate, user callbacks, custom x optimizers -- that only the facade replays, not the
+    closed-form oracle or a single mcpc_run)."""
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    return [n for n in names if not any(n.startswith(x) for x in exclude)]
 
 
 class Golden:

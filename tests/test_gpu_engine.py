@@ -106,7 +106,7 @@ def check_against_golden(g, ci, call, res, eng, xs_final, sched, x_atol=3e-4, e_
             np.testing.assert_allclose(np.abs(dW.astype(np.float64)).sum(), g.get(ci, f"gW{j}_abs"), rtol=2e-4)
 
 
-@pytest.mark.parametrize("name", fixture_names())
+@pytest.mark.parametrize("name", fixture_names(exclude=("g9_",)))
 def test_engine_matches_reference_golden(name):
     g = Golden(name)
     eng = make_engine(g)

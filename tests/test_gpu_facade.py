@@ -54,7 +54,9 @@ def _replay(name, small_only=True):
 def test_facade_replays_reference_harness(name):
     grads_carried = True     # .grad of earlier calls is only present if those calls materialised it
     for g, ci, call, out, grads, lins, trainer in _replay(name):
-        assert trainer.last_call_mode == ("stepwise" if call.get("noise", False) else "fused")
+        generic = any(k in call for k in ("x_lr_discount", "clip_x_grad", "xopt_extra", "update_x_at")) or \
+            call.get("update_p_at", "never") == "all"
+        assert trainer.last_call_mode == ("stepwise" if (call.get("noise", False) or generic) else "fused")
         np.testing.assert_allclose(out["energy"], g.get(ci, "energy"), rtol=3e-5, atol=1e-5)
         np.testing.assert_allclose(out["overall"], g.get(ci, "overall"), rtol=3e-5, atol=1e-5)
         if g.case["loss"] != "none":

@@ -28,7 +28,7 @@ def run_oracle_case(g, dtype=np.float32):
             b = [g.get(ci, f"b{j}_after") if bb is not None else None for j, bb in enumerate(b)]
 
 
-@pytest.mark.parametrize("name", fixture_names())
+@pytest.mark.parametrize("name", fixture_names(exclude=("g9_",)))
 def test_oracle_matches_reference(name):
     g = Golden(name)
     nc = g.case.get("rec_chains", None)
