@@ -329,7 +329,12 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     e->ct = 16; e->nw = 4;
     if (const char* env = getenv("MCPC_CT")) { const int v = atoi(env); if (v == 16 || v == 32) e->ct = v; }
     if (const char* env = getenv("MCPC_NW")) { const int v = atoi(env); if (v == 4 || (v == 8 && e->ct == 32)) e->nw = v; }
-    if (const char* env = getenv("MCPC_WS")) { if (atoi(env) == 1) { e->ws = 1; e->ct = 32; e->nw = 8; } }
+    // Default schedule: the wave-specialised kernel (32 chains, 4 GEMM + 4 epilogue waves) when the shard is large
+    // enough to give every CU a workgroup, otherwise 16-chain workgroups (twice as many of them).  MCPC_WS=0/1,
+    // MCPC_CT, MCPC_NW override for experiments; a WS plan that does not fit the LDS falls back below.
+    bool want_ws = d->batch >= 4096 && !getenv("MCPC_CT") && !getenv("MCPC_NW");
+    if (const char* env = getenv("MCPC_WS")) want_ws = atoi(env) == 1;
+    if (want_ws) { e->ws = 1; e->ct = 32; e->nw = 8; }
     e->nwg = e->Bpad / e->ct;
     for (int l = 0; l < e->L; ++l) e->npad[l] = pad16(d->sizes[l]);
     e->out_pad = pad16(d->n_out);
@@ -338,6 +343,10 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
         return fail(MCPC_ENOMEM, "last latent layer wider than %d units is not supported by the fused read-out (its back-projection is held in 16 register tiles per workgroup)", kNT * kWaves * 16);
     }
     int rc = plan_lds(e);
+    if (rc && e->ws) {                       // the staging slots do not fit: classic 16-chain schedule
+        e->ws = 0; e->ct = 16; e->nw = 4; e->nwg = e->Bpad / e->ct;
+        rc = plan_lds(e);
+    }
     if (rc) { delete e; return rc; }
 
     auto bail = [&](int code) { free_all(e); delete e; return code; };

@@ -63,8 +63,9 @@ __device__ __forceinline__ float act_d(int a, float x, float fx) {
 }
 
 __device__ __forceinline__ float sigmoid_f(float o) {
-    const float e = __builtin_amdgcn_exp2f(-o * 1.4426950408889634f);  // exp(-o)
-    return __builtin_amdgcn_rcpf(1.0f + e);
+    // same arithmetic as sigmoid_bce_f below, so that recording the loss never changes a trajectory
+    const float e = __builtin_amdgcn_exp2f(-fabsf(o) * 1.4426950408889634f);  // exp(-|o|)
+    return (o >= 0.0f ? 1.0f : e) * __builtin_amdgcn_rcpf(1.0f + e);
 }
 // BCEWithLogits element: max(o,0) - o*y + log1p(exp(-|o|))
 __device__ __forceinline__ float bce_logits_f(float o, float y) {

@@ -125,12 +125,13 @@ def test_pc_path_is_bitwise_reproducible_and_descends():
 
 
 def test_workgroup_variants_agree():
-    """16-chain / 32-chain workgroups (MCPC_CT, MCPC_NW) are different schedules of the same arithmetic."""
+    """16-chain / 32-chain workgroups and the wave-specialised kernel (MCPC_CT, MCPC_NW, MCPC_WS) are different
+    schedules of the same arithmetic."""
     import os
     W, b, y, xs = _problem(640)
     outs = []
-    for ct, nw in (("16", "4"), ("32", "8"), ("32", "4")):
-        os.environ["MCPC_CT"], os.environ["MCPC_NW"] = ct, nw
+    for ct, nw, ws in (("16", "4", "0"), ("32", "8", "0"), ("32", "4", "0"), ("32", "8", "1")):
+        os.environ["MCPC_CT"], os.environ["MCPC_NW"], os.environ["MCPC_WS"] = ct, nw, ws
         try:
             eng = _engine(640, W, b, y)
             assert eng.query()["chains_per_wg"] == int(ct)
@@ -138,8 +139,8 @@ def test_workgroup_variants_agree():
             outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], eng.read_param_grads_flat().cpu().numpy()))
             eng.close()
         finally:
-            del os.environ["MCPC_CT"], os.environ["MCPC_NW"]
-    for k in (1, 2):
+            del os.environ["MCPC_CT"], os.environ["MCPC_NW"], os.environ["MCPC_WS"]
+    for k in (1, 2, 3):
         np.testing.assert_allclose(outs[k][0], outs[0][0], rtol=1e-6)      # per-wave fp32 partial sums differ in grouping
         for a, c in zip(outs[k][1], outs[0][1]):
             assert np.array_equal(a, c)            # same k-order per chain: identical fp32 results
