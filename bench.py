@@ -154,6 +154,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    eng.sync_check()          # raises if a kernel reported a device-side fault during the timed call
     kernel_ms, n_launch, n_ksteps = eng.last_step_kernel_ms()
     eng.set_profiling(False)
     if dist is not None:

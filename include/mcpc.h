@@ -18,8 +18,8 @@
  * code; mcpc_last_error() returns a human-readable message for the calling thread.
  *
  * Threading: one engine per (device, stream); an engine is not re-entrant.  All launches are
- * asynchronous on the given stream; nothing in this API synchronises the host except
- * mcpc_create/mcpc_destroy (allocation).
+ * asynchronous on the given stream; the only host-synchronising calls are mcpc_create /
+ * mcpc_destroy (allocation), mcpc_sync_check and mcpc_last_step_kernel_ms.
  */
 #ifndef MCPC_H
 #define MCPC_H
@@ -158,6 +158,11 @@ int64_t mcpc_param_count(const mcpc_engine* e);
  * generator exposed for bit-exactness tests against oracle/philox.py. raw != 0 writes the u32 stream. */
 int mcpc_philox_normals(int device, uint64_t seed, uint64_t step, int layer, uint64_t chain_base,
                         int batch, int n_units, float* out, int raw, void* stream);
+
+/* Synchronise `stream` and report device-side faults of the runs issued so far (the wave-specialised step kernel
+ * bounds every intra-workgroup wait; a wait that runs out is recorded instead of hanging the GPU).
+ * Returns MCPC_ESTATE if the last results must not be used.  The only host-synchronising call besides create/destroy. */
+int mcpc_sync_check(mcpc_engine* e, void* stream);
 
 /* Introspection for benchmarks / DESIGN.md: bytes of LDS per workgroup, chains per workgroup,
  * workgroups per step launch, spill slots. */

@@ -92,6 +92,7 @@ struct mcpc_engine {
     // per-step phase table (device copy)
     KPhase* phases = nullptr;
     int n_phases = 0;
+    int* err = nullptr;             // device error word written by the kernels
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -107,7 +108,7 @@ namespace {
 int free_all(mcpc_engine* e) {
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int l = 0; l < kMaxLatent; ++l) { F(e->x[l]); F(e->m[l]); F(e->v[l]); F(e->spill_a[l]); F(e->spill_e[l]); }
-    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases);
+    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err);
     for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (int h = 0; h < 2; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
@@ -404,6 +405,8 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if (e->has_head && (rc = dmalloc(e->spill_eo, (size_t)e->slots * e->Bpad * e->out_pad))) return bail(rc);
 
     if ((rc = e->ws ? build_phases_ws(e) : build_phases(e))) return bail(rc);
+    if ((rc = dmalloc(e->err, 1))) return bail(rc);
+    if (hipMemset(e->err, 0, sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
     const void* kfn = e->ws ? (const void*)mcpc_steps_ws_kernel<2>
                       : e->ct == 16 ? (const void*)mcpc_steps_kernel<1, 4>
                       : (e->nw == 8 ? (const void*)mcpc_steps_kernel<2, 8> : (const void*)mcpc_steps_kernel<2, 4>);
@@ -664,6 +667,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     P.lds_red = e->lds_red;
     P.lds_ws_sync = e->lds_ws_sync; P.lds_ws_stage = e->lds_ws_stage;
     { const char* v = getenv("MCPC_WS_PRIO"); P.ws_prio = v ? atoi(v) : 1; }
+    P.err = e->err;
 #ifdef MCPC_STAMPS
     if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * kMaxWaves * 16); if (rc) return rc; }
     P.dbg = e->dbg;
@@ -832,6 +836,19 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
     if (chains_per_wg) *chains_per_wg = e->ct;
     if (n_workgroups) *n_workgroups = e->nwg;
     if (spill_slots) *spill_slots = e->slots;
+    return MCPC_OK;
+}
+
+int mcpc_sync_check(mcpc_engine* e, void* stream_) {
+    if (!e) return fail(MCPC_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->d.device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, e->err, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag != 0) {
+        (void)hipMemset(e->err, 0, sizeof(int));
+        return fail(MCPC_ESTATE, "the step kernel reported error word 0x%x (a workgroup-internal progress wait ran out): results of the last run are invalid", flag);
+    }
     return MCPC_OK;
 }
 

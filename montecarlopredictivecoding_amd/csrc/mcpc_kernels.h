@@ -99,6 +99,7 @@ struct KParams {
     int lds_red;           // float offset of the energy reduction scratch [2][kMaxLatent+1][kMaxWaves]
     int lds_ws_sync, lds_ws_stage;   // wave-specialised kernel: progress counters / accumulator staging slots
     int ws_prio;                     // 1: epilogue waves run at raised static priority
+    int* err;                        // device error word (bit 0/1: a progress-counter wait ran out)
 #ifdef MCPC_STAMPS
     unsigned long long* dbg;   // diagnostic build only: [nwg][kWaves][16] cycle sums per phase
 #endif

@@ -208,6 +208,10 @@ class Engine:
         L.check(self._lib.mcpc_read_param_grads_flat(self._h, _ptr(flat), flat.numel(), scale, self._stream()))
         return flat
 
+    def sync_check(self):
+        """Synchronise the stream and raise MCPCError if a kernel reported a device-side fault."""
+        L.check(self._lib.mcpc_sync_check(self._h, self._stream()))
+
     # ---- introspection -----------------------------------------------------------------------------
     def query(self):
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()

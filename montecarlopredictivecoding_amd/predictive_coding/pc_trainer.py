@@ -488,7 +488,8 @@ class PCTrainer(object):
                          is_return_xs, loss_fn):
         net = plan["net"]
         results = {"loss": [], "energy": [], "overall": []}
-        en = res.energies.cpu().numpy()            # the one host sync of the call
+        self._engine_for(plan).sync_check()        # the one host sync of the call (also surfaces device-side faults)
+        en = res.energies.cpu().numpy()
         rows = range(T) if is_return_results_every_t else [0]
         nl = len(net.sizes)
         for r in rows:

@@ -42,7 +42,7 @@ def _run(eng, xs, T, **kw):
     res = eng.run(T, **args)
     out = [torch.empty_like(x) for x in xs]
     eng.store_state(out)
-    torch.cuda.synchronize()
+    eng.sync_check()          # stream sync + device-side fault word
     return res, out
 
 
