@@ -76,6 +76,18 @@ struct KPhase {
     int dep_e, dep_g;      // wave-specialised kernel: entry whose completion by all E / all G waves must precede (-1: none)
 };
 
+// Phase descriptors are fetched through the constant address space: wave-uniform s_load_* on the scalar cache.
+// (Through a generic pointer hipcc emits a vector load + readfirstlane and an `s_waitcnt vmcnt(0)` that drains the
+// weight-fragment prefetch at every phase boundary, and keeps the descriptor in scratch.)
+__device__ __forceinline__ KPhase load_phase(const KPhase* tbl, int p) {
+    typedef __attribute__((address_space(4))) const int cint;
+    cint* w = (cint*)(tbl + p);
+    union { KPhase ph; int v[sizeof(KPhase) / 4]; } u;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(KPhase) / 4); ++i) u.v[i] = w[i];
+    return u.ph;
+}
+
 struct KParams {
     KLayer layer[kMaxLatent];
     KHead head;
@@ -153,36 +165,33 @@ __device__ __forceinline__ void issue_epilogue_loads(const KParams& P, const KPh
                                                      int lane, int chain0, f32x4 (&pa)[NTW][CTT], f32x4 (&pb)[NTW][CTT]) {
     const KLayer& Ly = P.layer[ph.layer];
     const int c = lane & 15, q = lane >> 4;
+    const int type = ph.type;
+    const bool mu1 = (ph.flags & PHF_MU1) != 0, lay0 = ph.layer == 0, has_loss = P.head.loss_kind != MCPC_LOSS_NONE;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        if (i < nt) {
-            const int u0 = 16 * (ph.tile0 + wave + NW * i) + 4 * q;
-            if (ph.type == PH_FWD) {
-                const f32x4 bias = (ph.flags & PHF_MU1) ? splat(0.f) : ld4(Ly.bias + u0);
+        const int u0 = 16 * (ph.tile0 + wave + NW * i) + 4 * q;
 #pragma unroll
-                for (int ct = 0; ct < CTT; ++ct) {
-                    const size_t row = (size_t)(chain0 + 16 * ct + c) * Ly.npad + u0;
-                    pa[i][ct] = ld4s(Ly.x + row);
-                    pb[i][ct] = (ph.flags & PHF_MU1) ? ld4s(P.mu1 + row) : bias;
-                }
-            } else if (ph.type == PH_HEADF) {
-                const f32x4 bias = ld4(P.head.bias + u0);
-#pragma unroll
-                for (int ct = 0; ct < CTT; ++ct) {
-                    pb[i][ct] = bias;
-                    if (P.head.loss_kind != MCPC_LOSS_NONE)
-                        pa[i][ct] = ld4s(P.head.y + (size_t)(chain0 + 16 * ct + c) * P.head.npad + u0);
-                }
-            } else if (ph.type == PH_BWD) {
-#pragma unroll
-                for (int ct = 0; ct < CTT; ++ct) {
-                    const int cl = 16 * ct + c;
+        for (int ct = 0; ct < CTT; ++ct) {
+            // every (i, ct) slot is assigned exactly once, from locals: keeps pa / pb in registers (stores to the
+            // same slot from several branches get tail-merged into an indexed store, i.e. a stack array)
+            f32x4 va = splat(0.f), vb = splat(0.f);
+            if (i < nt) {
+                const int cl = 16 * ct + c;
+                if (type == PH_FWD) {
                     const size_t row = (size_t)(chain0 + cl) * Ly.npad + u0;
-                    pa[i][ct] = ld4s(Ly.x + row);
-                    pb[i][ct] = (ph.layer == 0) ? (pa[i][ct] - ld4s(P.mu1 + row)) * Ly.ecoef
-                                                : ld4(lds + Ly.lds_e + cl * Ly.ld + u0);
+                    va = ld4s(Ly.x + row);
+                    vb = mu1 ? ld4s(P.mu1 + row) : ld4(Ly.bias + u0);
+                } else if (type == PH_HEADF) {
+                    vb = ld4(P.head.bias + u0);
+                    if (has_loss) va = ld4s(P.head.y + (size_t)(chain0 + cl) * P.head.npad + u0);
+                } else if (type == PH_BWD) {
+                    const size_t row = (size_t)(chain0 + cl) * Ly.npad + u0;
+                    va = ld4s(Ly.x + row);
+                    vb = lay0 ? (va - ld4s(P.mu1 + row)) * Ly.ecoef : ld4(lds + Ly.lds_e + cl * Ly.ld + u0);
                 }
             }
+            pa[i][ct] = va;
+            pb[i][ct] = vb;
         }
     }
 }
@@ -367,7 +376,7 @@ __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph
     // transcendental / LDS / global latencies of a single wave (a rolled loop serialises them)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        if (i >= nt) break;
+        if (i >= nt) continue;
         f32x4 a[CTT], xa[CTT], xb[CTT];
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) { a[ct] = acc[i][ct]; xa[ct] = pa[i][ct]; xb[ct] = pb[i][ct]; }
@@ -419,7 +428,7 @@ __device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& 
     // transcendental / LDS / global latencies of a single wave (a rolled loop serialises them)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        if (i >= nt) break;
+        if (i >= nt) continue;
         f32x4 a[CTT], xa[CTT], xb[CTT];
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) { a[ct] = acc[i][ct]; xa[ct] = pa[i][ct]; xb[ct] = pb[i][ct]; }
@@ -486,7 +495,7 @@ __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph,
     // transcendental / LDS / global latencies of a single wave (a rolled loop serialises them)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        if (i >= nt) break;
+        if (i >= nt) continue;
         f32x4 a[CTT], xa[CTT], xb[CTT];
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) { a[ct] = acc[i][ct]; xa[ct] = pa[i][ct]; xb[ct] = pb[i][ct]; }
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
     }
     STAMP_DECL
     // software pipeline over phases: descriptor + first two weight k-blocks of the upcoming phase
-    KPhase ph_next = P.phases[0];
+    KPhase ph_next = load_phase(P.phases, 0);
     int nt_next, aoff_next[NTW];
     f32x4 pre0_next[NTW], pre1_next[NTW];
 #pragma unroll
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
             for (int i = 0; i < NTW; ++i) { aoff[i] = aoff_next[i]; pre0[i] = pre0_next[i]; pre1[i] = pre1_next[i]; }
             // descriptor of the phase after this one (wraps into the next step)
             const bool has_next = (p + 1 < P.n_phases) || (s + 1 < P.n_steps);
-            if (has_next) ph_next = P.phases[p + 1 < P.n_phases ? p + 1 : 0];
+            if (has_next) ph_next = load_phase(P.phases, p + 1 < P.n_phases ? p + 1 : 0);
             if (ph.type == PH_ENERGY) {
                 if (do_energy) {
                     __syncthreads();   // uniform branch: publishes every wave's red[] entries of this step

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws_kernel(const KParams P) 
 
     if (is_g) {
         // =========================== G: fragments + MFMAs ==============================================
-        KPhase ph_next = P.phases[0];
+        KPhase ph_next = load_phase(P.phases, 0);
         int nt_next, aoff_next[4];
         f32x4 pre0_next[4], pre1_next[4];
 #pragma unroll
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws_kernel(const KParams P) 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { aoff4[i] = aoff_next[i]; pre0[i] = pre0_next[i]; pre1[i] = pre1_next[i]; }
                 const bool has_next = (p + 1 < n_ent) || (s + 1 < P.n_steps);
-                if (has_next) ph_next = P.phases[p + 1 < n_ent ? p + 1 : 0];
+                if (has_next) ph_next = load_phase(P.phases, p + 1 < n_ent ? p + 1 : 0);
                 const bool upd_only = (ph.type == PH_BWD && ph.nkb == 0);       // hand accb to the partner
                 if (!(ph.flags & PHF_WS_GEMM) && !upd_only) {
                     if (has_next) ws_prefetch(ph_next, k, lane, nt_next, aoff_next, pre0_next, pre1_next);
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws_kernel(const KParams P) 
         if (do_energy && lane <= kMaxLatent) red[lane * kMaxWaves + k] = 0.f;
 #pragma unroll 1
         for (int p = 0; p < n_ent; ++p) {
-            const KPhase ph = P.phases[p];
+            const KPhase ph = load_phase(P.phases, p);
             if (ph.type == PH_ENERGY) {
                 if (do_energy && k == 0) {
                     // every E wave has finished the forward entries of this step (their red[] slots are final)
