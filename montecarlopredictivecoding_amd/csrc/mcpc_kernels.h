@@ -158,40 +158,40 @@ __device__ __forceinline__ void st4s(float* p, f32x4 v) { __builtin_nontemporal_
 __device__ __forceinline__ f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return r; }
 
 
-// Request the operands of a phase's epilogue (x, targets, mu1: streamed from HBM/MALL; bias, E from
-// L2/LDS) into pa/pb, ahead of the phase's GEMM.
+// Request the operands of a phase's epilogue (x, targets: streamed from HBM/MALL; mu1, bias from L2; E from LDS)
+// into pa/pb, ahead of the phase's GEMM.  Branch-free on purpose: the entry type only selects ADDRESSES, every slot
+// issues the same three loads (one streamed, one cached, one LDS).  With a load inside an `if` hipcc joins the
+// branches behind an `s_waitcnt vmcnt(0)`, which serialised the slots at full HBM latency each.
 template <int CTT, int NW, int NTW>
 __device__ __forceinline__ void issue_epilogue_loads(const KParams& P, const KPhase& ph, const float* lds, int nt, int wave,
                                                      int lane, int chain0, f32x4 (&pa)[NTW][CTT], f32x4 (&pb)[NTW][CTT]) {
     const KLayer& Ly = P.layer[ph.layer];
     const int c = lane & 15, q = lane >> 4;
-    const int type = ph.type;
-    const bool mu1 = (ph.flags & PHF_MU1) != 0, lay0 = ph.layer == 0, has_loss = P.head.loss_kind != MCPC_LOSS_NONE;
+    const bool is_head = ph.type == PH_HEADF, is_bwd = ph.type == PH_BWD;
+    const bool mu1 = (ph.flags & PHF_MU1) != 0 || (is_bwd && ph.layer == 0);
+    const bool has_y = is_head && P.head.loss_kind != MCPC_LOSS_NONE;
+    // streamed operand: x_l (FWD, BWD) or the target (HEADF with a loss; without one any valid row of x)
+    const float* const baseA = has_y ? P.head.y : Ly.x;
+    const int strideA = has_y ? P.head.npad : Ly.npad;
+    // cached operand: mu1 rows (top layer), else the bias of the Linear that produced the accumulators
+    const float* const baseB = mu1 ? P.mu1 : (is_head ? P.head.bias : Ly.bias);
+    const int strideB = mu1 ? Ly.npad : 0;
+    const int tile_last = ph.tile0 + (ph.ntiles > 0 ? ph.ntiles - 1 : 0);   // entries without tiles (ENERGY) still load valid rows
+    const float ecoef = Ly.ecoef;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const int u0 = 16 * (ph.tile0 + wave + NW * i) + 4 * q;
+        int ut = ph.tile0 + wave + NW * i;                     // slots past nt re-read the entry's last tile (never used)
+        ut = ut > tile_last ? tile_last : ut;
+        const int u0 = 16 * ut + 4 * q;
+        const int uA = (is_head && !has_y) ? 0 : u0;
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
-            // every (i, ct) slot is assigned exactly once, from locals: keeps pa / pb in registers (stores to the
-            // same slot from several branches get tail-merged into an indexed store, i.e. a stack array)
-            f32x4 va = splat(0.f), vb = splat(0.f);
-            if (i < nt) {
-                const int cl = 16 * ct + c;
-                if (type == PH_FWD) {
-                    const size_t row = (size_t)(chain0 + cl) * Ly.npad + u0;
-                    va = ld4s(Ly.x + row);
-                    vb = mu1 ? ld4s(P.mu1 + row) : ld4(Ly.bias + u0);
-                } else if (type == PH_HEADF) {
-                    vb = ld4(P.head.bias + u0);
-                    if (has_loss) va = ld4s(P.head.y + (size_t)(chain0 + cl) * P.head.npad + u0);
-                } else if (type == PH_BWD) {
-                    const size_t row = (size_t)(chain0 + cl) * Ly.npad + u0;
-                    va = ld4s(Ly.x + row);
-                    vb = lay0 ? (va - ld4s(P.mu1 + row)) * Ly.ecoef : ld4(lds + Ly.lds_e + cl * Ly.ld + u0);
-                }
-            }
+            const int cl = 16 * ct + c;
+            const f32x4 va = ld4s(baseA + (size_t)(chain0 + cl) * strideA + uA);
+            const f32x4 vg = ld4(baseB + (size_t)(chain0 + cl) * strideB + u0);
+            const f32x4 ve = ld4(lds + Ly.lds_e + cl * Ly.ld + (is_bwd ? u0 : 4 * q));
             pa[i][ct] = va;
-            pb[i][ct] = vb;
+            pb[i][ct] = is_bwd ? (mu1 ? (va - vg) * ecoef : ve) : vg;
         }
     }
 }
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
             // ---- GEMM ------------------------------------------------------------------------------------
             // operands of the epilogue (x, targets: streamed; bias, E: L2/LDS) are requested ahead of the GEMM.
             // (Requesting them after the GEMM's last fragment load was measured slower on MI355X.)
-            issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
+            if (ph.type != PH_HEADB) issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
             if (nt > 0 && ph.nkb > 0)
                 gemm_tiles<NTW, CTT, NW>(acc, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
             // the next phase's first weight fragments travel while this phase's epilogue runs

@@ -21,6 +21,15 @@ constexpr int kWsSpinLimit = 1 << 24;  // iterations (~0.2 us each): seconds, fa
 
 enum : int { PHF_WS_GEMM = 16, PHF_WS_EPI = 32 };   // which role has work in a table entry
 
+// Everything the two roles hand to each other lives in LDS (global data written by an E wave -- x, spills, energies --
+// is only re-read by the same lane or by later kernels), so the hand-off fences order LDS accesses only: a full
+// workgroup-scope release would also drain every outstanding global store (`s_waitcnt vmcnt(0)`) at each publish.
+#ifdef MCPC_EXP_FULLFENCE
+#define MCPC_WS_FENCE(order_) __builtin_amdgcn_fence(order_, "workgroup")
+#else
+#define MCPC_WS_FENCE(order_) __builtin_amdgcn_fence(order_, "workgroup", "local")
+#endif
+
 struct WsSync {                        // lives in LDS
     int prog_e[4];
     int prog_g[4];
@@ -40,7 +49,7 @@ __device__ __forceinline__ void ws_wait_all(const int* p, int need, int* err) {
         __builtin_amdgcn_s_sleep(2);
     }
     if (spin == kWsSpinLimit && (threadIdx.x & 63) == 0) atomicOr(err, 1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    MCPC_WS_FENCE(__ATOMIC_ACQUIRE);
 }
 __device__ __forceinline__ void ws_wait_one(const int* p, int need, int* err) {
     int spin = 0;
@@ -49,10 +58,10 @@ __device__ __forceinline__ void ws_wait_one(const int* p, int need, int* err) {
         __builtin_amdgcn_s_sleep(2);
     }
     if (spin == kWsSpinLimit && (threadIdx.x & 63) == 0) atomicOr(err, 2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    MCPC_WS_FENCE(__ATOMIC_ACQUIRE);
 }
 __device__ __forceinline__ void ws_publish(int* p, int v) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // LDS / global writes of this wave before the counter
+    MCPC_WS_FENCE(__ATOMIC_RELEASE);     // LDS writes of this wave before the counter
     ws_st(p, v);
 }
 
@@ -244,6 +253,9 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws_kernel(const KParams P) 
                 ++handoffs;
                 if (lane == 0) ws_publish(&sync->stage_empty[k], handoffs);
             }
+#ifdef MCPC_EXP_NOEPI   // timing experiment only (wrong results): E waves skip the epilogue arithmetic and stores
+            if (P.n_steps < 0)
+#endif
             if (ph.type == PH_FWD) {
                 float esum;
                 if (Ly.act == MCPC_ACT_RELU) esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_RELU>(P, ph, lds, nt, k, lane, chain0, acc, pa, pb, slot, rec_idx);
