@@ -249,14 +249,20 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4*
     // tail: 0..4 k-blocks left, sets P (kb) and Q (kb+1) are loaded when they exist
     const int rem = nkb - kb;
     if (rem == 4) {
+        // pinned like the steady state: unpinned, hipcc moved the last request behind set R's MFMAs (re-using R's
+        // registers) and waited for it at once -- one exposed L2 round trip per GEMM with 16 k-blocks
         MCPC_LOAD_SET(aR, bR, kb + 2);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_block<NT, NTT, CTT>(acc, aP, bP);
+        __builtin_amdgcn_sched_barrier(0);
         MCPC_LOAD_SET(aP, bP, kb + 3);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
         mfma_block<NT, NTT, CTT>(acc, aR, bR);
         mfma_block<NT, NTT, CTT>(acc, aP, bP);
     } else if (rem == 3) {
         MCPC_LOAD_SET(aR, bR, kb + 2);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_block<NT, NTT, CTT>(acc, aP, bP);
         mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
         mfma_block<NT, NTT, CTT>(acc, aR, bR);
