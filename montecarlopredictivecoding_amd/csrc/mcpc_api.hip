@@ -58,7 +58,8 @@ struct mcpc_engine {
     int L = 0, Bpad = 0, nwg = 0, has_head = 0;
     int ct = kCT;                   // chains per workgroup: 16 (two workgroups per CU) or 32
     int nw = kWaves;                // waves per workgroup: 4, or 8 with 32 chains (two waves per SIMD, one workgroup per CU)
-    int ws = 0;                     // 1: wave-specialised kernel (4 GEMM waves + 4 epilogue waves, 32 chains)
+    int ws = 0;                     // 1: wave-specialised kernel with staging slots; 2: in-place variant (4 GEMM + 4 epilogue waves, 32 chains)
+    int ws2_chunk = 0;              // in-place variant: read-out tiles per chunk
     int lds_ws_sync = 0, lds_ws_stage = 0;
     int npad[kMaxLatent]{};
     int out_pad = 0;
@@ -150,6 +151,133 @@ int plan_lds(mcpc_engine* e) {
     e->lds_bytes = off * (int)sizeof(float);
     if (e->lds_bytes > 160 * 1024)
         return fail(MCPC_ENOMEM, "network needs %d bytes of LDS per workgroup (> 163840): latent widths too large for the fused kernel", e->lds_bytes);
+    return 0;
+}
+
+// LDS plan of the in-place wave-specialised kernel: every FX_l and E_l has its own rows (no overlays, no staging
+// slots); the read-out error lives in a ring of two chunks of `ws2_chunk` tiles, the largest that still fits.
+int plan_lds_ws2(mcpc_engine* e) {
+    const int CT = e->ct;
+    int off = 0;
+    for (int l = 0; l < e->L; ++l) { e->lds_a[l] = off; off += CT * (e->npad[l] + kLdPad); }
+    e->lds_e[0] = 0;
+    for (int l = 1; l < e->L; ++l) { e->lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
+    e->lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
+    e->lds_ws_sync = off; off += 16;
+    e->lds_ws_stage = 0;
+    e->lds_eo = off;
+    e->ws2_chunk = 0;
+    if (e->has_head) {
+        for (int hc : {8, 6, 4, 2}) {
+            if ((off + 2 * CT * (hc * 16 + kLdPad)) * (int)sizeof(float) <= 160 * 1024) { e->ws2_chunk = hc; break; }
+        }
+        if (!e->ws2_chunk) return fail(MCPC_ENOMEM, "in-place schedule does not fit the LDS");
+        off += 2 * CT * (e->ws2_chunk * 16 + kLdPad);
+    }
+    e->lds_bytes = off * (int)sizeof(float);
+    if (e->lds_bytes > 160 * 1024) return fail(MCPC_ENOMEM, "in-place schedule does not fit the LDS (%d bytes)", e->lds_bytes);
+    return 0;
+}
+
+// Table of the in-place wave-specialised kernel (mcpc_steps_ws2.h).  One step =
+//   read-out chunks  HF(0) HF(1) HB(0) HF(2) HB(1) ...   with the forward entries FWD_{L-1} ... FWD_1, FWD_0 slipped
+//   in one at a time behind the HB entries, then the updates BWD_{L-1} ... BWD_0 and the energy reduction.
+// Read dependencies (dep_e, "all E waves past entry"):  HF(c) <- last BWD_{L-1} of the PREVIOUS step (FX_{L-1});
+//   HB(c) <- HF(c);  FWD_l <- last BWD_{l-1} of the previous step (FX_{l-1});  BWD_l GEMM <- last FWD_{l+1} (E_{l+1}).
+// Write-after-read: only the chunk ring needs its own dependency (dep_g, "all G waves past entry"): HF(c) <- HB(c-2).
+// The others are implied: a G wave that stores into E_l / FX_l / FX_{L-1} has just waited for epilogues that can
+// only have run after every G wave finished the GEMMs that read the old contents (FWD_l after the BWD_{l-1}
+// epilogues, BWD_l after the FWD_{l+1} epilogues, the BWD_{L-1} hand-off after HB(last) <- HF(last) epilogues).
+int build_phases_ws2(mcpc_engine* e) {
+    const int L = e->L;
+    const int span = kWsPairs * kWsNT;       // 8
+    auto tiles = [&](int l) { return e->npad[l] / 16; };
+    auto blank = [&]() { KPhase k{}; k.dep_e = -1; k.dep_g = -1; return k; };
+    enum { REF_NONE = -1, REF_LAST_BWD = -1000, REF_LAST_FWD = -2000 };   // symbolic deps: REF_x - layer
+    // forward entries, bottom layer first (its input FX_{L-2} is refreshed first)
+    std::vector<KPhase> fwd;
+    for (int l = L - 1; l >= 0; --l)
+        for (int base = 0; base < tiles(l); base += span) {
+            KPhase k = blank();
+            k.type = PH_FWD; k.layer = l; k.tile0 = base; k.ntiles = std::min(span, tiles(l) - base);
+            if (l == 0) {
+                k.flags = PHF_MU1 | PHF_WS_EPI;
+            } else {
+                k.A = (const f32x4*)e->lin[l].Wf; k.a_tile_stride = tiles(l - 1) * 64; k.nkb = tiles(l - 1);
+                k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
+                k.out_lds = e->lds_e[l]; k.out_ld = e->npad[l] + kLdPad;
+                k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_BWD - (l - 1);
+            }
+            fwd.push_back(k);
+        }
+    std::vector<KPhase> ph;
+    size_t nf = 0;
+    if (e->has_head) {
+        const int hc = e->ws2_chunk;
+        const int ht = e->out_pad / 16;
+        const int nch = (ht + hc - 1) / hc;
+        const int chunk_floats = e->ct * (hc * 16 + kLdPad);
+        std::vector<int> idx_f(nch, -1), idx_b(nch, -1);
+        auto add_f = [&](int c) {
+            KPhase f = blank();
+            f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c * hc; f.ntiles = std::min(hc, ht - c * hc); f.rot = c & 3;
+            f.A = (const f32x4*)e->lin[L].Wf; f.a_tile_stride = tiles(L - 1) * 64; f.nkb = tiles(L - 1);
+            f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad;
+            f.out_lds = e->lds_eo + (c & 1) * chunk_floats; f.out_ld = hc * 16 + kLdPad;
+            f.flags = PHF_WS_GEMM | PHF_WS_EPI; f.dep_e = REF_LAST_BWD - (L - 1);
+            f.dep_g = c >= 2 ? idx_b[c - 2] : -1;
+            idx_f[c] = (int)ph.size(); ph.push_back(f);
+        };
+        auto add_b = [&](int c) {
+            KPhase b = blank();
+            b.type = PH_HEADB; b.layer = L - 1; b.tile0 = 0; b.ntiles = tiles(L - 1);
+            b.A = (const f32x4*)e->lin[L].Wb; b.a_tile_stride = ht * 64; b.a_off0 = c * hc * 64;
+            b.nkb = std::min(hc, ht - c * hc);
+            b.b_lds = e->lds_eo + (c & 1) * chunk_floats; b.ldb = hc * 16 + kLdPad;
+            b.flags = PHF_WS_GEMM; b.dep_e = idx_f[c];
+            idx_b[c] = (int)ph.size(); ph.push_back(b);
+            if (nf < fwd.size()) ph.push_back(fwd[nf++]);      // one forward entry behind every back-projection
+        };
+        add_f(0);
+        for (int c = 1; c < nch; ++c) { add_f(c); add_b(c - 1); }
+        add_b(nch - 1);
+    }
+    while (nf < fwd.size()) ph.push_back(fwd[nf++]);
+    // x updates, bottom layer first
+    for (int base = 0; base < tiles(L - 1); base += span) {
+        KPhase k = blank();
+        k.type = PH_BWD; k.layer = L - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(L - 1) - base);
+        k.flags = PHF_WS_EPI | (e->has_head ? PHF_WS2_HANDOFF : 0);
+        k.sign = e->has_head ? 1.0f : 0.0f;
+        k.out_lds = e->lds_a[L - 1]; k.out_ld = e->npad[L - 1] + kLdPad;
+        ph.push_back(k);
+    }
+    for (int l = L - 1; l >= 1; --l)
+        for (int base = 0; base < tiles(l - 1); base += span) {
+            KPhase k = blank();
+            k.type = PH_BWD; k.layer = l - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(l - 1) - base);
+            k.A = (const f32x4*)e->lin[l].Wb; k.a_tile_stride = tiles(l) * 64; k.nkb = tiles(l);
+            k.b_lds = e->lds_e[l]; k.ldb = e->npad[l] + kLdPad; k.sign = -1.0f;
+            k.out_lds = e->lds_a[l - 1]; k.out_ld = e->npad[l - 1] + kLdPad;
+            k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_FWD - l;
+            ph.push_back(k);
+        }
+    { KPhase k = blank(); k.type = PH_ENERGY; k.flags = PHF_WS_EPI; ph.push_back(k); }
+    // resolve the symbolic dependencies
+    std::vector<int> last_fwd(L, -1), last_bwd(L, -1);
+    for (size_t i = 0; i < ph.size(); ++i) {
+        if (ph[i].type == PH_FWD) last_fwd[ph[i].layer] = (int)i;
+        if (ph[i].type == PH_BWD) last_bwd[ph[i].layer] = (int)i;
+    }
+    for (auto& k : ph) {
+        if (k.dep_e <= REF_LAST_FWD) k.dep_e = last_fwd[REF_LAST_FWD - k.dep_e];
+        else if (k.dep_e <= REF_LAST_BWD) k.dep_e = last_bwd[REF_LAST_BWD - k.dep_e];
+    }
+    int rc = dmalloc(e->phases, ph.size());
+    if (rc) return rc;
+    if (hipMemcpy(e->phases, ph.data(), ph.size() * sizeof(KPhase), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(MCPC_EHIP, "hipMemcpy of the phase table failed");
+    e->n_phases = (int)ph.size();
     return 0;
 }
 
@@ -333,9 +461,9 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     // Default schedule: the wave-specialised kernel (32 chains, 4 GEMM + 4 epilogue waves) when the shard is large
     // enough to give every CU a workgroup, otherwise 16-chain workgroups (twice as many of them).  MCPC_WS=0/1,
     // MCPC_CT, MCPC_NW override for experiments; a WS plan that does not fit the LDS falls back below.
-    bool want_ws = d->batch >= 4096 && !getenv("MCPC_CT") && !getenv("MCPC_NW");
-    if (const char* env = getenv("MCPC_WS")) want_ws = atoi(env) == 1;
-    if (want_ws) { e->ws = 1; e->ct = 32; e->nw = 8; }
+    int want_ws = (d->batch >= 4096 && !getenv("MCPC_CT") && !getenv("MCPC_NW")) ? 1 : 0;
+    if (const char* env = getenv("MCPC_WS")) { const int v = atoi(env); want_ws = (v == 1 || v == 2) ? v : 0; }
+    if (want_ws) { e->ws = want_ws; e->ct = 32; e->nw = 8; }
     e->nwg = e->Bpad / e->ct;
     for (int l = 0; l < e->L; ++l) e->npad[l] = pad16(d->sizes[l]);
     e->out_pad = pad16(d->n_out);
@@ -343,8 +471,8 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
         delete e;
         return fail(MCPC_ENOMEM, "last latent layer wider than %d units is not supported by the fused read-out (its back-projection is held in 16 register tiles per workgroup)", kNT * kWaves * 16);
     }
-    int rc = plan_lds(e);
-    if (rc && e->ws) {                       // the staging slots do not fit: classic 16-chain schedule
+    int rc = e->ws == 2 ? plan_lds_ws2(e) : plan_lds(e);
+    if (rc && e->ws) {                       // the wave-specialised plan does not fit: classic 16-chain schedule
         e->ws = 0; e->ct = 16; e->nw = 4; e->nwg = e->Bpad / e->ct;
         rc = plan_lds(e);
     }
@@ -404,10 +532,10 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     }
     if (e->has_head && (rc = dmalloc(e->spill_eo, (size_t)e->slots * e->Bpad * e->out_pad))) return bail(rc);
 
-    if ((rc = e->ws ? build_phases_ws(e) : build_phases(e))) return bail(rc);
+    if ((rc = e->ws == 2 ? build_phases_ws2(e) : e->ws ? build_phases_ws(e) : build_phases(e))) return bail(rc);
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
     if (hipMemset(e->err, 0, sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
-    const void* kfn = e->ws ? (const void*)mcpc_steps_ws_kernel<2>
+    const void* kfn = e->ws == 2 ? (const void*)mcpc_steps_ws2_kernel<2> : e->ws ? (const void*)mcpc_steps_ws_kernel<2>
                       : e->ct == 16 ? (const void*)mcpc_steps_kernel<1, 4>
                       : (e->nw == 8 ? (const void*)mcpc_steps_kernel<2, 8> : (const void*)mcpc_steps_kernel<2, 4>);
     hipError_t herr = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
@@ -710,7 +838,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             }
             HIP_TRY(hipEventRecord(e->events[e->events_used].first, stream));
         }
-        if (e->ws) hipLaunchKernelGGL((mcpc_steps_ws_kernel<2>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
+        if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
+        else if (e->ws) hipLaunchKernelGGL((mcpc_steps_ws_kernel<2>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
         else if (e->ct == 16) hipLaunchKernelGGL((mcpc_steps_kernel<1, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
         else if (e->nw == 8) hipLaunchKernelGGL((mcpc_steps_kernel<2, 8>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
         else hipLaunchKernelGGL((mcpc_steps_kernel<2, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
@@ -723,6 +852,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         {
             static const char* names_ws[16] = {"G other", "G wait dep(E)", "G HEADB gemm", "G gemm", "G wait stage free", "G handoff",
                                                "-", "-", "E other", "E loads+dep", "E wait stage", "E epilogue", "-", "-", "-", "-"};
+            static const char* names_ws2[16] = {"G top", "G wait deps", "G HEADB gemm", "G gemm", "G prefetch next", "G store+publish",
+                                                "G entry w/o GEMM", "G acc init", "E other", "E loads", "E wait block", "E epilogue", "-", "-", "-", "-"};
             static const char* names[16] = {"FWD prologue", "FWD gemm", "FWD epilogue", "HEADF prologue", "HEADF gemm", "HEADF epilogue",
                                             "HEADB prologue", "HEADB gemm", "HEADB (acc->b)", "BWD prologue", "BWD gemm", "BWD epilogue",
                                             "energy", "barrier", "-", "-"};
@@ -735,7 +866,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             for (int i = 0; i < 16; ++i) tot += sum[i];
             fprintf(stderr, "[stamps] launch t0=%d n=%d: mean cycles/step/wave = %.0f\n", t, n, tot / (e->nwg * e->nw) / n);
             for (int i = 0; i < 16; ++i)
-                fprintf(stderr, "[stamps]   %-18s %5.1f%%  mean %8.0f  max %8.0f cycles/step\n", (e->ws ? names_ws : names)[i], 100.0 * sum[i] / tot,
+                fprintf(stderr, "[stamps]   %-18s %5.1f%%  mean %8.0f  max %8.0f cycles/step\n", (e->ws == 2 ? names_ws2 : e->ws ? names_ws : names)[i], 100.0 * sum[i] / tot,
                         sum[i] / (e->nwg * e->nw) / n, mx[i] / n);
         }
 #endif

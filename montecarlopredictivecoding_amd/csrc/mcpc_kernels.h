@@ -73,7 +73,9 @@ struct KPhase {
     int flags;             // PHF_*
     float sign;            // BWD: g = e + sign * f'(x) * back
     int out_lds, out_ld;   // HEADF: LDS offset / row stride of the e_o chunk this phase writes
-    int dep_e, dep_g;      // wave-specialised kernel: entry whose completion by all E / all G waves must precede (-1: none)
+    int dep_e, dep_g;      // wave-specialised kernels: entry whose completion by all E / all G waves must precede (-1: none;
+                           // in-place variant: an index above the entry's own refers to the previous step)
+    int rot;               // in-place variant: pair k owns tiles tile0 + ((k + rot) & 3) + 4 i (balances chunks of 6 tiles)
 };
 
 // Phase descriptors are fetched through the constant address space: wave-uniform s_load_* on the scalar cache.
@@ -364,7 +366,7 @@ template <int ACT> __device__ __forceinline__ float actd(float x, float fx) {
 }
 
 // ---- FWD epilogue: prediction errors, energies, activations to LDS, spills, trajectory records -------
-template <int CTT, int NW, int NTW, int ACT>
+template <int CTT, int NW, int NTW, int ACT, bool WRITE_FX = true>
 __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph, float* lds, int nt, int wave, int lane,
                                               int chain0, const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
                                               const f32x4 (&pb)[NTW][CTT], int slot, int rec_idx) {
@@ -396,7 +398,7 @@ __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph
             const f32x4 e = d * ecoef;
             f32x4 fx;
             fx.x = actf<ACT>(x.x); fx.y = actf<ACT>(x.y); fx.z = actf<ACT>(x.z); fx.w = actf<ACT>(x.w);
-            st4(fx_lds + cl * ld + u0, fx);
+            if constexpr (WRITE_FX) st4(fx_lds + cl * ld + u0, fx);   // in-place variant: FX_l is written by the x update
             if (l > 0) st4(e_lds + cl * ld + u0, e);
             if (slot >= 0) {
                 const f32x4 z = splat(0.f);
@@ -487,10 +489,10 @@ __device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& 
 // ---- BWD epilogue: x update of the phase's layer --------------------------------------------------------
 //   g = e + sign * f'(x) * back ;  MODE 1: SGD, no noise   MODE 2: SGD + fused Philox kick   MODE 0: everything
 //   else (Adam, external noise, gradients-only) behind wave-uniform branches.
-template <int CTT, int NW, int NTW, int ACT, int MODE>
+template <int CTT, int NW, int NTW, int ACT, int MODE, bool FXOUT = false>
 __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph, int nt, int wave, int lane, int chain0,
                                              const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
-                                             const f32x4 (&pb)[NTW][CTT], int s, int t) {
+                                             const f32x4 (&pb)[NTW][CTT], int s, int t, float* lds = nullptr) {
     const KLayer& Ly = P.layer[ph.layer];
     const int c = lane & 15, q = lane >> 4;
     const int l = ph.layer, npad = Ly.npad, n = Ly.n, B = P.B;
@@ -521,6 +523,11 @@ __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph,
                 const bool live = chain < B;
                 if (!P.update_x) {
                     if (live && Ly.xgrad != nullptr) st_unpadded(Ly.xgrad, chain, n, u0, g);
+                    if constexpr (FXOUT) {      // x stays: put f(x) back where the back-projection was handed over
+                        f32x4 fx;
+                        fx.x = actf<ACT>(x.x); fx.y = actf<ACT>(x.y); fx.z = actf<ACT>(x.z); fx.w = actf<ACT>(x.w);
+                        st4(lds + Ly.lds_a + (16 * ct + c) * Ly.ld + u0, fx);
+                    }
                     continue;
                 }
                 if (P.xopt == MCPC_XOPT_SGD) {
@@ -554,17 +561,22 @@ __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph,
             if (u0 + 2 >= n) xn.z = 0.f;
             if (u0 + 3 >= n) xn.w = 0.f;
             st4s(xptr + row, xn);
+            if constexpr (FXOUT) {              // in-place variant: the next step's GEMMs read f(x_new) from FX_l
+                f32x4 fx;
+                fx.x = actf<ACT>(xn.x); fx.y = actf<ACT>(xn.y); fx.z = actf<ACT>(xn.z); fx.w = actf<ACT>(xn.w);
+                st4(lds + Ly.lds_a + (16 * ct + c) * Ly.ld + u0, fx);
+            }
         }
     }
 }
 
-template <int CTT, int NW, int NTW, int ACT>
+template <int CTT, int NW, int NTW, int ACT, bool FXOUT = false>
 __device__ __forceinline__ void bwd_epilogue_mode(const KParams& P, const KPhase& ph, int nt, int wave, int lane, int chain0,
                                                   const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
-                                                  const f32x4 (&pb)[NTW][CTT], int s, int t, int mode) {
-    if (mode == 2) bwd_epilogue<CTT, NW, NTW, ACT, 2>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
-    else if (mode == 1) bwd_epilogue<CTT, NW, NTW, ACT, 1>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
-    else bwd_epilogue<CTT, NW, NTW, ACT, 0>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t);
+                                                  const f32x4 (&pb)[NTW][CTT], int s, int t, int mode, float* lds = nullptr) {
+    if (mode == 2) bwd_epilogue<CTT, NW, NTW, ACT, 2, FXOUT>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, lds);
+    else if (mode == 1) bwd_epilogue<CTT, NW, NTW, ACT, 1, FXOUT>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, lds);
+    else bwd_epilogue<CTT, NW, NTW, ACT, 0, FXOUT>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, lds);
 }
 
 template <int CTT, int NW>
@@ -963,3 +975,4 @@ __global__ void mcpc_philox_kernel(uint64_t seed, uint64_t step, int layer, uint
 }  // namespace mcpc
 
 #include "mcpc_steps_ws.h"
+#include "mcpc_steps_ws2.h"

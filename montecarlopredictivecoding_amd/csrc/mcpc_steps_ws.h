@@ -17,7 +17,7 @@ namespace mcpc {
 
 constexpr int kWsPairs = 4;            // (G, E) pairs per workgroup = tile stride
 constexpr int kWsNT = 2;               // unit tiles per pair per table entry (an entry hands out 8 tiles)
-constexpr int kWsSpinLimit = 1 << 24;  // iterations (~0.2 us each): seconds, far beyond any legitimate wait
+constexpr int kWsSpinLimit = 1 << 22;  // iterations (~0.1-0.2 us each): ~0.5 s, far beyond any legitimate wait (< 1 ms)
 
 enum : int { PHF_WS_GEMM = 16, PHF_WS_EPI = 32 };   // which role has work in a table entry
 
@@ -41,23 +41,25 @@ __device__ __forceinline__ int ws_ld(const int* p) { return __hip_atomic_load(p,
 __device__ __forceinline__ void ws_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // wait until all four counters are >= need; a spin that runs out records the fact in *err (host: mcpc_sync_check)
-__device__ __forceinline__ void ws_wait_all(const int* p, int need, int* err) {
-    int spin = 0;
+// (a wave whose wait ran out once stops waiting altogether -- `dead` -- so a broken schedule drains in about one
+// spin limit instead of one per remaining table entry)
+__device__ __forceinline__ void ws_wait_all(const int* p, int need, int* err, int& dead) {
+    int spin = dead ? kWsSpinLimit : 0;
     for (; spin < kWsSpinLimit; ++spin) {
         const int a = ws_ld(p), b = ws_ld(p + 1), c = ws_ld(p + 2), d = ws_ld(p + 3);
         if (min(min(a, b), min(c, d)) >= need) break;
         __builtin_amdgcn_s_sleep(2);
     }
-    if (spin == kWsSpinLimit && (threadIdx.x & 63) == 0) atomicOr(err, 1);
+    if (spin == kWsSpinLimit) { if (!dead && (threadIdx.x & 63) == 0) atomicOr(err, 1); dead = 1; }
     MCPC_WS_FENCE(__ATOMIC_ACQUIRE);
 }
-__device__ __forceinline__ void ws_wait_one(const int* p, int need, int* err) {
-    int spin = 0;
+__device__ __forceinline__ void ws_wait_one(const int* p, int need, int* err, int& dead) {
+    int spin = dead ? kWsSpinLimit : 0;
     for (; spin < kWsSpinLimit; ++spin) {
         if (ws_ld(p) >= need) break;
         __builtin_amdgcn_s_sleep(2);
     }
-    if (spin == kWsSpinLimit && (threadIdx.x & 63) == 0) atomicOr(err, 2);
+    if (spin == kWsSpinLimit) { if (!dead && (threadIdx.x & 63) == 0) atomicOr(err, 2); dead = 1; }
     MCPC_WS_FENCE(__ATOMIC_ACQUIRE);
 }
 __device__ __forceinline__ void ws_publish(int* p, int v) {
@@ -99,6 +101,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws_kernel(const KParams P) 
     const int n_ent = P.n_phases;
     WsSync* sync = reinterpret_cast<WsSync*>(lds + P.lds_ws_sync);
     float* stage = lds + P.lds_ws_stage + k * (kWsNT * CTT * 64 * 4);
+    int dead = 0;                                          // set once a bounded wait of this wave ran out
     if (tid < 16) reinterpret_cast<int*>(sync)[tid] = 0;
     __syncthreads();                                       // the only barrier: counters start at zero
 
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws_kernel(const KParams P) 
                     continue;
                 }
                 STAMP(0);
-                if (ph.dep_e >= 0) ws_wait_all(sync->prog_e, base + ph.dep_e + 1, P.err);
+                if (ph.dep_e >= 0) ws_wait_all(sync->prog_e, base + ph.dep_e + 1, P.err, dead);
                 STAMP(1);
                 if (ph.type == PH_HEADB) {
                     if (nt > 0) gemm_tiles<4, CTT, NW>(accb, (const gf32x4*)ph.A, aoff4, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws_kernel(const KParams P) 
                 STAMP(3);
                 if (has_next) ws_prefetch(ph_next, k, lane, nt_next, aoff_next, pre0_next, pre1_next);
                 // hand the block to E_k: wait until the previous block was copied out, write, signal
-                ws_wait_one(&sync->stage_empty[k], handoffs, P.err);
+                ws_wait_one(&sync->stage_empty[k], handoffs, P.err, dead);
                 STAMP(4);
 #pragma unroll
                 for (int i = 0; i < kWsNT; ++i)
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws_kernel(const KParams P) 
             if (ph.type == PH_ENERGY) {
                 if (do_energy && k == 0) {
                     // every E wave has finished the forward entries of this step (their red[] slots are final)
-                    ws_wait_all(sync->prog_e + 0, base + p, P.err);     // own counter equals base + p already
+                    ws_wait_all(sync->prog_e + 0, base + p, P.err, dead);     // own counter equals base + p already
                     if (lane <= kMaxLatent) {
                         double v = 0.0;
                         const bool used = (lane < L) || (lane == kMaxLatent && P.has_head);
@@ -240,11 +243,11 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws_kernel(const KParams P) 
             // operands of the epilogue travel while the partner still computes
             STAMP(8);
             issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, k, lane, chain0, pa, pb);
-            if (ph.dep_g >= 0) ws_wait_all(sync->prog_g, base + ph.dep_g + 1, P.err);   // e.g. the e_o chunk is free again
+            if (ph.dep_g >= 0) ws_wait_all(sync->prog_g, base + ph.dep_g + 1, P.err, dead);   // e.g. the e_o chunk is free again
             STAMP(9);
             const bool from_g = (ph.nkb > 0) || (ph.type == PH_BWD);              // G hands a block for this entry
             if (from_g) {
-                ws_wait_one(&sync->stage_full[k], handoffs + 1, P.err);
+                ws_wait_one(&sync->stage_full[k], handoffs + 1, P.err, dead);
                 STAMP(10);
 #pragma unroll
                 for (int i = 0; i < kWsNT; ++i)

@@ -1,0 +1,283 @@
+// Wave-specialised Langevin step kernel, in-place variant (the default for large shards; 32 chains per workgroup).
+//
+// Roles as in mcpc_steps_ws.h: waves 0-3 ("G", one per SIMD) stream weight fragments and issue MFMAs, waves 4-7
+// ("E") run the epilogues.  What differs is how the two roles meet:
+//   * no staging slots: G_k stores a finished accumulator block straight into the LDS rows its consumer reads
+//       FWD_l   -> E_l rows   (E_k turns mu into e_l in place; BWD_{l-1} reads E_l as its B operand)
+//       HEADF c -> e_o chunk  (E_k turns o into e_o in place; HEADB c reads the chunk)
+//       BWD_l   -> FX_l rows  (E_k turns the back-projection into f(x_l_new) in place; the NEXT step reads FX_l)
+//     so G never waits for a staging slot to drain, and the 16 KiB of slots pay for un-overlaid FX_l buffers;
+//   * every FX_l has its own rows and is refreshed by the x update, so the forward GEMMs of a step depend on the
+//     previous step's updates, not on each other: the table (build_phases_ws2) orders a step as
+//       read-out chunks (need f(x_{L-1}), updated first) interleaved with FWD_{L-1} ... FWD_1, then the updates
+//       BWD_{L-1} ... BWD_0,
+//     which leaves one or more GEMMs of slack between every producer epilogue and its consumer GEMM.
+// Progress counters (LDS, monotonic, polled with bounded spins):
+//   prog_g[k] = table entries completed by G_k, prog_e[k] = by E_k   (absolute: step * n_entries + index + 1)
+//   E_k entry p waits prog_g[k] > p (its own pair's block);  G entry p waits "all E past dep_e" (B operand ready)
+//   and, for read-out chunks only, "all G past dep_g" (chunk buffer no longer read).  Every other write-after-read
+//   hazard is implied by a read dependency -- see the table builder.
+#pragma once
+
+namespace mcpc {
+
+enum : int { PHF_WS2_HANDOFF = 64 };   // BWD entry without GEMM whose block (accb) still comes from G
+
+struct Ws2Sync {
+    int prog_e[4];
+    int prog_g[4];
+};
+
+__device__ __forceinline__ int ws2_need(int base, int n_ent, int p, int dep) {
+    return (dep > p ? base - n_ent : base) + dep + 1;      // an index above the entry's own: previous step
+}
+
+// G side: request the first two k-blocks of the fragments of an upcoming entry (weights need no dependency).
+// Branch-free: all four tile slots always issue both loads; unused slots repeat slot 0 (L1 hits) and entries without
+// a GEMM read `dummy` (any 2 KiB of valid global memory).  With the loads under `if (i < nt)` hipcc joined every
+// branch behind `s_waitcnt vmcnt(0)`: four serial L2 round trips (~1 k cycles) per table entry.
+__device__ __forceinline__ void ws2_prefetch(const KPhase& ph, int k, int lane, const void* dummy, int& nt_out, int (&aoff)[4],
+                                             f32x4 (&pre0)[4], f32x4 (&pre1)[4]) {
+    const int kk = (k + ph.rot) & 3;
+    const int ntmax = (ph.type == PH_HEADB) ? 4 : kWsNT;
+    int nt = (ph.ntiles - kk + kWsPairs - 1) / kWsPairs;
+    nt = nt < 0 ? 0 : (nt > ntmax ? ntmax : nt);
+    if (!(ph.flags & PHF_WS_GEMM) || ph.nkb <= 0) nt = 0;
+    nt_out = nt;
+    const bool valid = nt > 0;
+    const gf32x4* const A = valid ? (const gf32x4*)ph.A : (const gf32x4*)dummy;
+    const int second = (valid && ph.nkb > 1) ? 64 : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ii = i < nt ? i : 0;
+        const int off = valid ? (ph.tile0 + kk + kWsPairs * ii) * ph.a_tile_stride + ph.a_off0 : 0;
+        aoff[i] = off;
+        pre0[i] = A[off + lane];
+        pre1[i] = A[off + second + lane];
+    }
+}
+
+template <int ACT>
+__device__ __forceinline__ void ws2_fill_fx(const KLayer& Ly, float* lds, int chain0, int tid, int ct_rows) {
+    const int qpr = Ly.npad / 4;                            // quads per row
+    for (int idx = tid; idx < ct_rows * qpr; idx += 512) {
+        const int r = idx / qpr, u0 = 4 * (idx - r * qpr);
+        const f32x4 x = ld4s(Ly.x + (size_t)(chain0 + r) * Ly.npad + u0);
+        f32x4 fx;
+        fx.x = actf<ACT>(x.x); fx.y = actf<ACT>(x.y); fx.z = actf<ACT>(x.z); fx.w = actf<ACT>(x.w);
+        st4(lds + Ly.lds_a + r * Ly.ld + u0, fx);
+    }
+}
+
+template <int CTT>
+__global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = kWsPairs, NTW = kWsNT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_g = wave8 < 4;
+    const int k = wave8 & 3;                               // pair id
+    const int c = lane & 15, q = lane >> 4;
+    const int chain0 = blockIdx.x * (16 * CTT);
+    const int L = P.L;
+    const int n_ent = P.n_phases;
+    Ws2Sync* sync = reinterpret_cast<Ws2Sync*>(lds + P.lds_ws_sync);
+    int dead = 0;                                          // set once a bounded wait of this wave ran out
+    if (tid < 8) reinterpret_cast<int*>(sync)[tid] = 0;
+    // f(x_l) of the state the launch starts from; afterwards the x updates keep FX_l current
+    for (int l = 0; l < L; ++l) {
+        const KLayer& Ly = P.layer[l];
+        if (Ly.act == MCPC_ACT_RELU) ws2_fill_fx<MCPC_ACT_RELU>(Ly, lds, chain0, tid, 16 * CTT);
+        else if (Ly.act == MCPC_ACT_TANH) ws2_fill_fx<MCPC_ACT_TANH>(Ly, lds, chain0, tid, 16 * CTT);
+        else ws2_fill_fx<MCPC_ACT_IDENTITY>(Ly, lds, chain0, tid, 16 * CTT);
+    }
+    __syncthreads();                                       // the only barrier
+
+    if (is_g) {
+        // =========================== G: fragments + MFMAs ==============================================
+        if (P.ws_prio == 2) __builtin_amdgcn_s_setprio(2);
+        // Loop-carried: the descriptor of the upcoming entry and the first two k-blocks of its fragments.  The GEMM
+        // moves pre0/pre1 into its own register sets first thing, so the ONE prefetch site below refills the same
+        // variables -- with separate "next" copies hipcc put `s_waitcnt vmcnt(0)` + 16 v_mov at the loop latch, i.e.
+        // every entry waited out the L2 round trip of the prefetch it had just issued.
+        KPhase ph_next = load_phase(P.phases, 0);
+        int nt_next, aoff[4];
+        f32x4 pre0[4], pre1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pre0[i] = splat(0.f); pre1[i] = splat(0.f); aoff[i] = 0; }
+        ws2_prefetch(ph_next, k, lane, P.mu1, nt_next, aoff, pre0, pre1);
+        STAMP_DECL
+        for (int s = 0; s < P.n_steps; ++s) {
+            const int base = s * n_ent;
+            f32x4 accb[4][CTT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ct = 0; ct < CTT; ++ct) accb[i][ct] = splat(0.f);
+#pragma unroll 1
+            for (int p = 0; p < n_ent; ++p) {
+                const KPhase ph = ph_next;
+                const int nt = nt_next;
+                const bool has_next = (p + 1 < n_ent) || (s + 1 < P.n_steps);
+                if (has_next) ph_next = load_phase(P.phases, p + 1 < n_ent ? p + 1 : 0);
+                const bool handoff = (ph.flags & PHF_WS2_HANDOFF) != 0;             // accb goes to the partner
+                const bool is_headb = ph.type == PH_HEADB;
+                const bool works = (ph.flags & PHF_WS_GEMM) || handoff;
+                const bool stores = works && !is_headb;
+                f32x4 acc[kWsNT][CTT];
+#pragma unroll
+                for (int i = 0; i < kWsNT; ++i)
+#pragma unroll
+                    for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = splat(0.f);
+                STAMP(0);
+                if (works) {
+                    if (ph.dep_e >= 0) ws_wait_all(sync->prog_e, ws2_need(base, n_ent, p, ph.dep_e), P.err, dead);
+                    if (ph.dep_g >= 0) ws_wait_all(sync->prog_g, ws2_need(base, n_ent, p, ph.dep_g), P.err, dead);
+                    STAMP(1);
+                    if (is_headb) {
+                        if (nt > 0) gemm_tiles<4, CTT, NW>(accb, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
+                        STAMP(2);
+                    } else {
+                        if (handoff) {
+                            const int sub = ph.tile0 / (NW * kWsNT);                 // which pair of accb tiles
+#pragma unroll
+                            for (int i = 0; i < kWsNT; ++i)
+#pragma unroll
+                                for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = sub == 0 ? accb[i][ct] : accb[i + 2][ct];
+                        }
+                        if (nt > 0 && ph.nkb > 0) {
+                            int aoff2[kWsNT];
+                            f32x4 p0[kWsNT], p1[kWsNT];
+#pragma unroll
+                            for (int i = 0; i < kWsNT; ++i) { aoff2[i] = aoff[i]; p0[i] = pre0[i]; p1[i] = pre1[i]; }
+                            gemm_tiles<kWsNT, CTT, NW>(acc, (const gf32x4*)ph.A, aoff2, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, p0, p1);
+                        }
+                        STAMP(3);
+                    }
+                }
+                // the one prefetch site: fragments of the next entry travel while this block is handed over
+                ws2_prefetch(ph_next, k, lane, P.mu1, nt_next, aoff, pre0, pre1);   // (past the last entry: the old descriptor again)
+                STAMP(4);
+                if (stores) {
+                    // the block goes where its consumer reads it; E_k finishes it in place
+                    const int kk = (k + ph.rot) & 3;
+                    int ntw = (ph.ntiles - kk + NW - 1) / NW;
+                    ntw = ntw < 0 ? 0 : (ntw > kWsNT ? kWsNT : ntw);
+                    float* const out = lds + ph.out_lds;
+                    const int col0 = (ph.type == PH_HEADF) ? 0 : 16 * ph.tile0;
+#pragma unroll
+                    for (int i = 0; i < kWsNT; ++i) {
+                        if (i >= ntw) continue;
+                        const int col = col0 + 16 * (kk + NW * i) + 4 * q;
+#pragma unroll
+                        for (int ct = 0; ct < CTT; ++ct) st4(out + (16 * ct + c) * ph.out_ld + col, acc[i][ct]);
+                    }
+                }
+                if (lane == 0) ws_publish(&sync->prog_g[k], base + p + 1);
+                STAMP(5);
+            }
+        }
+#ifdef MCPC_STAMPS
+        if (lane == 0)
+            for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * 8 + wave8) * 16 + i] = st_sum[i];
+#endif
+        return;
+    }
+
+    // =============================== E: epilogues ===========================================================
+    if (P.ws_prio == 1) __builtin_amdgcn_s_setprio(2);
+    const int upd_mode = (P.update_x && P.xopt == MCPC_XOPT_SGD)
+                             ? (P.noise_mode == MCPC_NOISE_PHILOX ? 2 : (P.noise_mode == MCPC_NOISE_NONE ? 1 : 0)) : 0;
+    STAMP_DECL
+    for (int s = 0; s < P.n_steps; ++s) {
+        const int t = P.t0 + s;
+        const int base = s * n_ent;
+        const bool do_energy = (P.energy_mode == MCPC_ENERGY_ALL) || (P.energy_mode == MCPC_ENERGY_LAST && t == P.T - 1);
+        const int slot = (t >= P.acc_begin && t < P.acc_end) ? (t - P.spill_t0) : -1;
+        int rec_idx = -1;
+        if (P.rec_count > 0 && t >= P.rec_begin) {
+            const int kk = (t - P.rec_begin) / P.rec_stride;
+            if (kk < P.rec_count && P.rec_begin + kk * P.rec_stride == t) rec_idx = kk;
+        }
+        float* red = lds + P.lds_red + (s & 1) * (kMaxLatent + 1) * kMaxWaves;
+        if (do_energy && lane <= kMaxLatent) red[lane * kMaxWaves + k] = 0.f;
+#pragma unroll 1
+        for (int p = 0; p < n_ent; ++p) {
+            const KPhase ph = load_phase(P.phases, p);
+            if (ph.type == PH_ENERGY) {
+                if (do_energy && k == 0) {
+                    // every E wave has finished the entries of this step that add to red[]
+                    ws_wait_all(sync->prog_e + 0, base + p, P.err, dead);     // own counter equals base + p already
+                    if (lane <= kMaxLatent) {
+                        double v = 0.0;
+                        const bool used = (lane < L) || (lane == kMaxLatent && P.has_head);
+                        if (used) {
+#pragma unroll
+                            for (int w = 0; w < kWsPairs; ++w) v += (double)red[lane * kMaxWaves + w];
+                        }
+                        const int erow = (P.energy_mode == MCPC_ENERGY_ALL) ? t : 0;
+                        P.epart[((size_t)erow * gridDim.x + blockIdx.x) * (kMaxLatent + 1) + lane] = v;
+                    }
+                }
+                if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
+                continue;
+            }
+            if (!(ph.flags & PHF_WS_EPI)) {
+                if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
+                continue;
+            }
+            const int kk = (k + ph.rot) & 3;
+            int nt = (ph.ntiles - kk + NW - 1) / NW;
+            nt = nt < 0 ? 0 : (nt > kWsNT ? kWsNT : nt);
+            f32x4 acc[kWsNT][CTT], pa[kWsNT][CTT], pb[kWsNT][CTT];
+#pragma unroll
+            for (int i = 0; i < kWsNT; ++i)
+#pragma unroll
+                for (int ct = 0; ct < CTT; ++ct) { acc[i][ct] = splat(0.f); pa[i][ct] = splat(0.f); pb[i][ct] = splat(0.f); }
+            const KLayer& Ly = P.layer[ph.layer];
+            STAMP(8);
+            // operands of the epilogue travel while the partner still computes
+            issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, kk, lane, chain0, pa, pb);
+            STAMP(9);
+            const bool from_g = ((ph.flags & PHF_WS_GEMM) && ph.nkb > 0) || (ph.flags & PHF_WS2_HANDOFF);
+            if (from_g) {
+                ws_wait_one(&sync->prog_g[k], base + p + 1, P.err, dead);
+                STAMP(10);
+                const float* const src = lds + ph.out_lds;
+                const int col0 = (ph.type == PH_HEADF) ? 0 : 16 * ph.tile0;
+#pragma unroll
+                for (int i = 0; i < kWsNT; ++i) {
+                    const int col = col0 + 16 * (kk + NW * (i < nt ? i : 0)) + 4 * q;     // unused slots re-read slot 0
+#pragma unroll
+                    for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = ld4(src + (16 * ct + c) * ph.out_ld + col);
+                }
+            }
+#ifdef MCPC_EXP_NOEPI   // timing experiment only (wrong results): E waves skip the epilogue arithmetic and stores
+            if (P.n_steps < 0)
+#endif
+            if (ph.type == PH_FWD) {
+                float esum;
+                if (Ly.act == MCPC_ACT_RELU) esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_RELU, false>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx);
+                else if (Ly.act == MCPC_ACT_TANH) esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_TANH, false>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx);
+                else esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_IDENTITY, false>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx);
+                if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[ph.layer * kMaxWaves + k] += esum; }
+            } else if (ph.type == PH_HEADF) {
+                float lsum = headf_epilogue<CTT, NW, NTW>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx, do_energy);
+                if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[kMaxLatent * kMaxWaves + k] += lsum; }
+            } else if (ph.type == PH_BWD) {
+                if (Ly.act == MCPC_ACT_RELU) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_RELU, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s, t, upd_mode, lds);
+                else if (Ly.act == MCPC_ACT_TANH) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_TANH, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s, t, upd_mode, lds);
+                else bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_IDENTITY, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s, t, upd_mode, lds);
+            }
+            if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
+            STAMP(11);
+        }
+    }
+#ifdef MCPC_STAMPS
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * 8 + wave8) * 16 + i] = st_sum[i];
+#endif
+}
+
+}  // namespace mcpc
