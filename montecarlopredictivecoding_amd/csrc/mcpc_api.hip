@@ -458,10 +458,11 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     e->ct = 16; e->nw = 4;
     if (const char* env = getenv("MCPC_CT")) { const int v = atoi(env); if (v == 16 || v == 32) e->ct = v; }
     if (const char* env = getenv("MCPC_NW")) { const int v = atoi(env); if (v == 4 || (v == 8 && e->ct == 32)) e->nw = v; }
-    // Default schedule: the wave-specialised kernel (32 chains, 4 GEMM + 4 epilogue waves) when the shard is large
-    // enough to give every CU a workgroup, otherwise 16-chain workgroups (twice as many of them).  MCPC_WS=0/1,
-    // MCPC_CT, MCPC_NW override for experiments; a WS plan that does not fit the LDS falls back below.
-    int want_ws = (d->batch >= 4096 && !getenv("MCPC_CT") && !getenv("MCPC_NW")) ? 1 : 0;
+    // Default schedule: the in-place wave-specialised kernel (32 chains, 4 GEMM + 4 epilogue waves) when the shard is
+    // large enough to give every CU a workgroup, otherwise 16-chain workgroups (twice as many of them).  MCPC_WS=0/1/2
+    // (1 = the older variant with staging slots), MCPC_CT, MCPC_NW override for experiments; a wave-specialised plan
+    // that does not fit the LDS falls back below.
+    int want_ws = (d->batch >= 4096 && !getenv("MCPC_CT") && !getenv("MCPC_NW")) ? 2 : 0;
     if (const char* env = getenv("MCPC_WS")) { const int v = atoi(env); want_ws = (v == 1 || v == 2) ? v : 0; }
     if (want_ws) { e->ws = want_ws; e->ct = 32; e->nw = 8; }
     e->nwg = e->Bpad / e->ct;
@@ -853,7 +854,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             static const char* names_ws[16] = {"G other", "G wait dep(E)", "G HEADB gemm", "G gemm", "G wait stage free", "G handoff",
                                                "-", "-", "E other", "E loads+dep", "E wait stage", "E epilogue", "-", "-", "-", "-"};
             static const char* names_ws2[16] = {"G top", "G wait deps", "G HEADB gemm", "G gemm", "G prefetch next", "G store+publish",
-                                                "G entry w/o GEMM", "G acc init", "E other", "E loads", "E wait block", "E epilogue", "-", "-", "-", "-"};
+                                                "G entry w/o GEMM", "G acc init", "E other", "E loads", "E wait block", "E epilogue FWD", "E epilogue HEADF", "E epilogue BWD", "-", "-"};
             static const char* names[16] = {"FWD prologue", "FWD gemm", "FWD epilogue", "HEADF prologue", "HEADF gemm", "HEADF epilogue",
                                             "HEADB prologue", "HEADB gemm", "HEADB (acc->b)", "BWD prologue", "BWD gemm", "BWD epilogue",
                                             "energy", "barrier", "-", "-"};

@@ -21,6 +21,12 @@
 
 namespace mcpc {
 
+#ifdef MCPC_EXP_NOGEMM    // timing experiment only (wrong results): G waves skip their GEMMs
+#define MCPC_EXP_GEMM_GATE && P.n_steps < 0
+#else
+#define MCPC_EXP_GEMM_GATE
+#endif
+
 enum : int { PHF_WS2_HANDOFF = 64 };   // BWD entry without GEMM whose block (accb) still comes from G
 
 struct Ws2Sync {
@@ -67,6 +73,79 @@ __device__ __forceinline__ void ws2_fill_fx(const KLayer& Ly, float* lds, int ch
         fx.x = actf<ACT>(x.x); fx.y = actf<ACT>(x.y); fx.z = actf<ACT>(x.z); fx.w = actf<ACT>(x.w);
         st4(lds + Ly.lds_a + r * Ly.ld + u0, fx);
     }
+}
+
+// Uniform values the epilogue loops use over and over are parked in VGPRs: the E waves have ~100 registers to
+// spare but no SGPRs (hipcc re-loaded them from the kernel arguments inside the loops: s_load + s_waitcnt lgkmcnt(0),
+// a scalar-cache round trip per use).
+__device__ __forceinline__ int vreg(int s) { int v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
+__device__ __forceinline__ float vreg(float s) { float v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
+__device__ __forceinline__ float* vreg(float* s) {
+    const uint64_t u = (uint64_t)s;
+    const uint32_t lo = (uint32_t)vreg((int)(uint32_t)u), hi = (uint32_t)vreg((int)(uint32_t)(u >> 32));
+    return (float*)(((uint64_t)hi << 32) | lo);
+}
+
+// HEADF epilogue of the E waves: arithmetic of headf_epilogue (mcpc_kernels.h), uniforms in VGPRs
+template <int CTT, int NW, int NTW>
+__device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPhase& ph, float* lds, int nt, int wave, int lane,
+                                                    int chain0, const f32x4 (&acc)[NTW][CTT], const f32x4 (&pa)[NTW][CTT],
+                                                    const f32x4 (&pb)[NTW][CTT], int slot, int rec_idx, bool do_energy) {
+    const KHead& H = P.head;
+    const int c = lane & 15, q = lane >> 4;
+    const int kind = H.loss_kind;
+    const int npad = vreg(H.npad), n = vreg(H.n), ld = vreg(ph.out_ld), B = vreg(P.B), mask_start = vreg(H.mask_start);
+    const float inv_var = vreg(H.inv_var);
+    const int eo_off = vreg(ph.out_lds), tile0x16 = vreg(16 * ph.tile0);
+    float* const spill = slot >= 0 ? vreg(H.spill_e + (size_t)slot * P.Bpad * H.npad) : nullptr;
+    float* const rec = (rec_idx >= 0 && H.rec_out != nullptr) ? H.rec_out + (size_t)rec_idx * P.B * H.n : nullptr;
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        if (i >= nt) continue;
+        const int u0 = tile0x16 + 16 * (wave + NW * i) + 4 * q;
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) {
+            const int cl = 16 * ct + c, chain = chain0 + cl;
+            const bool live = chain < B;
+            const f32x4 o = acc[i][ct] + pb[i][ct];
+            f32x4 e = splat(0.f);
+            if (kind != MCPC_LOSS_NONE) {
+                const f32x4 y = pa[i][ct];
+                const float ov[4] = {o.x, o.y, o.z, o.w}, yv[4] = {y.x, y.y, y.z, y.w};
+                float ev[4];
+                if (kind == MCPC_LOSS_GAUSSIAN) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool on = live && (u0 + r) >= mask_start && (u0 + r) < n;
+                        const float dlt = ov[r] - yv[r];
+                        ev[r] = on ? inv_var * dlt : 0.f;
+                        lsum += on ? 0.5f * inv_var * dlt * dlt : 0.f;
+                    }
+                } else if (do_energy) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool on = live && (u0 + r) >= mask_start && (u0 + r) < n;
+                        float sg, bc;
+                        sigmoid_bce_f(ov[r], yv[r], sg, bc);
+                        ev[r] = on ? sg - yv[r] : 0.f;
+                        lsum += on ? bc : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool on = live && (u0 + r) >= mask_start && (u0 + r) < n;
+                        ev[r] = on ? sigmoid_f(ov[r]) - yv[r] : 0.f;
+                    }
+                }
+                e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
+            }
+            st4(lds + eo_off + cl * ld + (u0 - tile0x16), e);
+            if (slot >= 0) st4s(spill + (size_t)chain * npad + u0, e);
+            if (rec != nullptr && live) st_unpadded(rec, chain, H.n, u0, o);
+        }
+    }
+    return lsum;
 }
 
 template <int CTT>
@@ -136,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
                     if (ph.dep_g >= 0) ws_wait_all(sync->prog_g, ws2_need(base, n_ent, p, ph.dep_g), P.err, dead);
                     STAMP(1);
                     if (is_headb) {
-                        if (nt > 0) gemm_tiles<4, CTT, NW>(accb, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
+                        if (nt > 0 MCPC_EXP_GEMM_GATE) gemm_tiles<4, CTT, NW>(accb, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
                         STAMP(2);
                     } else {
                         if (handoff) {
@@ -146,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
 #pragma unroll
                                 for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = sub == 0 ? accb[i][ct] : accb[i + 2][ct];
                         }
-                        if (nt > 0 && ph.nkb > 0) {
+                        if (nt > 0 && ph.nkb > 0 MCPC_EXP_GEMM_GATE) {
                             int aoff2[kWsNT];
                             f32x4 p0[kWsNT], p1[kWsNT];
 #pragma unroll
@@ -263,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
                 else esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_IDENTITY, false>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx);
                 if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[ph.layer * kMaxWaves + k] += esum; }
             } else if (ph.type == PH_HEADF) {
-                float lsum = headf_epilogue<CTT, NW, NTW>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx, do_energy);
+                float lsum = ws2_headf_epilogue<CTT, NW, NTW>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx, do_energy);
                 if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[kMaxLatent * kMaxWaves + k] += lsum; }
             } else if (ph.type == PH_BWD) {
                 if (Ly.act == MCPC_ACT_RELU) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_RELU, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s, t, upd_mode, lds);
@@ -271,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
                 else bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_IDENTITY, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s, t, upd_mode, lds);
             }
             if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
-            STAMP(11);
+            if (ph.type == PH_FWD) STAMP(11); else if (ph.type == PH_HEADF) STAMP(12); else STAMP(13);
         }
     }
 #ifdef MCPC_STAMPS
