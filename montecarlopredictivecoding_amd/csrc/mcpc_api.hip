@@ -59,7 +59,7 @@ struct mcpc_engine {
     int ct = kCT;                   // chains per workgroup: 16 (two workgroups per CU) or 32
     int nw = kWaves;                // waves per workgroup: 4, or 8 with 32 chains (two waves per SIMD, one workgroup per CU)
     int ws = 0;                     // 1: wave-specialised kernel with staging slots; 2: in-place variant (4 GEMM + 4 epilogue waves, 32 chains)
-    int ws2_chunk = 0;              // in-place variant: read-out tiles per chunk
+    int ws2_chunk = 0, ws2_ring = 0; // in-place variant: read-out tiles per chunk, chunks in the LDS ring
     int lds_ws_sync = 0, lds_ws_stage = 0;
     int npad[kMaxLatent]{};
     int out_pad = 0;
@@ -154,49 +154,61 @@ int plan_lds(mcpc_engine* e) {
     return 0;
 }
 
-// LDS plan of the in-place wave-specialised kernel: every FX_l and E_l has its own rows (no overlays, no staging
-// slots); the read-out error lives in a ring of two chunks of `ws2_chunk` tiles, the largest that still fits.
+// LDS plan of the in-place wave-specialised kernel: every FX_l and E_l has its own rows (no staging slots).  The
+// read-out error lives in a ring of `ws2_ring` chunks of `ws2_chunk` tiles that starts ON TOP of E_{L-1}: E_{L-1} is
+// only needed from the end of the read-out phase (FWD_{L-1} is scheduled behind it) to the BWD_{L-2} GEMM, and the
+// ring only during the read-out phase.  That pays for chunks of 8 tiles (two per GEMM wave: no imbalance) and a ring
+// of three (two GEMMs of slack between a chunk's epilogue and its back-projection) at cfg-M.
 int plan_lds_ws2(mcpc_engine* e) {
-    const int CT = e->ct;
+    const int CT = e->ct, L = e->L;
     int off = 0;
-    for (int l = 0; l < e->L; ++l) { e->lds_a[l] = off; off += CT * (e->npad[l] + kLdPad); }
+    for (int l = 0; l < L; ++l) { e->lds_a[l] = off; off += CT * (e->npad[l] + kLdPad); }
     e->lds_e[0] = 0;
-    for (int l = 1; l < e->L; ++l) { e->lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
+    for (int l = 1; l < L - 1; ++l) { e->lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
     e->lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
     e->lds_ws_sync = off; off += 16;
     e->lds_ws_stage = 0;
+    const int e_last = L >= 2 ? CT * (e->npad[L - 1] + kLdPad) : 0;      // E_{L-1}: the last region, the ring overlays it
+    if (L >= 2) e->lds_e[L - 1] = off;
     e->lds_eo = off;
-    e->ws2_chunk = 0;
+    e->ws2_chunk = 0; e->ws2_ring = 0;
+    int ring_floats = 0;
     if (e->has_head) {
-        for (int hc : {8, 6, 4, 2}) {
-            if ((off + 2 * CT * (hc * 16 + kLdPad)) * (int)sizeof(float) <= 160 * 1024) { e->ws2_chunk = hc; break; }
+        const int ht = e->out_pad / 16;
+        static const int cand[][2] = {{8, 3}, {8, 2}, {6, 3}, {6, 2}, {4, 3}, {4, 2}, {2, 2}};
+        for (auto& hr : cand) {
+            const int hc = std::min(hr[0], std::max(ht, 1)), nb = hr[1];
+            const int need = nb * CT * (hc * 16 + kLdPad);
+            if ((off + std::max(need, e_last)) * (int)sizeof(float) <= 160 * 1024) { e->ws2_chunk = hc; e->ws2_ring = nb; ring_floats = need; break; }
         }
         if (!e->ws2_chunk) return fail(MCPC_ENOMEM, "in-place schedule does not fit the LDS");
-        off += 2 * CT * (e->ws2_chunk * 16 + kLdPad);
     }
+    off += std::max(ring_floats, e_last);
     e->lds_bytes = off * (int)sizeof(float);
     if (e->lds_bytes > 160 * 1024) return fail(MCPC_ENOMEM, "in-place schedule does not fit the LDS (%d bytes)", e->lds_bytes);
     return 0;
 }
 
-// Table of the in-place wave-specialised kernel (mcpc_steps_ws2.h).  One step =
-//   read-out chunks  HF(0) HF(1) HB(0) HF(2) HB(1) ...   with the forward entries FWD_{L-1} ... FWD_1, FWD_0 slipped
-//   in one at a time behind the HB entries, then the updates BWD_{L-1} ... BWD_0 and the energy reduction.
+// Table of the in-place wave-specialised kernel (mcpc_steps_ws2.h), R = ring size.  One step =
+//   read-out:  HF(0) .. HF(R-1) HB(0) HF(R) HB(1) ...  with the forward entries FWD_{L-2} ... FWD_1, FWD_0 slipped in
+//              one at a time behind the HB entries;
+//   FWD_{L-1}  (its output E_{L-1} shares LDS with the ring, so it follows the last HB);
+//   updates:   BWD_{L-1} (accb hand-off), BWD_0 ... BWD_{L-2} (the one that needs E_{L-1} last);  energy reduction.
 // Read dependencies (dep_e, "all E waves past entry"):  HF(c) <- last BWD_{L-1} of the PREVIOUS step (FX_{L-1});
 //   HB(c) <- HF(c);  FWD_l <- last BWD_{l-1} of the previous step (FX_{l-1});  BWD_l GEMM <- last FWD_{l+1} (E_{l+1}).
-// Write-after-read: only the chunk ring needs its own dependency (dep_g, "all G waves past entry"): HF(c) <- HB(c-2).
-// The others are implied: a G wave that stores into E_l / FX_l / FX_{L-1} has just waited for epilogues that can
-// only have run after every G wave finished the GEMMs that read the old contents (FWD_l after the BWD_{l-1}
-// epilogues, BWD_l after the FWD_{l+1} epilogues, the BWD_{L-1} hand-off after HB(last) <- HF(last) epilogues).
+// Write-after-read (dep_g, "all G waves past entry") is only needed around the ring:
+//   HF(c) <- HB(c-R);  HF(c), c < R, in a ring slot that overlaps E_{L-1} <- last BWD_{L-2} of the previous step;
+//   FWD_{L-1} <- HB(last).
+// The others are implied: a G wave that stores into E_l / FX_l / FX_{L-1} has just waited for epilogues that can only
+// have run after every G wave finished the GEMMs that read the old contents (FWD_l after the BWD_{l-1} epilogues,
+// BWD_l after the FWD_{l+1} epilogues, the BWD_{L-1} hand-off after HB(last) <- HF(last) epilogues).
 int build_phases_ws2(mcpc_engine* e) {
     const int L = e->L;
     const int span = kWsPairs * kWsNT;       // 8
     auto tiles = [&](int l) { return e->npad[l] / 16; };
     auto blank = [&]() { KPhase k{}; k.dep_e = -1; k.dep_g = -1; return k; };
-    enum { REF_NONE = -1, REF_LAST_BWD = -1000, REF_LAST_FWD = -2000 };   // symbolic deps: REF_x - layer
-    // forward entries, bottom layer first (its input FX_{L-2} is refreshed first)
-    std::vector<KPhase> fwd;
-    for (int l = L - 1; l >= 0; --l)
+    enum { REF_LAST_BWD = -1000, REF_LAST_FWD = -2000, REF_LAST_HB = -3000 };   // symbolic deps: REF_x - layer
+    auto fwd_entries = [&](int l, std::vector<KPhase>& out) {
         for (int base = 0; base < tiles(l); base += span) {
             KPhase k = blank();
             k.type = PH_FWD; k.layer = l; k.tile0 = base; k.ntiles = std::min(span, tiles(l) - base);
@@ -207,25 +219,32 @@ int build_phases_ws2(mcpc_engine* e) {
                 k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
                 k.out_lds = e->lds_e[l]; k.out_ld = e->npad[l] + kLdPad;
                 k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_BWD - (l - 1);
+                if (l == L - 1 && e->has_head) k.dep_g = REF_LAST_HB;
             }
-            fwd.push_back(k);
+            out.push_back(k);
         }
+    };
+    // forward entries that can run beside the read-out (everything but FWD_{L-1} when there is a read-out)
+    std::vector<KPhase> fill, after;
+    for (int l = L - 1; l >= 0; --l) fwd_entries(l, (l == L - 1 && e->has_head && L >= 2) ? after : fill);
     std::vector<KPhase> ph;
     size_t nf = 0;
     if (e->has_head) {
-        const int hc = e->ws2_chunk;
+        const int hc = e->ws2_chunk, R = e->ws2_ring;
         const int ht = e->out_pad / 16;
         const int nch = (ht + hc - 1) / hc;
         const int chunk_floats = e->ct * (hc * 16 + kLdPad);
+        const int e_last = L >= 2 ? e->ct * (e->npad[L - 1] + kLdPad) : 0;
         std::vector<int> idx_f(nch, -1), idx_b(nch, -1);
         auto add_f = [&](int c) {
             KPhase f = blank();
             f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c * hc; f.ntiles = std::min(hc, ht - c * hc); f.rot = c & 3;
             f.A = (const f32x4*)e->lin[L].Wf; f.a_tile_stride = tiles(L - 1) * 64; f.nkb = tiles(L - 1);
             f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad;
-            f.out_lds = e->lds_eo + (c & 1) * chunk_floats; f.out_ld = hc * 16 + kLdPad;
+            f.out_lds = e->lds_eo + (c % R) * chunk_floats; f.out_ld = hc * 16 + kLdPad;
             f.flags = PHF_WS_GEMM | PHF_WS_EPI; f.dep_e = REF_LAST_BWD - (L - 1);
-            f.dep_g = c >= 2 ? idx_b[c - 2] : -1;
+            if (c >= R) f.dep_g = idx_b[c - R];
+            else if (L >= 2 && (c % R) * chunk_floats < e_last) f.dep_g = REF_LAST_BWD - (L - 2);   // slot overlaps E_{L-1}
             idx_f[c] = (int)ph.size(); ph.push_back(f);
         };
         auto add_b = [&](int c) {
@@ -233,17 +252,21 @@ int build_phases_ws2(mcpc_engine* e) {
             b.type = PH_HEADB; b.layer = L - 1; b.tile0 = 0; b.ntiles = tiles(L - 1);
             b.A = (const f32x4*)e->lin[L].Wb; b.a_tile_stride = ht * 64; b.a_off0 = c * hc * 64;
             b.nkb = std::min(hc, ht - c * hc);
-            b.b_lds = e->lds_eo + (c & 1) * chunk_floats; b.ldb = hc * 16 + kLdPad;
+            b.b_lds = e->lds_eo + (c % R) * chunk_floats; b.ldb = hc * 16 + kLdPad;
             b.flags = PHF_WS_GEMM; b.dep_e = idx_f[c];
             idx_b[c] = (int)ph.size(); ph.push_back(b);
-            if (nf < fwd.size()) ph.push_back(fwd[nf++]);      // one forward entry behind every back-projection
+            if (nf < fill.size()) ph.push_back(fill[nf++]);      // one forward entry behind every back-projection
         };
-        add_f(0);
-        for (int c = 1; c < nch; ++c) { add_f(c); add_b(c - 1); }
-        add_b(nch - 1);
+        for (int c = 0; c < nch; ++c) {
+            add_f(c);
+            if (c >= R - 1) add_b(c - (R - 1));
+        }
+        for (int c = std::max(nch - (R - 1), 0); c < nch; ++c) add_b(c);
     }
-    while (nf < fwd.size()) ph.push_back(fwd[nf++]);
-    // x updates, bottom layer first
+    while (nf < fill.size()) ph.push_back(fill[nf++]);
+    for (auto& k : after) ph.push_back(k);
+    // x updates: the bottom layer first (its back-projection is complete), then top-down ... no: bottom-up from
+    // BWD_0, so that BWD_{L-2}, which reads the E_{L-1} produced last, comes last
     for (int base = 0; base < tiles(L - 1); base += span) {
         KPhase k = blank();
         k.type = PH_BWD; k.layer = L - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(L - 1) - base);
@@ -252,7 +275,7 @@ int build_phases_ws2(mcpc_engine* e) {
         k.out_lds = e->lds_a[L - 1]; k.out_ld = e->npad[L - 1] + kLdPad;
         ph.push_back(k);
     }
-    for (int l = L - 1; l >= 1; --l)
+    for (int l = 1; l <= L - 1; ++l)
         for (int base = 0; base < tiles(l - 1); base += span) {
             KPhase k = blank();
             k.type = PH_BWD; k.layer = l - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(l - 1) - base);
@@ -265,14 +288,19 @@ int build_phases_ws2(mcpc_engine* e) {
     { KPhase k = blank(); k.type = PH_ENERGY; k.flags = PHF_WS_EPI; ph.push_back(k); }
     // resolve the symbolic dependencies
     std::vector<int> last_fwd(L, -1), last_bwd(L, -1);
+    int last_hb = -1;
     for (size_t i = 0; i < ph.size(); ++i) {
         if (ph[i].type == PH_FWD) last_fwd[ph[i].layer] = (int)i;
         if (ph[i].type == PH_BWD) last_bwd[ph[i].layer] = (int)i;
+        if (ph[i].type == PH_HEADB) last_hb = (int)i;
     }
-    for (auto& k : ph) {
-        if (k.dep_e <= REF_LAST_FWD) k.dep_e = last_fwd[REF_LAST_FWD - k.dep_e];
-        else if (k.dep_e <= REF_LAST_BWD) k.dep_e = last_bwd[REF_LAST_BWD - k.dep_e];
-    }
+    auto resolve = [&](int d) {
+        if (d == REF_LAST_HB) return last_hb;
+        if (d <= REF_LAST_FWD) return last_fwd[REF_LAST_FWD - d];
+        if (d <= REF_LAST_BWD) return last_bwd[REF_LAST_BWD - d];
+        return d;
+    };
+    for (auto& k : ph) { k.dep_e = resolve(k.dep_e); k.dep_g = resolve(k.dep_g); }
     int rc = dmalloc(e->phases, ph.size());
     if (rc) return rc;
     if (hipMemcpy(e->phases, ph.data(), ph.size() * sizeof(KPhase), hipMemcpyHostToDevice) != hipSuccess)
