@@ -541,8 +541,11 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     for (int l = 0; l < e->L; ++l) per_slot += (size_t)e->Bpad * e->npad[l] * (l >= 1 ? 2 : 1);
     per_slot += (size_t)e->Bpad * e->out_pad;
     per_slot *= sizeof(float);
-    const int64_t budget = d->spill_budget_bytes > 0 ? d->spill_budget_bytes : (int64_t)2 << 30;
-    e->slots = (int)std::max<int64_t>(1, std::min<int64_t>(64, budget / (int64_t)per_slot));
+    int64_t budget = d->spill_budget_bytes > 0 ? d->spill_budget_bytes : (int64_t)2 << 30;
+    int slot_cap = 64;
+    if (const char* v = getenv("MCPC_SPILL_GB")) budget = (int64_t)atoi(v) << 30;      // tuning knobs
+    if (const char* v = getenv("MCPC_SLOT_CAP")) slot_cap = std::max(2, atoi(v));
+    e->slots = (int)std::max<int64_t>(1, std::min<int64_t>(slot_cap, budget / (int64_t)per_slot));
     if (e->slots >= 2) { e->slots &= ~1; e->half_slots = e->slots / 2; } else { e->half_slots = 1; }
     if (getenv("MCPC_NO_OVERLAP")) e->half_slots = e->slots;       // tuning knob: serial flushes on the caller's stream
     if (e->half_slots < e->slots) {
@@ -672,7 +675,8 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
         const int wave_tiles = ((ne + 63) / 64) * ((na + 63) / 64);
         // enough K-splits for ~4096 waves (3 resident per SIMD at ~150 registers): the kernel streams the
         // spill from HBM, and occupancy + the two-block prefetch hide its latency
-        int ksplit = std::max(1, std::min(4096 / wave_tiles, rows / 64));
+        static const int target_waves = getenv("MCPC_DW_WAVES") ? std::max(256, atoi(getenv("MCPC_DW_WAVES"))) : 4096;
+        int ksplit = std::max(1, std::min(target_waves / wave_tiles, rows / 64));
         int rps = ((rows + ksplit - 1) / ksplit + 15) / 16 * 16;
         ksplit = (rows + rps - 1) / rps;
         const size_t g_floats = (size_t)ksplit * ne * na, b_floats = (size_t)ksplit * ne;
