@@ -13,7 +13,7 @@ import sys
 def total(path, name):
     s = n = 0
     for r in csv.DictReader(open(path)):
-        if "mcpc_steps_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+        if "mcpc_steps" in r["Kernel_Name"] and r["Counter_Name"] == name:
             s += float(r["Counter_Value"]); n += 1
     return s, n
 

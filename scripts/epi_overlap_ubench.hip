@@ -62,6 +62,33 @@ __global__ __launch_bounds__(512) void k(const Args a) {
         f32x4 o = {0.1f * lane, -0.2f * lane, 0.05f * lane, 0.3f}, y = {0.f, 1.f, 0.f, 1.f};
         float lsum = 0.f;
         m0 = __builtin_amdgcn_s_memtime();
+        if (EK == 4) {
+            // same arithmetic, 4 independent quads per iteration written stage by stage (16 exps, then 16 rcps, ...)
+            f32x4 oq[4] = {o, o * 1.1f, o * 0.9f, o * 1.2f};
+            for (int it = 0; it < a.e_iters / 4; ++it) {
+                float ov[16], ex[16], rc[16], lg[16], ev[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ov[j] = oq[j >> 2][j & 3];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ex[j] = __builtin_amdgcn_exp2f(-fabsf(ov[j]) * 1.4426950408889634f);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) rc[j] = __builtin_amdgcn_rcpf(1.0f + ex[j]);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) lg[j] = __builtin_amdgcn_logf(1.0f + ex[j]);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float yv = y[j & 3];
+                    const bool on = (4 * lane + (j & 3)) >= a.mask && (4 * lane + (j & 3)) < a.n;
+                    const float sg = (ov[j] >= 0.0f ? 1.0f : ex[j]) * rc[j];
+                    const float bc = fmaxf(ov[j], 0.0f) - ov[j] * yv + 0.6931471805599453f * lg[j];
+                    ev[j] = on ? sg - yv : 0.f;
+                    lsum += on ? bc : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) oq[j >> 2][j & 3] += ev[j] * a.scale;
+            }
+            o = oq[0] + oq[1] + oq[2] + oq[3];
+        } else
         for (int it = 0; it < a.e_iters; ++it) {
             f32x4 yy = y;
             if (EK == 2) yy = __builtin_nontemporal_load((const f32x4*)(xg + ((it & 63) * 64 + lane) * 4));
@@ -119,6 +146,7 @@ int main() {
         run<0, 0>(a, 0, EI); run<1, 0>(a, GI, EI); run<2, 0>(a, GI, EI);
         run<1, 1>(a, GI, EI); run<2, 1>(a, GI, EI);
         run<1, 2>(a, GI, EI); run<2, 2>(a, GI, EI);
+        run<0, 4>(a, 0, EI); run<1, 4>(a, GI, EI); run<2, 4>(a, GI, EI);
     }
     return 0;
 }

@@ -48,6 +48,29 @@ __global__ __launch_bounds__(256) void k32(float* out, unsigned long long* cyc, 
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = m1 - m0;
 }
 
+
+// 4x4x1 (16 blocks): the fine-grained shape -- 4 chains x 64 units per instruction, A broadcast from block `abid`
+template <int NACC, int BCAST>
+__global__ __launch_bounds__(256) void k4(float* out, unsigned long long* cyc, int iters) {
+    f32x4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = {0.f, 0.f, 0.f, 0.f};
+    float a = threadIdx.x * 1e-3f, b = threadIdx.x * 2e-3f + 1.f;
+    unsigned long long m0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#define K4_ROUND(ABID) _Pragma("unroll") for (int i = 0; i < NACC; ++i) { \
+            if (BCAST) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[i], 4, ABID, 0); \
+            else acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[i], 0, 0, 0); }
+#pragma unroll
+        for (int r = 0; r < 96 / NACC / 4; ++r) { K4_ROUND(0) K4_ROUND(5) K4_ROUND(10) K4_ROUND(15) }
+        a += 1e-6f;
+    }
+    unsigned long long m1 = __builtin_amdgcn_s_memtime();
+    f32x4 s = acc[0];
+    for (int i = 1; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y + s.z + s.w;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = m1 - m0;
+}
+
 template <typename F> void run(const char* name, F launch, int per_iter, double flop_per_mfma) {
     float* out; unsigned long long* cyc;
     hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 256 * 4 * 8);
@@ -76,5 +99,9 @@ int main() {
     run("32x32x2 f32, 4 acc round-robin", [](float* o, unsigned long long* c, int n) { hipLaunchKernelGGL((k32<4>), dim3(256), dim3(256), 0, 0, o, c, n); }, 16, 4096.0);
     run("32x32x2 f32, 2 acc alternating", [](float* o, unsigned long long* c, int n) { hipLaunchKernelGGL((k32<2>), dim3(256), dim3(256), 0, 0, o, c, n); }, 16, 4096.0);
     run("32x32x2 f32, 1 acc chain", [](float* o, unsigned long long* c, int n) { hipLaunchKernelGGL((k32<1>), dim3(256), dim3(256), 0, 0, o, c, n); }, 16, 4096.0);
+    run("4x4x1 16B f32, 6 acc, no bcast", [](float* o, unsigned long long* c, int n) { hipLaunchKernelGGL((k4<6, 0>), dim3(256), dim3(256), 0, 0, o, c, n); }, 96, 512.0);
+    run("4x4x1 16B f32, 6 acc, cbsz=4 abid", [](float* o, unsigned long long* c, int n) { hipLaunchKernelGGL((k4<6, 1>), dim3(256), dim3(256), 0, 0, o, c, n); }, 96, 512.0);
+    run("4x4x1 16B f32, 3 acc, cbsz=4 abid", [](float* o, unsigned long long* c, int n) { hipLaunchKernelGGL((k4<3, 1>), dim3(256), dim3(256), 0, 0, o, c, n); }, 96, 512.0);
+    run("4x4x1 16B f32, 12 acc, cbsz=4 abid", [](float* o, unsigned long long* c, int n) { hipLaunchKernelGGL((k4<12, 1>), dim3(256), dim3(256), 0, 0, o, c, n); }, 96, 512.0);
     return 0;
 }
