@@ -154,60 +154,67 @@ int plan_lds(mcpc_engine* e) {
     return 0;
 }
 
-// LDS plan of the in-place wave-specialised kernel: every FX_l and E_l has its own rows (no staging slots).  The
-// read-out error lives in a ring of `ws2_ring` chunks of `ws2_chunk` tiles that starts ON TOP of E_{L-1}: E_{L-1} is
-// only needed from the end of the read-out phase (FWD_{L-1} is scheduled behind it) to the BWD_{L-2} GEMM, and the
-// ring only during the read-out phase.  That pays for chunks of 8 tiles (two per GEMM wave: no imbalance) and a ring
-// of three (two GEMMs of slack between a chunk's epilogue and its back-projection) at cfg-M.
+// LDS plan of the in-place wave-specialised kernel: every FX_l has its own rows (no staging slots).  With a read-out,
+// the prediction errors E_1 .. E_{L-1} and the ring of read-out error chunks share ONE region: the ring is only live
+// during the read-out phase at the start of a step, the E_l only from the forward entries (scheduled behind the
+// read-out) to the x updates at its end.  At cfg-M that pays for a ring of THREE chunks of 13 tiles (49 tiles =
+// 13+12+12+12; a table entry hands out up to 16 tiles, four per GEMM wave): two GEMMs of slack between a chunk's
+// epilogue and its back-projection, 15 table entries per step.
 int plan_lds_ws2(mcpc_engine* e) {
     const int CT = e->ct, L = e->L;
     int off = 0;
     for (int l = 0; l < L; ++l) { e->lds_a[l] = off; off += CT * (e->npad[l] + kLdPad); }
     e->lds_e[0] = 0;
-    for (int l = 1; l < L - 1; ++l) { e->lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
     e->lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
     e->lds_ws_sync = off; off += 16;
     e->lds_ws_stage = 0;
-    const int e_last = L >= 2 ? CT * (e->npad[L - 1] + kLdPad) : 0;      // E_{L-1}: the last region, the ring overlays it
-    if (L >= 2) e->lds_e[L - 1] = off;
+    // shared region: E_1 .. E_{L-1} stacked | ring
+    int e_sum = 0;
+    for (int l = 1; l < L; ++l) { e->lds_e[l] = off + e_sum; e_sum += CT * (e->npad[l] + kLdPad); }
     e->lds_eo = off;
     e->ws2_chunk = 0; e->ws2_ring = 0;
     int ring_floats = 0;
     if (e->has_head) {
-        const int ht = e->out_pad / 16;
-        static const int cand[][2] = {{8, 3}, {8, 2}, {6, 3}, {6, 2}, {4, 3}, {4, 2}, {2, 2}};
-        for (auto& hr : cand) {
-            const int hc = std::min(hr[0], std::max(ht, 1)), nb = hr[1];
-            const int need = nb * CT * (hc * 16 + kLdPad);
-            if ((off + std::max(need, e_last)) * (int)sizeof(float) <= 160 * 1024) { e->ws2_chunk = hc; e->ws2_ring = nb; ring_floats = need; break; }
-        }
-        if (!e->ws2_chunk) return fail(MCPC_ENOMEM, "in-place schedule does not fit the LDS");
+        // fewest chunks of at most 16 tiles whose ring of two still fits; chunks equalised; ring of three if that fits too
+        const int ht = std::max(e->out_pad / 16, 1);
+        const int span = kWsPairs * kWs2NT;
+        auto fits = [&](int hc, int nb) { return (off + std::max(nb * CT * (hc * 16 + kLdPad), e_sum)) * (int)sizeof(float) <= 160 * 1024; };
+        int hc_fit = 0;
+        for (int hc = std::min(span, ht); hc >= 1; --hc)
+            if (fits(hc, 2)) { hc_fit = hc; break; }
+        if (!hc_fit) return fail(MCPC_ENOMEM, "in-place schedule does not fit the LDS");
+        const int nch = (ht + hc_fit - 1) / hc_fit;
+        const int hc = (ht + nch - 1) / nch;                 // equalised: the widest chunk of the split
+        const int nb = (nch >= 3 && fits(hc, 3)) ? 3 : 2;
+        e->ws2_chunk = hc; e->ws2_ring = nb; ring_floats = nb * CT * (hc * 16 + kLdPad);
     }
-    off += std::max(ring_floats, e_last);
+    off += std::max(ring_floats, e_sum);
     e->lds_bytes = off * (int)sizeof(float);
     if (e->lds_bytes > 160 * 1024) return fail(MCPC_ENOMEM, "in-place schedule does not fit the LDS (%d bytes)", e->lds_bytes);
     return 0;
 }
 
 // Table of the in-place wave-specialised kernel (mcpc_steps_ws2.h), R = ring size.  One step =
-//   read-out:  HF(0) .. HF(R-1) HB(0) HF(R) HB(1) ...  with the forward entries FWD_{L-2} ... FWD_1, FWD_0 slipped in
-//              one at a time behind the HB entries;
-//   FWD_{L-1}  (its output E_{L-1} shares LDS with the ring, so it follows the last HB);
-//   updates:   BWD_{L-1} (accb hand-off), BWD_0 ... BWD_{L-2} (the one that needs E_{L-1} last);  energy reduction.
-// Read dependencies (dep_e, "all E waves past entry"):  HF(c) <- last BWD_{L-1} of the PREVIOUS step (FX_{L-1});
-//   HB(c) <- HF(c);  FWD_l <- last BWD_{l-1} of the previous step (FX_{l-1});  BWD_l GEMM <- last FWD_{l+1} (E_{l+1}).
-// Write-after-read (dep_g, "all G waves past entry") is only needed around the ring:
-//   HF(c) <- HB(c-R);  HF(c), c < R, in a ring slot that overlaps E_{L-1} <- last BWD_{L-2} of the previous step;
-//   FWD_{L-1} <- HB(last).
-// The others are implied: a G wave that stores into E_l / FX_l / FX_{L-1} has just waited for epilogues that can only
-// have run after every G wave finished the GEMMs that read the old contents (FWD_l after the BWD_{l-1} epilogues,
-// BWD_l after the FWD_{l+1} epilogues, the BWD_{L-1} hand-off after HB(last) <- HF(last) epilogues).
+//   read-out:  HF(0) .. HF(R-1) HB(0) HF(R) HB(1) ...   (FWD_0, which has no GEMM, slipped in behind the first HB);
+//   forward:   FWD_{L-1} ... FWD_1   (their outputs E_l share LDS with the ring, so they follow the last HB);
+//   updates:   BWD_{L-1} (accb hand-off), BWD_0 ... BWD_{L-2};  energy reduction.
+// Read dependencies, waited for in front of the GEMM (dep_e, "all E waves past entry"):
+//   HF(c) <- last BWD_{L-1} of the PREVIOUS step (FX_{L-1});  HB(c) <- HF(c);  FWD_l <- last BWD_{l-1} of the previous
+//   step (FX_{l-1});  BWD_l GEMM <- last FWD_{l+1} (E_{l+1}).
+// Write-after-read dependencies, waited for behind the GEMM, before the block is stored:
+//   dep_g ("all G waves past entry"):  HF(c) <- HB(c-R) (ring slot);  HF(c) in a slot that overlaps the E_l <- last GEMM
+//     of the previous step that reads an E_l (BWD_{L-2});  FWD_l <- HB(last);
+//   dep_se ("all E waves past entry"): HF(c) in a slot that overlaps the E_l <- the last BWD entry of the previous step
+//     (its epilogue loads read E_l).
+// The others are implied: a G wave that stores into FX_l has just waited for epilogues that can only have run after every
+// G wave finished the GEMMs that read the old contents (the BWD_{L-1} hand-off after HB(last) <- HF(last) epilogues, BWD_l
+// after the FWD_{l+1} epilogues, which follow FWD_{l+1}'s GEMM over FX_l).
 int build_phases_ws2(mcpc_engine* e) {
     const int L = e->L;
-    const int span = kWsPairs * kWsNT;       // 8
+    const int span = kWsPairs * kWs2NT;      // 16
     auto tiles = [&](int l) { return e->npad[l] / 16; };
-    auto blank = [&]() { KPhase k{}; k.dep_e = -1; k.dep_g = -1; return k; };
-    enum { REF_LAST_BWD = -1000, REF_LAST_FWD = -2000, REF_LAST_HB = -3000 };   // symbolic deps: REF_x - layer
+    auto blank = [&]() { KPhase k{}; k.dep_e = -1; k.dep_g = -1; k.dep_se = -1; return k; };
+    enum { REF_LAST_BWD = -1000, REF_LAST_FWD = -2000, REF_LAST_HB = -3000, REF_LAST_BWD_GEMM = -4000, REF_LAST_BWD_ANY = -5000 };   // symbolic deps
     auto fwd_entries = [&](int l, std::vector<KPhase>& out) {
         for (int base = 0; base < tiles(l); base += span) {
             KPhase k = blank();
@@ -219,39 +226,42 @@ int build_phases_ws2(mcpc_engine* e) {
                 k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
                 k.out_lds = e->lds_e[l]; k.out_ld = e->npad[l] + kLdPad;
                 k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_BWD - (l - 1);
-                if (l == L - 1 && e->has_head) k.dep_g = REF_LAST_HB;
+                if (e->has_head) k.dep_g = REF_LAST_HB;       // E_l shares LDS with the ring
             }
             out.push_back(k);
         }
     };
-    // forward entries that can run beside the read-out (everything but FWD_{L-1} when there is a read-out)
+    // FWD_0 has no GEMM and no LDS output: it fills a gap of the read-out; the others follow the read-out
     std::vector<KPhase> fill, after;
-    for (int l = L - 1; l >= 0; --l) fwd_entries(l, (l == L - 1 && e->has_head && L >= 2) ? after : fill);
+    for (int l = L - 1; l >= 0; --l) fwd_entries(l, (l >= 1 && e->has_head) ? after : fill);
     std::vector<KPhase> ph;
     size_t nf = 0;
     if (e->has_head) {
-        const int hc = e->ws2_chunk, R = e->ws2_ring;
+        const int hc = e->ws2_chunk, R = e->ws2_ring;        // hc: widest chunk = ring slot width
         const int ht = e->out_pad / 16;
         const int nch = (ht + hc - 1) / hc;
+        std::vector<int> c_start(nch + 1, 0);                 // chunk c = tiles [c_start[c], c_start[c+1]): sizes differ by <= 1
+        for (int c = 0; c < nch; ++c) c_start[c + 1] = c_start[c] + ht / nch + (c < ht % nch ? 1 : 0);
         const int chunk_floats = e->ct * (hc * 16 + kLdPad);
-        const int e_last = L >= 2 ? e->ct * (e->npad[L - 1] + kLdPad) : 0;
+        int e_sum = 0;
+        for (int l = 1; l < L; ++l) e_sum += e->ct * (e->npad[l] + kLdPad);
         std::vector<int> idx_f(nch, -1), idx_b(nch, -1);
         auto add_f = [&](int c) {
             KPhase f = blank();
-            f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c * hc; f.ntiles = std::min(hc, ht - c * hc); f.rot = c & 3;
+            f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c_start[c]; f.ntiles = c_start[c + 1] - c_start[c]; f.rot = c & 3;
             f.A = (const f32x4*)e->lin[L].Wf; f.a_tile_stride = tiles(L - 1) * 64; f.nkb = tiles(L - 1);
             f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad;
             f.out_lds = e->lds_eo + (c % R) * chunk_floats; f.out_ld = hc * 16 + kLdPad;
             f.flags = PHF_WS_GEMM | PHF_WS_EPI; f.dep_e = REF_LAST_BWD - (L - 1);
             if (c >= R) f.dep_g = idx_b[c - R];
-            else if (L >= 2 && (c % R) * chunk_floats < e_last) f.dep_g = REF_LAST_BWD - (L - 2);   // slot overlaps E_{L-1}
+            else if ((c % R) * chunk_floats < e_sum) { f.dep_g = REF_LAST_BWD_GEMM; f.dep_se = REF_LAST_BWD_ANY; }   // slot overlaps the E_l
             idx_f[c] = (int)ph.size(); ph.push_back(f);
         };
         auto add_b = [&](int c) {
             KPhase b = blank();
             b.type = PH_HEADB; b.layer = L - 1; b.tile0 = 0; b.ntiles = tiles(L - 1);
-            b.A = (const f32x4*)e->lin[L].Wb; b.a_tile_stride = ht * 64; b.a_off0 = c * hc * 64;
-            b.nkb = std::min(hc, ht - c * hc);
+            b.A = (const f32x4*)e->lin[L].Wb; b.a_tile_stride = ht * 64; b.a_off0 = c_start[c] * 64;
+            b.nkb = c_start[c + 1] - c_start[c];
             b.b_lds = e->lds_eo + (c % R) * chunk_floats; b.ldb = hc * 16 + kLdPad;
             b.flags = PHF_WS_GEMM; b.dep_e = idx_f[c];
             idx_b[c] = (int)ph.size(); ph.push_back(b);
@@ -265,8 +275,8 @@ int build_phases_ws2(mcpc_engine* e) {
     }
     while (nf < fill.size()) ph.push_back(fill[nf++]);
     for (auto& k : after) ph.push_back(k);
-    // x updates: the bottom layer first (its back-projection is complete), then top-down ... no: bottom-up from
-    // BWD_0, so that BWD_{L-2}, which reads the E_{L-1} produced last, comes last
+    // x updates: BWD_{L-1} first (its back-projection is complete: accb), then bottom-up from BWD_0, so that BWD_{L-2},
+    // which reads the E_{L-1} produced last, comes last
     for (int base = 0; base < tiles(L - 1); base += span) {
         KPhase k = blank();
         k.type = PH_BWD; k.layer = L - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(L - 1) - base);
@@ -288,19 +298,21 @@ int build_phases_ws2(mcpc_engine* e) {
     { KPhase k = blank(); k.type = PH_ENERGY; k.flags = PHF_WS_EPI; ph.push_back(k); }
     // resolve the symbolic dependencies
     std::vector<int> last_fwd(L, -1), last_bwd(L, -1);
-    int last_hb = -1;
+    int last_hb = -1, last_bwd_gemm = -1, last_bwd_any = -1;
     for (size_t i = 0; i < ph.size(); ++i) {
         if (ph[i].type == PH_FWD) last_fwd[ph[i].layer] = (int)i;
-        if (ph[i].type == PH_BWD) last_bwd[ph[i].layer] = (int)i;
+        if (ph[i].type == PH_BWD) { last_bwd[ph[i].layer] = (int)i; last_bwd_any = (int)i; if (ph[i].flags & PHF_WS_GEMM) last_bwd_gemm = (int)i; }
         if (ph[i].type == PH_HEADB) last_hb = (int)i;
     }
     auto resolve = [&](int d) {
+        if (d == REF_LAST_BWD_ANY) return last_bwd_any;
+        if (d == REF_LAST_BWD_GEMM) return last_bwd_gemm;
         if (d == REF_LAST_HB) return last_hb;
-        if (d <= REF_LAST_FWD) return last_fwd[REF_LAST_FWD - d];
-        if (d <= REF_LAST_BWD) return last_bwd[REF_LAST_BWD - d];
+        if (d <= REF_LAST_FWD && d > REF_LAST_HB) return last_fwd[REF_LAST_FWD - d];
+        if (d <= REF_LAST_BWD && d > REF_LAST_FWD) return last_bwd[REF_LAST_BWD - d];
         return d;
     };
-    for (auto& k : ph) { k.dep_e = resolve(k.dep_e); k.dep_g = resolve(k.dep_g); }
+    for (auto& k : ph) { k.dep_e = resolve(k.dep_e); k.dep_g = resolve(k.dep_g); k.dep_se = resolve(k.dep_se); }
     int rc = dmalloc(e->phases, ph.size());
     if (rc) return rc;
     if (hipMemcpy(e->phases, ph.data(), ph.size() * sizeof(KPhase), hipMemcpyHostToDevice) != hipSuccess)

@@ -75,7 +75,9 @@ struct KPhase {
     int out_lds, out_ld;   // HEADF: LDS offset / row stride of the e_o chunk this phase writes
     int dep_e, dep_g;      // wave-specialised kernels: entry whose completion by all E / all G waves must precede (-1: none;
                            // in-place variant: an index above the entry's own refers to the previous step)
-    int rot;               // in-place variant: pair k owns tiles tile0 + ((k + rot) & 3) + 4 i (balances chunks of 6 tiles)
+    int rot;               // in-place variant: pair k owns tiles tile0 + ((k + rot) & 3) + 4 i (balances uneven chunks)
+    int dep_se;            // in-place variant: entry all E waves must have passed before this entry's block is STORED (its
+                           // LDS rows are still read by their epilogues); dep_g is waited for at the same point
 };
 
 // Phase descriptors are fetched through the constant address space: wave-uniform s_load_* on the scalar cache.
@@ -211,9 +213,18 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4*
     // Three named register sets, fragment loads issued TWO k-blocks ahead of their MFMAs: with one
     // wave per SIMD (or two) the loads in flight per CU, not the issue rate, bound the L2 stream.
     // The fragments of k-blocks 0 and 1 were requested by the caller during the previous phase.
+    // (Four sets / three blocks ahead: 35.7 -> 33.3 cycles per MFMA in the isolated loop, scripts/mfma_stream_ubench.hip,
+    // but no gain inside the step kernel, where the GEMMs are 12-16 k-blocks long -- measured and dropped.)
     const int c = lane & 15, q = lane >> 4;
     const float* bp = B + c * ldb + 4 * q;
     f32x4 aP[NT], aQ[NT], aR[NT], bP[CTT], bQ[CTT], bR[CTT];
+    // Fragment addresses = wave-uniform base (SGPR pair, advanced by the scalar ALU) + a 32-bit per-lane byte offset that
+    // never changes during the GEMM: `global_load_dwordx4 v, v_off, s[base]` needs no VALU address arithmetic at all (with
+    // a 64-bit per-lane pointer every load cost a v_add, a v_ashr and a v_lshl_add_u64 between the MFMA blocks).
+    uint32_t voff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) voff[t] = (uint32_t)(aoff[t] + lane) * 16u;
+    const char __attribute__((address_space(1)))* const Ab = (const char __attribute__((address_space(1)))*)A;
 #define MCPC_LOAD_B(b_, k_)                                                                         \
     do {                                                                                            \
         _Pragma("unroll") for (int ct = 0; ct < CTT; ++ct)                                          \
@@ -221,8 +232,25 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4*
     } while (0)
 #define MCPC_LOAD_SET(a_, b_, k_)                                                                   \
     do {                                                                                            \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) a_[t] = A[aoff[t] + MCPC_KSEL(k_) * 64 + lane]; \
+        const char __attribute__((address_space(1)))* const Ak_ = Ab + (size_t)MCPC_KSEL(k_) * 1024u; \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) a_[t] = *(const gf32x4*)(Ak_ + voff[t]);     \
         MCPC_LOAD_B(b_, k_);                                                                        \
+    } while (0)
+    // One pipeline stage = "request set k+2, compute set k".  The requests are spread over the MFMA block (one memory
+    // instruction behind every few MFMAs, where the issue port idles anyway while the matrix pipe works) instead of
+    // sitting in a clump between two blocks, during which the pipe drained: 36-37 -> 33 cycles per MFMA.
+#define MCPC_STAGE_SCHED()                                                                          \
+    do {                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   /* 2 MFMA */                       \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   /* 1 VMEM read */                  \
+        }                                                                                           \
+        _Pragma("unroll") for (int ct = 0; ct < CTT; ++ct) {                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                      \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* 1 DS read */                    \
+        }                                                                                           \
+        if constexpr (4 * NT * CTT - 2 * NT - 2 * CTT > 0)                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * CTT - 2 * NT - 2 * CTT, 0);        \
     } while (0)
 #pragma unroll
     for (int t = 0; t < NT; ++t) { aP[t] = pre0[t]; aQ[t] = pre1[t]; }
@@ -233,19 +261,20 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4*
     // load before the next MFMA block (guide section 5, "Three .s-level traps" (c)).
     int kb = 0;
     for (; kb + 5 <= nkb; kb += 3) {
-        // sched_barrier pins "request set k+2, then compute set k": left alone, the machine scheduler
-        // sinks the loads next to their consumers and the two-block prefetch distance is lost
-        MCPC_LOAD_SET(aR, bR, kb + 2);
+        // sched_barrier pins the stage boundaries: left alone, the machine scheduler sinks the loads next to their
+        // consumers and the two-block prefetch distance is lost
         __builtin_amdgcn_sched_barrier(0);
+        MCPC_LOAD_SET(aR, bR, kb + 2);
         mfma_block<NT, NTT, CTT>(acc, aP, bP);
+        MCPC_STAGE_SCHED();
         __builtin_amdgcn_sched_barrier(0);
         MCPC_LOAD_SET(aP, bP, kb + 3);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
+        MCPC_STAGE_SCHED();
         __builtin_amdgcn_sched_barrier(0);
         MCPC_LOAD_SET(aQ, bQ, kb + 4);
-        __builtin_amdgcn_sched_barrier(0);
         mfma_block<NT, NTT, CTT>(acc, aR, bR);
+        MCPC_STAGE_SCHED();
         __builtin_amdgcn_sched_barrier(0);
     }
     // tail: 0..4 k-blocks left, sets P (kb) and Q (kb+1) are loaded when they exist
@@ -274,6 +303,7 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4*
     } else {
         if (rem == 1) mfma_block<NT, NTT, CTT>(acc, aP, bP);
     }
+#undef MCPC_STAGE_SCHED
 #undef MCPC_LOAD_SET
 #undef MCPC_LOAD_B
 }

@@ -17,6 +17,9 @@ namespace mcpc {
 
 constexpr int kWsPairs = 4;            // (G, E) pairs per workgroup = tile stride
 constexpr int kWsNT = 2;               // unit tiles per pair per table entry (an entry hands out 8 tiles)
+#ifndef MCPC_WS_SLEEP
+#define MCPC_WS_SLEEP 2
+#endif
 constexpr int kWsSpinLimit = 1 << 22;  // iterations (~0.1-0.2 us each): ~0.5 s, far beyond any legitimate wait (< 1 ms)
 
 enum : int { PHF_WS_GEMM = 16, PHF_WS_EPI = 32 };   // which role has work in a table entry
@@ -48,7 +51,7 @@ __device__ __forceinline__ void ws_wait_all(const int* p, int need, int* err, in
     for (; spin < kWsSpinLimit; ++spin) {
         const int a = ws_ld(p), b = ws_ld(p + 1), c = ws_ld(p + 2), d = ws_ld(p + 3);
         if (min(min(a, b), min(c, d)) >= need) break;
-        __builtin_amdgcn_s_sleep(2);
+        if (MCPC_WS_SLEEP > 0) __builtin_amdgcn_s_sleep(MCPC_WS_SLEEP);
     }
     if (spin == kWsSpinLimit) { if (!dead && (threadIdx.x & 63) == 0) atomicOr(err, 1); dead = 1; }
     MCPC_WS_FENCE(__ATOMIC_ACQUIRE);
@@ -57,7 +60,7 @@ __device__ __forceinline__ void ws_wait_one(const int* p, int need, int* err, in
     int spin = dead ? kWsSpinLimit : 0;
     for (; spin < kWsSpinLimit; ++spin) {
         if (ws_ld(p) >= need) break;
-        __builtin_amdgcn_s_sleep(2);
+        if (MCPC_WS_SLEEP > 0) __builtin_amdgcn_s_sleep(MCPC_WS_SLEEP);
     }
     if (spin == kWsSpinLimit) { if (!dead && (threadIdx.x & 63) == 0) atomicOr(err, 2); dead = 1; }
     MCPC_WS_FENCE(__ATOMIC_ACQUIRE);

@@ -27,6 +27,8 @@ namespace mcpc {
 #define MCPC_EXP_GEMM_GATE
 #endif
 
+constexpr int kWs2NT = 4;              // unit tiles per pair per table entry of THIS kernel: an entry hands out 16 tiles
+static_assert(kWs2NT == 4, "accb holds 4 tiles per pair");
 enum : int { PHF_WS2_HANDOFF = 64 };   // BWD entry without GEMM whose block (accb) still comes from G
 
 struct Ws2Sync {
@@ -45,7 +47,7 @@ __device__ __forceinline__ int ws2_need(int base, int n_ent, int p, int dep) {
 __device__ __forceinline__ void ws2_prefetch(const KPhase& ph, int k, int lane, const void* dummy, int& nt_out, int (&aoff)[4],
                                              f32x4 (&pre0)[4], f32x4 (&pre1)[4]) {
     const int kk = (k + ph.rot) & 3;
-    const int ntmax = (ph.type == PH_HEADB) ? 4 : kWsNT;
+    const int ntmax = (ph.type == PH_HEADB) ? 4 : kWs2NT;
     int nt = (ph.ntiles - kk + kWsPairs - 1) / kWsPairs;
     nt = nt < 0 ? 0 : (nt > ntmax ? ntmax : nt);
     if (!(ph.flags & PHF_WS_GEMM) || ph.nkb <= 0) nt = 0;
@@ -151,7 +153,7 @@ __device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPha
 template <int CTT>
 __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NW = kWsPairs, NTW = kWsNT;
+    constexpr int NW = kWsPairs, NTW = kWs2NT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -204,33 +206,34 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
                 const bool is_headb = ph.type == PH_HEADB;
                 const bool works = (ph.flags & PHF_WS_GEMM) || handoff;
                 const bool stores = works && !is_headb;
-                f32x4 acc[kWsNT][CTT];
+                f32x4 acc[kWs2NT][CTT];
 #pragma unroll
-                for (int i = 0; i < kWsNT; ++i)
+                for (int i = 0; i < kWs2NT; ++i)
 #pragma unroll
                     for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = splat(0.f);
                 STAMP(0);
                 if (works) {
                     if (ph.dep_e >= 0) ws_wait_all(sync->prog_e, ws2_need(base, n_ent, p, ph.dep_e), P.err, dead);
-                    if (ph.dep_g >= 0) ws_wait_all(sync->prog_g, ws2_need(base, n_ent, p, ph.dep_g), P.err, dead);
                     STAMP(1);
                     if (is_headb) {
                         if (nt > 0 MCPC_EXP_GEMM_GATE) gemm_tiles<4, CTT, NW>(accb, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
                         STAMP(2);
                     } else {
                         if (handoff) {
-                            const int sub = ph.tile0 / (NW * kWsNT);                 // which pair of accb tiles
 #pragma unroll
-                            for (int i = 0; i < kWsNT; ++i)
+                            for (int i = 0; i < kWs2NT; ++i)
 #pragma unroll
-                                for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = sub == 0 ? accb[i][ct] : accb[i + 2][ct];
+                                for (int ct = 0; ct < CTT; ++ct) {
+                                    if constexpr (kWs2NT == 4) acc[i][ct] = accb[i][ct];     // one entry covers all of accb
+                                    else acc[i][ct] = ph.tile0 < NW * kWs2NT ? accb[i][ct] : accb[(i + 2) & 3][ct];
+                                }
                         }
                         if (nt > 0 && ph.nkb > 0 MCPC_EXP_GEMM_GATE) {
-                            int aoff2[kWsNT];
-                            f32x4 p0[kWsNT], p1[kWsNT];
+                            int aoff2[kWs2NT];
+                            f32x4 p0[kWs2NT], p1[kWs2NT];
 #pragma unroll
-                            for (int i = 0; i < kWsNT; ++i) { aoff2[i] = aoff[i]; p0[i] = pre0[i]; p1[i] = pre1[i]; }
-                            gemm_tiles<kWsNT, CTT, NW>(acc, (const gf32x4*)ph.A, aoff2, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, p0, p1);
+                            for (int i = 0; i < kWs2NT; ++i) { aoff2[i] = aoff[i]; p0[i] = pre0[i]; p1[i] = pre1[i]; }
+                            gemm_tiles<kWs2NT, CTT, NW>(acc, (const gf32x4*)ph.A, aoff2, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, p0, p1);
                         }
                         STAMP(3);
                     }
@@ -239,14 +242,18 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
                 ws2_prefetch(ph_next, k, lane, P.mu1, nt_next, aoff, pre0, pre1);   // (past the last entry: the old descriptor again)
                 STAMP(4);
                 if (stores) {
+                    // write-after-read: the rows this block goes to may still be read by GEMMs (dep_g) or epilogues (dep_se)
+                    // of entries that share them -- waited for here, behind the GEMM, not in front of it
+                    if (ph.dep_g >= 0) ws_wait_all(sync->prog_g, ws2_need(base, n_ent, p, ph.dep_g), P.err, dead);
+                    if (ph.dep_se >= 0) ws_wait_all(sync->prog_e, ws2_need(base, n_ent, p, ph.dep_se), P.err, dead);
                     // the block goes where its consumer reads it; E_k finishes it in place
                     const int kk = (k + ph.rot) & 3;
                     int ntw = (ph.ntiles - kk + NW - 1) / NW;
-                    ntw = ntw < 0 ? 0 : (ntw > kWsNT ? kWsNT : ntw);
+                    ntw = ntw < 0 ? 0 : (ntw > kWs2NT ? kWs2NT : ntw);
                     float* const out = lds + ph.out_lds;
                     const int col0 = (ph.type == PH_HEADF) ? 0 : 16 * ph.tile0;
 #pragma unroll
-                    for (int i = 0; i < kWsNT; ++i) {
+                    for (int i = 0; i < kWs2NT; ++i) {
                         if (i >= ntw) continue;
                         const int col = col0 + 16 * (kk + NW * i) + 4 * q;
 #pragma unroll
@@ -308,10 +315,10 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
             }
             const int kk = (k + ph.rot) & 3;
             int nt = (ph.ntiles - kk + NW - 1) / NW;
-            nt = nt < 0 ? 0 : (nt > kWsNT ? kWsNT : nt);
-            f32x4 acc[kWsNT][CTT], pa[kWsNT][CTT], pb[kWsNT][CTT];
+            nt = nt < 0 ? 0 : (nt > kWs2NT ? kWs2NT : nt);
+            f32x4 acc[kWs2NT][CTT], pa[kWs2NT][CTT], pb[kWs2NT][CTT];
 #pragma unroll
-            for (int i = 0; i < kWsNT; ++i)
+            for (int i = 0; i < kWs2NT; ++i)
 #pragma unroll
                 for (int ct = 0; ct < CTT; ++ct) { acc[i][ct] = splat(0.f); pa[i][ct] = splat(0.f); pb[i][ct] = splat(0.f); }
             const KLayer& Ly = P.layer[ph.layer];
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
                 const float* const src = lds + ph.out_lds;
                 const int col0 = (ph.type == PH_HEADF) ? 0 : 16 * ph.tile0;
 #pragma unroll
-                for (int i = 0; i < kWsNT; ++i) {
+                for (int i = 0; i < kWs2NT; ++i) {
                     const int col = col0 + 16 * (kk + NW * (i < nt ? i : 0)) + 4 * q;     // unused slots re-read slot 0
 #pragma unroll
                     for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = ld4(src + (16 * ct + c) * ph.out_ld + col);

@@ -26,6 +26,7 @@ variants = {
     "no loss": dict(noise_mode=L.NOISE_PHILOX, loss_kind=L.LOSS_NONE, energy_mode=L.ENERGY_ALL),
     "bare (no noise, no loss, no energies)": dict(noise_mode=L.NOISE_NONE, loss_kind=L.LOSS_NONE, energy_mode=L.ENERGY_NONE),
     "adam, no noise": dict(noise_mode=L.NOISE_NONE, loss_kind=L.LOSS_BERNOULLI, energy_mode=L.ENERGY_ALL, xopt=L.XOPT_ADAM),
+    "full again": dict(noise_mode=L.NOISE_PHILOX, loss_kind=L.LOSS_BERNOULLI, energy_mode=L.ENERGY_ALL),
     "learning (acc all steps)": dict(noise_mode=L.NOISE_PHILOX, loss_kind=L.LOSS_BERNOULLI, energy_mode=L.ENERGY_ALL, acc_begin=0, acc_end=K),
 }
 for name, kw in variants.items():

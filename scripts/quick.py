@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Developer probe: inference-only and learning steps/s of cfg-M for the library MCPC_LIB points at (default: libmcpc.so)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import make_problem, SIZES, N_OUT  # noqa: E402
+from montecarlopredictivecoding_amd import _lib as L  # noqa: E402
+from montecarlopredictivecoding_amd.engine import Engine  # noqa: E402
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+dev = torch.device("cuda", 0)
+W, b, y, xs = make_problem(6000, 30, dev)
+eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, 6000, device=dev)
+eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
+base = dict(noise_mode=L.NOISE_PHILOX, loss_kind=L.LOSS_BERNOULLI, energy_mode=L.ENERGY_ALL, lr=0.03, seed=1)
+out = []
+for name, kw in (("inference", {}), ("learning", dict(acc_begin=K // 5, acc_end=K))):
+    best = 1e9
+    for rep in range(3):
+        eng.load_state(xs)
+        eng.run(50, **base)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        eng.run(K, **base, **kw)
+        torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / K * 1e6)
+    out.append(f"{name} {best:6.1f} us/step")
+print(os.path.basename(os.environ.get("MCPC_LIB", "libmcpc.so")), " | ".join(out), flush=True)
