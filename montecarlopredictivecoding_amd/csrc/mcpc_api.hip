@@ -177,7 +177,7 @@ int plan_lds_ws2(mcpc_engine* e) {
     if (e->has_head) {
         // fewest chunks of at most 16 tiles whose ring of two still fits; chunks equalised; ring of three if that fits too
         const int ht = std::max(e->out_pad / 16, 1);
-        const int span = kWsPairs * kWs2NT;
+        const int span = kWs2Pairs * kWs2NT;
         auto fits = [&](int hc, int nb) { return (off + std::max(nb * CT * (hc * 16 + kLdPad), e_sum)) * (int)sizeof(float) <= 160 * 1024; };
         int hc_fit = 0;
         for (int hc = std::min(span, ht); hc >= 1; --hc)
@@ -211,7 +211,7 @@ int plan_lds_ws2(mcpc_engine* e) {
 // after the FWD_{l+1} epilogues, which follow FWD_{l+1}'s GEMM over FX_l).
 int build_phases_ws2(mcpc_engine* e) {
     const int L = e->L;
-    const int span = kWsPairs * kWs2NT;      // 16
+    const int span = kWs2Pairs * kWs2NT;     // 16
     auto tiles = [&](int l) { return e->npad[l] / 16; };
     auto blank = [&]() { KPhase k{}; k.dep_e = -1; k.dep_g = -1; k.dep_se = -1; return k; };
     enum { REF_LAST_BWD = -1000, REF_LAST_FWD = -2000, REF_LAST_HB = -3000, REF_LAST_BWD_GEMM = -4000, REF_LAST_BWD_ANY = -5000 };   // symbolic deps
@@ -248,7 +248,7 @@ int build_phases_ws2(mcpc_engine* e) {
         std::vector<int> idx_f(nch, -1), idx_b(nch, -1);
         auto add_f = [&](int c) {
             KPhase f = blank();
-            f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c_start[c]; f.ntiles = c_start[c + 1] - c_start[c]; f.rot = c & 3;
+            f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c_start[c]; f.ntiles = c_start[c + 1] - c_start[c]; f.rot = c & (kWs2Pairs - 1);
             f.A = (const f32x4*)e->lin[L].Wf; f.a_tile_stride = tiles(L - 1) * 64; f.nkb = tiles(L - 1);
             f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad;
             f.out_lds = e->lds_eo + (c % R) * chunk_floats; f.out_ld = hc * 16 + kLdPad;
@@ -274,7 +274,8 @@ int build_phases_ws2(mcpc_engine* e) {
         for (int c = std::max(nch - (R - 1), 0); c < nch; ++c) add_b(c);
     }
     while (nf < fill.size()) ph.push_back(fill[nf++]);
-    for (auto& k : after) ph.push_back(k);
+    // bottom-up (FWD_1 first): the small GEMMs go first, so that the epilogue of FWD_1 has FWD_2's GEMM to hide behind
+    for (auto it = after.rbegin(); it != after.rend(); ++it) ph.push_back(*it);
     // x updates: BWD_{L-1} first (its back-projection is complete: accb), then bottom-up from BWD_0, so that BWD_{L-2},
     // which reads the E_{L-1} produced last, comes last
     for (int base = 0; base < tiles(L - 1); base += span) {
@@ -504,7 +505,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     // that does not fit the LDS falls back below.
     int want_ws = (d->batch >= 4096 && !getenv("MCPC_CT") && !getenv("MCPC_NW")) ? 2 : 0;
     if (const char* env = getenv("MCPC_WS")) { const int v = atoi(env); want_ws = (v == 1 || v == 2) ? v : 0; }
-    if (want_ws) { e->ws = want_ws; e->ct = 32; e->nw = 8; }
+    if (want_ws) { e->ws = want_ws; e->ct = 32; e->nw = want_ws == 2 ? 2 * kWs2Pairs : 8; }
     e->nwg = e->Bpad / e->ct;
     for (int l = 0; l < e->L; ++l) e->npad[l] = pad16(d->sizes[l]);
     e->out_pad = pad16(d->n_out);
@@ -842,7 +843,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     { const char* v = getenv("MCPC_WS_PRIO"); P.ws_prio = v ? atoi(v) : 1; }
     P.err = e->err;
 #ifdef MCPC_STAMPS
-    if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * kMaxWaves * 16); if (rc) return rc; }
+    if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * 2 * kMaxWaves * 16); if (rc) return rc; }
     P.dbg = e->dbg;
 #endif
 
@@ -883,7 +884,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             }
             HIP_TRY(hipEventRecord(e->events[e->events_used].first, stream));
         }
-        if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
+        if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
         else if (e->ws) hipLaunchKernelGGL((mcpc_steps_ws_kernel<2>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
         else if (e->ct == 16) hipLaunchKernelGGL((mcpc_steps_kernel<1, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
         else if (e->nw == 8) hipLaunchKernelGGL((mcpc_steps_kernel<2, 8>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
@@ -898,7 +899,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             static const char* names_ws[16] = {"G other", "G wait dep(E)", "G HEADB gemm", "G gemm", "G wait stage free", "G handoff",
                                                "-", "-", "E other", "E loads+dep", "E wait stage", "E epilogue", "-", "-", "-", "-"};
             static const char* names_ws2[16] = {"G top", "G wait deps", "G HEADB gemm", "G gemm", "G prefetch next", "G store+publish",
-                                                "G entry w/o GEMM", "G acc init", "E other", "E loads", "E wait block", "E epilogue FWD", "E epilogue HEADF", "E epilogue BWD", "-", "-"};
+                                                "(launch, s_memtime)", "(launch, 100 MHz)", "E other", "E loads", "E wait block", "E epilogue FWD", "E epilogue HEADF", "E epilogue BWD", "-", "-"};
             static const char* names[16] = {"FWD prologue", "FWD gemm", "FWD epilogue", "HEADF prologue", "HEADF gemm", "HEADF epilogue",
                                             "HEADB prologue", "HEADB gemm", "HEADB (acc->b)", "BWD prologue", "BWD gemm", "BWD epilogue",
                                             "energy", "barrier", "-", "-"};
@@ -908,6 +909,10 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             double tot = 0, sum[16] = {0}, mx[16] = {0};
             for (size_t w = 0; w < (size_t)e->nwg * e->nw; ++w)
                 for (int i = 0; i < 16; ++i) { sum[i] += (double)h[w * 16 + i]; mx[i] = std::max(mx[i], (double)h[w * 16 + i]); }
+            if (e->ws == 2) {
+                fprintf(stderr, "[stamps] shader clock during the launch = %.3f GHz (s_memtime ticks per 100 MHz wall-clock tick)\n", sum[6] / sum[7] * 0.1);
+                sum[6] = sum[7] = 0;
+            }
             for (int i = 0; i < 16; ++i) tot += sum[i];
             fprintf(stderr, "[stamps] launch t0=%d n=%d: mean cycles/step/wave = %.0f\n", t, n, tot / (e->nwg * e->nw) / n);
             for (int i = 0; i < 16; ++i)

@@ -27,14 +27,35 @@ namespace mcpc {
 #define MCPC_EXP_GEMM_GATE
 #endif
 
-constexpr int kWs2NT = 4;              // unit tiles per pair per table entry of THIS kernel: an entry hands out 16 tiles
-static_assert(kWs2NT == 4, "accb holds 4 tiles per pair");
+#ifndef MCPC_WS2_PAIRS
+#define MCPC_WS2_PAIRS 4
+#endif
+constexpr int kWs2Pairs = MCPC_WS2_PAIRS;          // (G, E) pairs per workgroup: 4 = one GEMM and one epilogue wave per SIMD.
+                                                   // (8 = two of each: measured 99 vs 95 us per step at cfg-M -- the two GEMM waves of a SIMD walk the
+                                                   // same table behind the same dependencies, so they stall together instead of filling each other's gaps)
+constexpr int kWs2NT = 16 / kWs2Pairs;             // unit tiles per pair per table entry: an entry hands out 16 tiles
+constexpr int kWs2Threads = 2 * kWs2Pairs * 64;
+static_assert(kWs2Pairs == 4 || kWs2Pairs == 8, "4 or 8 pairs");
 enum : int { PHF_WS2_HANDOFF = 64 };   // BWD entry without GEMM whose block (accb) still comes from G
 
 struct Ws2Sync {
-    int prog_e[4];
-    int prog_g[4];
+    int prog_e[kWs2Pairs];
+    int prog_g[kWs2Pairs];
 };
+
+// wait until all kWs2Pairs counters are >= need (see ws_wait_all)
+__device__ __forceinline__ void ws2_wait_all(const int* p, int need, int* err, int& dead) {
+    int spin = dead ? kWsSpinLimit : 0;
+    for (; spin < kWsSpinLimit; ++spin) {
+        int m = ws_ld(p);
+#pragma unroll
+        for (int i = 1; i < kWs2Pairs; ++i) m = min(m, ws_ld(p + i));
+        if (m >= need) break;
+        if (MCPC_WS_SLEEP > 0) __builtin_amdgcn_s_sleep(MCPC_WS_SLEEP);
+    }
+    if (spin == kWsSpinLimit) { if (!dead && (threadIdx.x & 63) == 0) atomicOr(err, 1); dead = 1; }
+    MCPC_WS_FENCE(__ATOMIC_ACQUIRE);
+}
 
 __device__ __forceinline__ int ws2_need(int base, int n_ent, int p, int dep) {
     return (dep > p ? base - n_ent : base) + dep + 1;      // an index above the entry's own: previous step
@@ -44,21 +65,20 @@ __device__ __forceinline__ int ws2_need(int base, int n_ent, int p, int dep) {
 // Branch-free: all four tile slots always issue both loads; unused slots repeat slot 0 (L1 hits) and entries without
 // a GEMM read `dummy` (any 2 KiB of valid global memory).  With the loads under `if (i < nt)` hipcc joined every
 // branch behind `s_waitcnt vmcnt(0)`: four serial L2 round trips (~1 k cycles) per table entry.
-__device__ __forceinline__ void ws2_prefetch(const KPhase& ph, int k, int lane, const void* dummy, int& nt_out, int (&aoff)[4],
-                                             f32x4 (&pre0)[4], f32x4 (&pre1)[4]) {
-    const int kk = (k + ph.rot) & 3;
-    const int ntmax = (ph.type == PH_HEADB) ? 4 : kWs2NT;
-    int nt = (ph.ntiles - kk + kWsPairs - 1) / kWsPairs;
-    nt = nt < 0 ? 0 : (nt > ntmax ? ntmax : nt);
+__device__ __forceinline__ void ws2_prefetch(const KPhase& ph, int k, int lane, const void* dummy, int& nt_out, int (&aoff)[kWs2NT],
+                                             f32x4 (&pre0)[kWs2NT], f32x4 (&pre1)[kWs2NT]) {
+    const int kk = (k + ph.rot) & (kWs2Pairs - 1);
+    int nt = (ph.ntiles - kk + kWs2Pairs - 1) / kWs2Pairs;
+    nt = nt < 0 ? 0 : (nt > kWs2NT ? kWs2NT : nt);
     if (!(ph.flags & PHF_WS_GEMM) || ph.nkb <= 0) nt = 0;
     nt_out = nt;
     const bool valid = nt > 0;
     const gf32x4* const A = valid ? (const gf32x4*)ph.A : (const gf32x4*)dummy;
     const int second = (valid && ph.nkb > 1) ? 64 : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < kWs2NT; ++i) {
         const int ii = i < nt ? i : 0;
-        const int off = valid ? (ph.tile0 + kk + kWsPairs * ii) * ph.a_tile_stride + ph.a_off0 : 0;
+        const int off = valid ? (ph.tile0 + kk + kWs2Pairs * ii) * ph.a_tile_stride + ph.a_off0 : 0;
         aoff[i] = off;
         pre0[i] = A[off + lane];
         pre1[i] = A[off + second + lane];
@@ -68,7 +88,7 @@ __device__ __forceinline__ void ws2_prefetch(const KPhase& ph, int k, int lane, 
 template <int ACT>
 __device__ __forceinline__ void ws2_fill_fx(const KLayer& Ly, float* lds, int chain0, int tid, int ct_rows) {
     const int qpr = Ly.npad / 4;                            // quads per row
-    for (int idx = tid; idx < ct_rows * qpr; idx += 512) {
+    for (int idx = tid; idx < ct_rows * qpr; idx += kWs2Threads) {
         const int r = idx / qpr, u0 = 4 * (idx - r * qpr);
         const f32x4 x = ld4s(Ly.x + (size_t)(chain0 + r) * Ly.npad + u0);
         f32x4 fx;
@@ -151,21 +171,21 @@ __device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPha
 }
 
 template <int CTT>
-__global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P) {
+__global__ __launch_bounds__(kWs2Threads) void mcpc_steps_ws2_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NW = kWsPairs, NTW = kWs2NT;
+    constexpr int NW = kWs2Pairs, NTW = kWs2NT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_g = wave8 < 4;
-    const int k = wave8 & 3;                               // pair id
+    const bool is_g = wave8 < kWs2Pairs;                   // waves 0..NW-1 and NW..2NW-1 both spread evenly over the 4 SIMDs
+    const int k = wave8 & (kWs2Pairs - 1);                 // pair id
     const int c = lane & 15, q = lane >> 4;
     const int chain0 = blockIdx.x * (16 * CTT);
     const int L = P.L;
     const int n_ent = P.n_phases;
     Ws2Sync* sync = reinterpret_cast<Ws2Sync*>(lds + P.lds_ws_sync);
     int dead = 0;                                          // set once a bounded wait of this wave ran out
-    if (tid < 8) reinterpret_cast<int*>(sync)[tid] = 0;
+    if (tid < 2 * kWs2Pairs) reinterpret_cast<int*>(sync)[tid] = 0;
     // f(x_l) of the state the launch starts from; afterwards the x updates keep FX_l current
     for (int l = 0; l < L; ++l) {
         const KLayer& Ly = P.layer[l];
@@ -183,17 +203,20 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
         // variables -- with separate "next" copies hipcc put `s_waitcnt vmcnt(0)` + 16 v_mov at the loop latch, i.e.
         // every entry waited out the L2 round trip of the prefetch it had just issued.
         KPhase ph_next = load_phase(P.phases, 0);
-        int nt_next, aoff[4];
-        f32x4 pre0[4], pre1[4];
+        int nt_next, aoff[kWs2NT];
+        f32x4 pre0[kWs2NT], pre1[kWs2NT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { pre0[i] = splat(0.f); pre1[i] = splat(0.f); aoff[i] = 0; }
+        for (int i = 0; i < kWs2NT; ++i) { pre0[i] = splat(0.f); pre1[i] = splat(0.f); aoff[i] = 0; }
         ws2_prefetch(ph_next, k, lane, P.mu1, nt_next, aoff, pre0, pre1);
         STAMP_DECL
+#ifdef MCPC_STAMPS
+        const unsigned long long clk_m0 = mcpc_stamp(), clk_r0 = wall_clock64();
+#endif
         for (int s = 0; s < P.n_steps; ++s) {
             const int base = s * n_ent;
-            f32x4 accb[4][CTT];
+            f32x4 accb[kWs2NT][CTT];                       // back-projection of the read-out error: 16 tiles over the pairs
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < kWs2NT; ++i)
 #pragma unroll
                 for (int ct = 0; ct < CTT; ++ct) accb[i][ct] = splat(0.f);
 #pragma unroll 1
@@ -213,28 +236,20 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
                     for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = splat(0.f);
                 STAMP(0);
                 if (works) {
-                    if (ph.dep_e >= 0) ws_wait_all(sync->prog_e, ws2_need(base, n_ent, p, ph.dep_e), P.err, dead);
+                    if (ph.dep_e >= 0) ws2_wait_all(sync->prog_e, ws2_need(base, n_ent, p, ph.dep_e), P.err, dead);
                     STAMP(1);
                     if (is_headb) {
-                        if (nt > 0 MCPC_EXP_GEMM_GATE) gemm_tiles<4, CTT, NW>(accb, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
+                        if (nt > 0 MCPC_EXP_GEMM_GATE) gemm_tiles<kWs2NT, CTT, NW>(accb, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
                         STAMP(2);
                     } else {
                         if (handoff) {
 #pragma unroll
                             for (int i = 0; i < kWs2NT; ++i)
 #pragma unroll
-                                for (int ct = 0; ct < CTT; ++ct) {
-                                    if constexpr (kWs2NT == 4) acc[i][ct] = accb[i][ct];     // one entry covers all of accb
-                                    else acc[i][ct] = ph.tile0 < NW * kWs2NT ? accb[i][ct] : accb[(i + 2) & 3][ct];
-                                }
+                                for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = accb[i][ct];     // one entry covers all of accb
                         }
-                        if (nt > 0 && ph.nkb > 0 MCPC_EXP_GEMM_GATE) {
-                            int aoff2[kWs2NT];
-                            f32x4 p0[kWs2NT], p1[kWs2NT];
-#pragma unroll
-                            for (int i = 0; i < kWs2NT; ++i) { aoff2[i] = aoff[i]; p0[i] = pre0[i]; p1[i] = pre1[i]; }
-                            gemm_tiles<kWs2NT, CTT, NW>(acc, (const gf32x4*)ph.A, aoff2, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, p0, p1);
-                        }
+                        if (nt > 0 && ph.nkb > 0 MCPC_EXP_GEMM_GATE)
+                            gemm_tiles<kWs2NT, CTT, NW>(acc, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
                         STAMP(3);
                     }
                 }
@@ -244,10 +259,10 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
                 if (stores) {
                     // write-after-read: the rows this block goes to may still be read by GEMMs (dep_g) or epilogues (dep_se)
                     // of entries that share them -- waited for here, behind the GEMM, not in front of it
-                    if (ph.dep_g >= 0) ws_wait_all(sync->prog_g, ws2_need(base, n_ent, p, ph.dep_g), P.err, dead);
-                    if (ph.dep_se >= 0) ws_wait_all(sync->prog_e, ws2_need(base, n_ent, p, ph.dep_se), P.err, dead);
+                    if (ph.dep_g >= 0) ws2_wait_all(sync->prog_g, ws2_need(base, n_ent, p, ph.dep_g), P.err, dead);
+                    if (ph.dep_se >= 0) ws2_wait_all(sync->prog_e, ws2_need(base, n_ent, p, ph.dep_se), P.err, dead);
                     // the block goes where its consumer reads it; E_k finishes it in place
-                    const int kk = (k + ph.rot) & 3;
+                    const int kk = (k + ph.rot) & (NW - 1);
                     int ntw = (ph.ntiles - kk + NW - 1) / NW;
                     ntw = ntw < 0 ? 0 : (ntw > kWs2NT ? kWs2NT : ntw);
                     float* const out = lds + ph.out_lds;
@@ -265,8 +280,10 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
             }
         }
 #ifdef MCPC_STAMPS
+        st_sum[6] = mcpc_stamp() - clk_m0;          // whole launch in s_memtime ticks ...
+        st_sum[7] = wall_clock64() - clk_r0;        // ... and in 100 MHz wall-clock ticks: their ratio is the shader clock
         if (lane == 0)
-            for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * 8 + wave8) * 16 + i] = st_sum[i];
+            for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * (2 * kWs2Pairs) + wave8) * 16 + i] = st_sum[i];
 #endif
         return;
     }
@@ -294,13 +311,13 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
             if (ph.type == PH_ENERGY) {
                 if (do_energy && k == 0) {
                     // every E wave has finished the entries of this step that add to red[]
-                    ws_wait_all(sync->prog_e + 0, base + p, P.err, dead);     // own counter equals base + p already
+                    ws2_wait_all(sync->prog_e + 0, base + p, P.err, dead);    // own counter equals base + p already
                     if (lane <= kMaxLatent) {
                         double v = 0.0;
                         const bool used = (lane < L) || (lane == kMaxLatent && P.has_head);
                         if (used) {
 #pragma unroll
-                            for (int w = 0; w < kWsPairs; ++w) v += (double)red[lane * kMaxWaves + w];
+                            for (int w = 0; w < kWs2Pairs; ++w) v += (double)red[lane * kMaxWaves + w];
                         }
                         const int erow = (P.energy_mode == MCPC_ENERGY_ALL) ? t : 0;
                         P.epart[((size_t)erow * gridDim.x + blockIdx.x) * (kMaxLatent + 1) + lane] = v;
@@ -313,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void mcpc_steps_ws2_kernel(const KParams P)
                 if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
                 continue;
             }
-            const int kk = (k + ph.rot) & 3;
+            const int kk = (k + ph.rot) & (NW - 1);
             int nt = (ph.ntiles - kk + NW - 1) / NW;
             nt = nt < 0 ? 0 : (nt > kWs2NT ? kWs2NT : nt);
             f32x4 acc[kWs2NT][CTT], pa[kWs2NT][CTT], pb[kWs2NT][CTT];
