@@ -212,7 +212,7 @@ def main():
                 "workgroups": q["n_workgroups"], "spill_slots": q["spill_slots"],
             },
             "roofline": {
-                "kernel": "mcpc_steps_kernel",
+                "kernel": q["step_kernel"],
                 "bound": "mfma",
                 "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP32_TFLOPS,

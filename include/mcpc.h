@@ -168,6 +168,8 @@ int mcpc_sync_check(mcpc_engine* e, void* stream);
  * workgroups per step launch, spill slots. */
 int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg, int32_t* n_workgroups,
                int32_t* spill_slots);
+/* Name of the step kernel this engine launches, as it appears in a rocprofv3 kernel trace (static string). */
+const char* mcpc_step_kernel_name(const mcpc_engine* e);
 
 /* Timing hook: HIP-event time (ms) of the step-kernel launches of the most recent mcpc_run
  * whose run had profiling enabled via mcpc_set_profiling(e, 1).  Synchronises the stream. */

@@ -89,6 +89,7 @@ SYMBOLS = {
                                       C.c_void_p, C.c_int, C.c_void_p]),
     "mcpc_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                              C.POINTER(C.c_int32)]),
+    "mcpc_step_kernel_name": (C.c_char_p, [C.c_void_p]),
     "mcpc_sync_check": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mcpc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mcpc_last_step_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32),

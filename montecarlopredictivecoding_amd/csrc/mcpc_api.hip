@@ -1020,6 +1020,14 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
     return MCPC_OK;
 }
 
+const char* mcpc_step_kernel_name(const mcpc_engine* e) {
+    if (!e) return "";
+    if (e->ws == 2) return "mcpc::mcpc_steps_ws2_kernel<2>";
+    if (e->ws) return "mcpc::mcpc_steps_ws_kernel<2>";
+    if (e->ct == 16) return "mcpc::mcpc_steps_kernel<1, 4>";
+    return e->nw == 8 ? "mcpc::mcpc_steps_kernel<2, 8>" : "mcpc::mcpc_steps_kernel<2, 4>";
+}
+
 int mcpc_sync_check(mcpc_engine* e, void* stream_) {
     if (!e) return fail(MCPC_EINVAL, "null engine");
     HIP_TRY(hipSetDevice(e->d.device));

@@ -216,7 +216,8 @@ class Engine:
     def query(self):
         a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         L.check(self._lib.mcpc_query(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        return dict(lds_bytes=a.value, chains_per_wg=b.value, n_workgroups=c.value, spill_slots=d.value)
+        name = self._lib.mcpc_step_kernel_name(self._h).decode()
+        return dict(lds_bytes=a.value, chains_per_wg=b.value, n_workgroups=c.value, spill_slots=d.value, step_kernel=name)
 
     def set_profiling(self, enable: bool):
         L.check(self._lib.mcpc_set_profiling(self._h, 1 if enable else 0))
