@@ -130,8 +130,9 @@ struct KParams {
 // MFMA r pairs A.r with B.r: k-set {k0+4q+r : q=0..3}; four MFMAs cover the 16-deep block.
 // The fragment loads of k-block kb+1 are issued before the MFMAs of k-block kb (two named register
 // sets, loop unrolled by two) so that an L2 round trip hides behind 8*NT MFMAs.
-template <int NT, int NTT, int CTT>
-__device__ __forceinline__ void mfma_block(f32x4 (&acc)[NTT][CTT], const f32x4 (&a)[NT], const f32x4 (&b)[CTT]) {
+template <int NT, int NTT, int CTT, int NA>
+__device__ __forceinline__ void mfma_block(f32x4 (&acc)[NTT][CTT], const f32x4 (&a)[NA], const f32x4 (&b)[CTT]) {
+    static_assert(NA >= NT, "fragment set smaller than the tile count");
     // round-robin over every accumulator of the wave: a given accumulator is touched again only after
     // NT*CTT other MFMAs (the dependent-accumulate latency of v_mfma_f32_16x16x4_f32 is not hidden by
     // alternating just two accumulators)
@@ -252,14 +253,33 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4*
         if constexpr (4 * NT * CTT - 2 * NT - 2 * CTT > 0)                                          \
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * CTT - 2 * NT - 2 * CTT, 0);        \
     } while (0)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { aP[t] = pre0[t]; aQ[t] = pre1[t]; }
     MCPC_LOAD_B(bP, 0);
     if (nkb > 1) MCPC_LOAD_B(bQ, 1);
+    int kb = 0;
+    if (nkb >= 5) {
+        // first round peeled: the prefetched fragments are consumed where they are (copying them into sets P and Q
+        // cost 8*NT v_mov behind an `s_waitcnt vmcnt(0)` at the head of every GEMM)
+        __builtin_amdgcn_sched_barrier(0);
+        MCPC_LOAD_SET(aR, bR, 2);
+        mfma_block<NT, NTT, CTT>(acc, pre0, bP);
+        MCPC_STAGE_SCHED();
+        __builtin_amdgcn_sched_barrier(0);
+        MCPC_LOAD_SET(aP, bP, 3);
+        mfma_block<NT, NTT, CTT>(acc, pre1, bQ);
+        MCPC_STAGE_SCHED();
+        __builtin_amdgcn_sched_barrier(0);
+        MCPC_LOAD_SET(aQ, bQ, 4);
+        mfma_block<NT, NTT, CTT>(acc, aR, bR);
+        MCPC_STAGE_SCHED();
+        __builtin_amdgcn_sched_barrier(0);
+        kb = 3;
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { aP[t] = pre0[t]; aQ[t] = pre1[t]; }
+    }
     // Steady state: NO conditional loads inside the loop.  hipcc counts vmcnt exactly only across
     // straight-line code; a branch around a load makes it fall back to draining every outstanding
     // load before the next MFMA block (guide section 5, "Three .s-level traps" (c)).
-    int kb = 0;
     for (; kb + 5 <= nkb; kb += 3) {
         // sched_barrier pins the stage boundaries: left alone, the machine scheduler sinks the loads next to their
         // consumers and the two-block prefetch distance is lost

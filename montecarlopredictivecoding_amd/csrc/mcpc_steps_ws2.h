@@ -33,7 +33,13 @@ namespace mcpc {
 constexpr int kWs2Pairs = MCPC_WS2_PAIRS;          // (G, E) pairs per workgroup: 4 = one GEMM and one epilogue wave per SIMD.
                                                    // (8 = two of each: measured 99 vs 95 us per step at cfg-M -- the two GEMM waves of a SIMD walk the
                                                    // same table behind the same dependencies, so they stall together instead of filling each other's gaps)
-constexpr int kWs2NT = 16 / kWs2Pairs;             // unit tiles per pair per table entry: an entry hands out 16 tiles
+#ifndef MCPC_WS2_SPAN
+#define MCPC_WS2_SPAN 16
+#endif
+#ifndef MCPC_WS2_WAVES_PER_EU
+#define MCPC_WS2_WAVES_PER_EU 2
+#endif
+constexpr int kWs2NT = MCPC_WS2_SPAN / kWs2Pairs;   // unit tiles per pair per table entry: an entry hands out 16 tiles
 constexpr int kWs2Threads = 2 * kWs2Pairs * 64;
 static_assert(kWs2Pairs == 4 || kWs2Pairs == 8, "4 or 8 pairs");
 enum : int { PHF_WS2_HANDOFF = 64 };   // BWD entry without GEMM whose block (accb) still comes from G
@@ -171,7 +177,7 @@ __device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPha
 }
 
 template <int CTT>
-__global__ __launch_bounds__(kWs2Threads) void mcpc_steps_ws2_kernel(const KParams P) {
+__global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps_ws2_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NW = kWs2Pairs, NTW = kWs2NT;
     const int tid = threadIdx.x;
