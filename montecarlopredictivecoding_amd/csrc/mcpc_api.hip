@@ -60,7 +60,7 @@ struct mcpc_engine {
     int nw = kWaves;                // waves per workgroup: 4, or 8 with 32 chains (two waves per SIMD, one workgroup per CU)
     int ws = 0;                     // 1: wave-specialised kernel with staging slots; 2: in-place variant (4 GEMM + 4 epilogue waves, 32 chains)
     int ws2_chunk = 0, ws2_ring = 0; // in-place variant: read-out tiles per chunk, chunks in the LDS ring
-    int lds_ws_sync = 0, lds_ws_stage = 0;
+    int lds_ws_sync = 0;
     int npad[kMaxLatent]{};
     int out_pad = 0;
     Lin lin[kMaxLatent + 1];
@@ -133,7 +133,7 @@ int plan_lds(mcpc_engine* e) {
     int buf[2] = {0, 0};
     const int CT = e->ct;
     for (int l = 0; l < e->L; ++l) buf[l & 1] = std::max(buf[l & 1], CT * (e->npad[l] + kLdPad));
-    const int eo_floats = e->has_head ? (e->ws ? 2 * CT * (8 * 16 + kLdPad) : CT * (kChunkTiles * 16 + kLdPad)) : 0;
+    const int eo_floats = e->has_head ? CT * (kChunkTiles * 16 + kLdPad) : 0;
     const int eo_buf = ((e->L - 1) & 1) ^ 1;
     buf[eo_buf] = std::max(buf[eo_buf], eo_floats);
     int off = 0;
@@ -144,10 +144,6 @@ int plan_lds(mcpc_engine* e) {
     for (int l = 1; l < e->L; ++l) { e->lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
     e->lds_e[0] = 0;
     e->lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
-    if (e->ws) {
-        e->lds_ws_sync = off; off += 16;
-        e->lds_ws_stage = off; off += kWsPairs * kWsNT * (CT / 16) * 64 * 4;
-    }
     e->lds_bytes = off * (int)sizeof(float);
     if (e->lds_bytes > 160 * 1024)
         return fail(MCPC_ENOMEM, "network needs %d bytes of LDS per workgroup (> 163840): latent widths too large for the fused kernel", e->lds_bytes);
@@ -167,7 +163,6 @@ int plan_lds_ws2(mcpc_engine* e) {
     e->lds_e[0] = 0;
     e->lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
     e->lds_ws_sync = off; off += 16;
-    e->lds_ws_stage = 0;
     // shared region: E_1 .. E_{L-1} stacked | ring
     int e_sum = 0;
     for (int l = 1; l < L; ++l) { e->lds_e[l] = off + e_sum; e_sum += CT * (e->npad[l] + kLdPad); }
@@ -388,84 +383,6 @@ int build_phases(mcpc_engine* e) {
     return 0;
 }
 
-// Schedule of the wave-specialised kernel: 8 tiles per entry (2 per pair), the read-out in chunks of 8 tiles whose
-// back-projection is issued one chunk late (F(c+1) before B(c)) so that the e_o chunk of F(c) is ready when the
-// GEMM waves get to B(c); dependencies are entry indices waited on through the LDS progress counters.
-int build_phases_ws(mcpc_engine* e) {
-    std::vector<KPhase> ph;
-    const int L = e->L;
-    const int span = kWsPairs * kWsNT;       // 8
-    auto tiles = [&](int l) { return e->npad[l] / 16; };
-    std::vector<int> last_fwd(L, -1);        // index of the last entry that produces f(x_l) / e_l
-    auto blank = [&]() { KPhase k{}; k.dep_e = -1; k.dep_g = -1; return k; };
-    for (int base = 0; base < tiles(0); base += span) {
-        KPhase k = blank();
-        k.type = PH_FWD; k.layer = 0; k.tile0 = base; k.ntiles = std::min(span, tiles(0) - base);
-        k.flags = PHF_MU1 | PHF_WS_EPI;
-        last_fwd[0] = (int)ph.size(); ph.push_back(k);
-    }
-    for (int l = 1; l < L; ++l)
-        for (int base = 0; base < tiles(l); base += span) {
-            KPhase k = blank();
-            k.type = PH_FWD; k.layer = l; k.tile0 = base; k.ntiles = std::min(span, tiles(l) - base);
-            k.A = (const f32x4*)e->lin[l].Wf; k.a_tile_stride = tiles(l - 1) * 64; k.nkb = tiles(l - 1);
-            k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
-            k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = last_fwd[l - 1];
-            last_fwd[l] = (int)ph.size(); ph.push_back(k);
-        }
-    if (e->has_head) {
-        const int ht = e->out_pad / 16;
-        const int nch = (ht + span - 1) / span;
-        const int chunk_floats = e->ct * (span * 16 + kLdPad);
-        std::vector<int> idx_f(nch, -1), idx_b(nch, -1);
-        auto add_f = [&](int c) {
-            KPhase f = blank();
-            f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c * span; f.ntiles = std::min(span, ht - c * span);
-            f.A = (const f32x4*)e->lin[L].Wf; f.a_tile_stride = tiles(L - 1) * 64; f.nkb = tiles(L - 1);
-            f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad;
-            f.out_lds = e->lds_eo + (c & 1) * chunk_floats; f.out_ld = span * 16 + kLdPad;
-            f.flags = PHF_WS_GEMM | PHF_WS_EPI; f.dep_e = last_fwd[L - 1];
-            f.dep_g = c >= 2 ? idx_b[c - 2] : -1;       // the chunk buffer is free once B(c-2) has read it
-            idx_f[c] = (int)ph.size(); ph.push_back(f);
-        };
-        auto add_b = [&](int c) {
-            KPhase b = blank();
-            b.type = PH_HEADB; b.layer = L - 1; b.tile0 = 0; b.ntiles = tiles(L - 1);
-            b.A = (const f32x4*)e->lin[L].Wb; b.a_tile_stride = ht * 64; b.a_off0 = c * span * 64;
-            b.nkb = std::min(span, ht - c * span);
-            b.b_lds = e->lds_eo + (c & 1) * chunk_floats; b.ldb = span * 16 + kLdPad;
-            b.flags = PHF_WS_GEMM | PHF_ACC_FROM_B | PHF_ACC_TO_B; b.dep_e = idx_f[c];
-            idx_b[c] = (int)ph.size(); ph.push_back(b);
-        };
-        add_f(0);
-        for (int c = 1; c < nch; ++c) { add_f(c); add_b(c - 1); }
-        add_b(nch - 1);
-    }
-    { KPhase k = blank(); k.type = PH_ENERGY; k.flags = PHF_WS_EPI; ph.push_back(k); }
-    for (int base = 0; base < tiles(L - 1); base += span) {
-        KPhase k = blank();
-        k.type = PH_BWD; k.layer = L - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(L - 1) - base);
-        k.flags = (e->has_head ? PHF_ACC_FROM_B : 0) | PHF_WS_EPI;
-        k.sign = e->has_head ? 1.0f : 0.0f;
-        ph.push_back(k);
-    }
-    for (int l = L - 1; l >= 1; --l)
-        for (int base = 0; base < tiles(l - 1); base += span) {
-            KPhase k = blank();
-            k.type = PH_BWD; k.layer = l - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(l - 1) - base);
-            k.A = (const f32x4*)e->lin[l].Wb; k.a_tile_stride = tiles(l) * 64; k.nkb = tiles(l);
-            k.b_lds = e->lds_e[l]; k.ldb = e->npad[l] + kLdPad; k.sign = -1.0f;
-            k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = last_fwd[l];
-            ph.push_back(k);
-        }
-    int rc = dmalloc(e->phases, ph.size());
-    if (rc) return rc;
-    if (hipMemcpy(e->phases, ph.data(), ph.size() * sizeof(KPhase), hipMemcpyHostToDevice) != hipSuccess)
-        return fail(MCPC_EHIP, "hipMemcpy of the phase table failed");
-    e->n_phases = (int)ph.size();
-    return 0;
-}
-
 }  // namespace
 
 extern "C" {
@@ -500,12 +417,11 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if (const char* env = getenv("MCPC_CT")) { const int v = atoi(env); if (v == 16 || v == 32) e->ct = v; }
     if (const char* env = getenv("MCPC_NW")) { const int v = atoi(env); if (v == 4 || (v == 8 && e->ct == 32)) e->nw = v; }
     // Default schedule: the in-place wave-specialised kernel (32 chains, 4 GEMM + 4 epilogue waves) when the shard is
-    // large enough to give every CU a workgroup, otherwise 16-chain workgroups (twice as many of them).  MCPC_WS=0/1/2
-    // (1 = the older variant with staging slots), MCPC_CT, MCPC_NW override for experiments; a wave-specialised plan
-    // that does not fit the LDS falls back below.
+    // large enough to give every CU a workgroup, otherwise 16-chain workgroups (twice as many of them).  MCPC_WS=0/2, MCPC_CT,
+    // MCPC_NW override for experiments; a wave-specialised plan that does not fit the LDS falls back below.
     int want_ws = (d->batch >= 4096 && !getenv("MCPC_CT") && !getenv("MCPC_NW")) ? 2 : 0;
-    if (const char* env = getenv("MCPC_WS")) { const int v = atoi(env); want_ws = (v == 1 || v == 2) ? v : 0; }
-    if (want_ws) { e->ws = want_ws; e->ct = 32; e->nw = want_ws == 2 ? 2 * kWs2Pairs : 8; }
+    if (const char* env = getenv("MCPC_WS")) want_ws = atoi(env) == 2 ? 2 : 0;
+    if (want_ws) { e->ws = 2; e->ct = 32; e->nw = 2 * kWs2Pairs; }
     e->nwg = e->Bpad / e->ct;
     for (int l = 0; l < e->L; ++l) e->npad[l] = pad16(d->sizes[l]);
     e->out_pad = pad16(d->n_out);
@@ -577,10 +493,10 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     }
     if (e->has_head && (rc = dmalloc(e->spill_eo, (size_t)e->slots * e->Bpad * e->out_pad))) return bail(rc);
 
-    if ((rc = e->ws == 2 ? build_phases_ws2(e) : e->ws ? build_phases_ws(e) : build_phases(e))) return bail(rc);
+    if ((rc = e->ws == 2 ? build_phases_ws2(e) : build_phases(e))) return bail(rc);
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
     if (hipMemset(e->err, 0, sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
-    const void* kfn = e->ws == 2 ? (const void*)mcpc_steps_ws2_kernel<2> : e->ws ? (const void*)mcpc_steps_ws_kernel<2>
+    const void* kfn = e->ws == 2 ? (const void*)mcpc_steps_ws2_kernel<2>
                       : e->ct == 16 ? (const void*)mcpc_steps_kernel<1, 4>
                       : (e->nw == 8 ? (const void*)mcpc_steps_kernel<2, 8> : (const void*)mcpc_steps_kernel<2, 4>);
     hipError_t herr = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
@@ -839,7 +755,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     P.energy_mode = r->energy_mode;
     P.rec_begin = r->rec_begin; P.rec_stride = std::max(r->rec_stride, 1); P.rec_count = r->rec_count;
     P.lds_red = e->lds_red;
-    P.lds_ws_sync = e->lds_ws_sync; P.lds_ws_stage = e->lds_ws_stage;
+    P.lds_ws_sync = e->lds_ws_sync;
     { const char* v = getenv("MCPC_WS_PRIO"); P.ws_prio = v ? atoi(v) : 1; }
     P.err = e->err;
 #ifdef MCPC_STAMPS
@@ -885,7 +801,6 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             HIP_TRY(hipEventRecord(e->events[e->events_used].first, stream));
         }
         if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
-        else if (e->ws) hipLaunchKernelGGL((mcpc_steps_ws_kernel<2>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
         else if (e->ct == 16) hipLaunchKernelGGL((mcpc_steps_kernel<1, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
         else if (e->nw == 8) hipLaunchKernelGGL((mcpc_steps_kernel<2, 8>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
         else hipLaunchKernelGGL((mcpc_steps_kernel<2, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
@@ -896,8 +811,6 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         HIP_TRY(hipGetLastError());
 #ifdef MCPC_STAMPS
         {
-            static const char* names_ws[16] = {"G other", "G wait dep(E)", "G HEADB gemm", "G gemm", "G wait stage free", "G handoff",
-                                               "-", "-", "E other", "E loads+dep", "E wait stage", "E epilogue", "-", "-", "-", "-"};
             static const char* names_ws2[16] = {"G top", "G wait deps", "G HEADB gemm", "G gemm", "G prefetch next", "G store+publish",
                                                 "(launch, s_memtime)", "(launch, 100 MHz)", "E other", "E loads", "E wait block", "E epilogue FWD", "E epilogue HEADF", "E epilogue BWD", "-", "-"};
             static const char* names[16] = {"FWD prologue", "FWD gemm", "FWD epilogue", "HEADF prologue", "HEADF gemm", "HEADF epilogue",
@@ -916,7 +829,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             for (int i = 0; i < 16; ++i) tot += sum[i];
             fprintf(stderr, "[stamps] launch t0=%d n=%d: mean cycles/step/wave = %.0f\n", t, n, tot / (e->nwg * e->nw) / n);
             for (int i = 0; i < 16; ++i)
-                fprintf(stderr, "[stamps]   %-18s %5.1f%%  mean %8.0f  max %8.0f cycles/step\n", (e->ws == 2 ? names_ws2 : e->ws ? names_ws : names)[i], 100.0 * sum[i] / tot,
+                fprintf(stderr, "[stamps]   %-18s %5.1f%%  mean %8.0f  max %8.0f cycles/step\n", (e->ws == 2 ? names_ws2 : names)[i], 100.0 * sum[i] / tot,
                         sum[i] / (e->nwg * e->nw) / n, mx[i] / n);
         }
 #endif
@@ -1023,7 +936,6 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
 const char* mcpc_step_kernel_name(const mcpc_engine* e) {
     if (!e) return "";
     if (e->ws == 2) return "mcpc::mcpc_steps_ws2_kernel<2>";
-    if (e->ws) return "mcpc::mcpc_steps_ws_kernel<2>";
     if (e->ct == 16) return "mcpc::mcpc_steps_kernel<1, 4>";
     return e->nw == 8 ? "mcpc::mcpc_steps_kernel<2, 8>" : "mcpc::mcpc_steps_kernel<2, 4>";
 }

@@ -113,7 +113,7 @@ struct KParams {
     int energy_mode;
     int rec_begin, rec_stride, rec_count;
     int lds_red;           // float offset of the energy reduction scratch [2][kMaxLatent+1][kMaxWaves]
-    int lds_ws_sync, lds_ws_stage;   // wave-specialised kernel: progress counters / accumulator staging slots
+    int lds_ws_sync;                 // wave-specialised kernel: float offset of the progress counters
     int ws_prio;                     // 1: epilogue waves run at raised static priority
     int* err;                        // device error word (bit 0/1: a progress-counter wait ran out)
 #ifdef MCPC_STAMPS
@@ -636,7 +636,6 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, q = lane >> 4;
     const int chain0 = blockIdx.x * (16 * CTT);
     const int L = P.L;
     // fused fast paths of the x update (wave-uniform, fixed for the launch)

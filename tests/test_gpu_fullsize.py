@@ -125,12 +125,12 @@ def test_pc_path_is_bitwise_reproducible_and_descends():
 
 
 def test_workgroup_variants_agree():
-    """16-chain / 32-chain workgroups and the wave-specialised kernel (MCPC_CT, MCPC_NW, MCPC_WS = 1 staged / 2 in-place) are different
+    """16-chain / 32-chain workgroups and the wave-specialised kernel (MCPC_CT, MCPC_NW, MCPC_WS = 2: in-place wave-specialised) are different
     schedules of the same arithmetic."""
     import os
     W, b, y, xs = _problem(640)
     outs = []
-    for ct, nw, ws in (("16", "4", "0"), ("32", "8", "0"), ("32", "4", "0"), ("32", "8", "1"), ("32", "8", "2")):
+    for ct, nw, ws in (("16", "4", "0"), ("32", "8", "0"), ("32", "4", "0"), ("32", "8", "2")):
         os.environ["MCPC_CT"], os.environ["MCPC_NW"], os.environ["MCPC_WS"] = ct, nw, ws
         try:
             eng = _engine(640, W, b, y)
@@ -140,7 +140,7 @@ def test_workgroup_variants_agree():
             eng.close()
         finally:
             del os.environ["MCPC_CT"], os.environ["MCPC_NW"], os.environ["MCPC_WS"]
-    for k in (1, 2, 3, 4):
+    for k in range(1, len(outs)):
         np.testing.assert_allclose(outs[k][0], outs[0][0], rtol=1e-6)      # per-wave fp32 partial sums differ in grouping
         for a, c in zip(outs[k][1], outs[0][1]):
             assert np.array_equal(a, c)            # same k-order per chain: identical fp32 results
