@@ -21,6 +21,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(params=["default", "inplace"], autouse=True)
+def step_kernel(request, monkeypatch):
+    """Run every facade test on the kernel a small shard gets by default and on the in-place wave-specialised kernel
+    large shards get (MCPC_WS=2 is read when an engine is created; a plan that does not fit falls back by itself)."""
+    if request.param == "inplace":
+        monkeypatch.setenv("MCPC_WS", "2")
+    return request.param
+
+
 def _mods():
     import montecarlopredictivecoding_amd.predictive_coding as pc
     import montecarlopredictivecoding_amd.utils.model as um
