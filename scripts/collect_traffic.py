@@ -22,7 +22,7 @@ fetch, nf = total(sys.argv[1], "FETCH_SIZE")
 write, nw = total(sys.argv[2], "WRITE_SIZE")
 steps = int(sys.argv[3])
 out = {
-    "kernel": "mcpc_steps_kernel", "launches": nf, "steps": steps,
+    "kernel": "mcpc_steps*", "launches": nf, "steps": steps,
     "fetch_kib_raw": fetch, "write_kib_raw": write,
     "read_bytes_per_step": 2.0 * fetch * 1024 / steps, "write_bytes_per_step": write * 1024 / steps,
     "bytes_per_step": (2.0 * fetch + write) * 1024 / steps,
