@@ -620,10 +620,15 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
         hipLaunchKernelGGL(mcpc_dw_kernel, dim3((wave_tiles + 3) / 4, ksplit), dim3(256), 0, stream, E, A, e->slab, slab_b,
                            rows, ne, na, rps);
         const float sign = j < e->L ? -1.0f : 1.0f;
-        hipLaunchKernelGGL(mcpc_reduce_slabs_kernel, dim3(grid_for((size_t)ne * na)), dim3(256), 0, stream, e->slab, ln.G,
-                           (size_t)ne * na, ksplit, sign, 1);
-        hipLaunchKernelGGL(mcpc_reduce_slabs_kernel, dim3(grid_for((size_t)ne)), dim3(256), 0, stream, slab_b, ln.Gb,
-                           (size_t)ne, ksplit, sign, 1);
+        // few elements and many splits: 16 waves per 64 elements; otherwise one thread per element
+        auto reduce = [&](const float* slab, float* dst, size_t n) {
+            if (n <= 16384 && ksplit >= 128)
+                hipLaunchKernelGGL(mcpc_reduce_slabs_wide_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, stream, slab, dst, (int)n, ksplit, sign, 1);
+            else
+                hipLaunchKernelGGL(mcpc_reduce_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, stream, slab, dst, n, ksplit, sign, 1);
+        };
+        reduce(e->slab, ln.G, (size_t)ne * na);
+        reduce(slab_b, ln.Gb, (size_t)ne);
     }
     HIP_TRY(hipGetLastError());
     return 0;

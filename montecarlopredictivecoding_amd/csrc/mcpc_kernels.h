@@ -954,6 +954,27 @@ __global__ void mcpc_reduce_slabs_kernel(const float* __restrict__ slab, float* 
     }
 }
 
+// Same contract for short vectors (bias slabs, the 256x32 matrix) and many splits: a block of 16 waves owns 64 consecutive
+// elements, wave w sums the splits w, w+16, ... (coalesced 256-B rows, ascending order) and the 16 partial sums are added
+// in wave order through LDS -- bitwise reproducible, and the ~1000 dependent loads of the form above become ~63.
+__global__ __launch_bounds__(1024) void mcpc_reduce_slabs_wide_kernel(const float* __restrict__ slab, float* __restrict__ dst, int n,
+                                                                     int ksplit, float sign, int accumulate) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (idx < n)
+        for (int k = w; k < ksplit; k += 16) s += __builtin_nontemporal_load(slab + (size_t)k * n + idx);
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && idx < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += part[j][lane];
+        dst[idx] = accumulate ? dst[idx] + sign * t : sign * t;
+    }
+}
+
 // Linear 0 (constant input): G_W0[u][k] = -sum_chain esum[chain][u] * inputs[chain][k];  G_b0[u] = -sum_chain esum[chain][u]
 __global__ void mcpc_dw0_kernel(const float* __restrict__ esum, const float* __restrict__ inputs,
                                 float* __restrict__ gW, float* __restrict__ gb, int B, int n1, int npad1, int n_in,
