@@ -17,5 +17,7 @@ dev = torch.device("cuda", 0)
 W, b, y, xs = make_problem(B, 30, dev)
 eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=dev)
 eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y); eng.load_state(xs)
-eng.run(K, loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=1, energy_mode=L.ENERGY_ALL)
+learn = len(sys.argv) > 3 and sys.argv[3] == "learn"       # learning mode: Hebbian sums over all K steps (flushes overlap)
+eng.run(K, loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=1, energy_mode=L.ENERGY_ALL,
+        **(dict(acc_begin=0, acc_end=K) if learn else {}))
 torch.cuda.synchronize()
