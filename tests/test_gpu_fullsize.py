@@ -66,6 +66,47 @@ def test_full_size_subset_matches_oracle_and_energy_identity():
     eng.close()
 
 
+@pytest.mark.parametrize("act,loss,sizes,batch", [("tanh", "gaussian_mask", [20, 128, 128], 4608),
+                                                  ("relu", "none", [20, 128, 128], 8192),
+                                                  ("tanh", "bernoulli", [30, 256, 256], 4100)])
+def test_other_full_size_modes_match_oracle_on_a_chain_subset(act, loss, sizes, batch):
+    """The kernel large shards get (in-place, wave-specialised) on other shapes and modes of BASELINE.json: the figure_3
+    generation net with no loss (cfg-gen), a masked Gaussian read-out with tanh, a ragged batch -- a chain subset is
+    replayed on the oracle with the NumPy twin of the device noise."""
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    g = torch.Generator().manual_seed(5)
+    dims = [sizes[0]] + sizes + [N_OUT]
+    W = [((torch.rand(dims[j + 1], dims[j], generator=g) * 2 - 1) / dims[j] ** 0.5).to(DEV) for j in range(4)]
+    b = [((torch.rand(dims[j + 1], generator=g) * 2 - 1) / dims[j] ** 0.5).to(DEV) for j in range(4)]
+    y = torch.rand(batch, N_OUT, generator=g).to(DEV) if loss != "bernoulli" else (torch.rand(batch, N_OUT, generator=g) < 0.13).float().to(DEV)
+    xs = [((torch.rand(batch, n, generator=g) * 2 - 1) * 2.0).to(DEV) for n in sizes]
+    a_dev = L.ACT_TANH if act == "tanh" else L.ACT_RELU
+    a_ora = mo.ACT_TANH if act == "tanh" else mo.ACT_RELU
+    eng = Engine(sizes, [a_dev] * 3, sizes[0], N_OUT, batch, device=DEV)
+    assert eng.query()["chains_per_wg"] == 32
+    eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
+    kind = {"gaussian_mask": L.LOSS_GAUSSIAN, "none": L.LOSS_NONE, "bernoulli": L.LOSS_BERNOULLI}[loss]
+    T, lr = 12, 0.05
+    kw = dict(loss_kind=kind, lr=lr)
+    ospec = mo.LossSpec(mo.LOSS_NONE)
+    lo, n = batch - 40, 24                                   # includes the last, partly padded workgroup of the ragged batch
+    if loss == "gaussian_mask":
+        kw.update(loss_var=0.3, mask_start=392)
+        ospec = mo.LossSpec(mo.LOSS_GAUSSIAN, y[lo:lo + n].cpu().numpy(), var=0.3, mask_start=392)
+    elif loss == "bernoulli":
+        ospec = mo.LossSpec(mo.LOSS_BERNOULLI, y[lo:lo + n].cpu().numpy())
+    res, out = _run(eng, xs, T, **kw)
+    en = res.energies.cpu().numpy()
+    np.testing.assert_allclose(en[:, -1], en[:, 0] + en[:, 1:4].sum(1), rtol=1e-12)
+    net = mo.NetSpec(sizes=sizes, acts=[a_ora] * 3, W=[w.cpu().numpy() for w in W], b=[x.cpu().numpy() for x in b])
+    ref = mo.run(net, np.zeros((n, sizes[0]), np.float32), [x[lo:lo + n].cpu().numpy() for x in xs], ospec,
+                 mo.XOpt(mo.OPT_SGD, lr), T, noise=lambda t, l: philox.layer_normals(77, 1000 + t, l, lo, n, sizes[l]))
+    for l in range(3):
+        np.testing.assert_allclose(out[l][lo:lo + n].cpu().numpy(), ref.xs[l], rtol=0, atol=1e-3)
+    eng.close()
+
+
 def test_sharding_and_launch_slicing_do_not_change_trajectories():
     """Global chain ids feed the Philox counter: 6000 chains as one shard, as two shards of 3000, or one shard
     advanced in three launches give bit-identical states; the Hebbian sums agree up to summation order."""
