@@ -416,12 +416,21 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     e->ct = 16; e->nw = 4;
     if (const char* env = getenv("MCPC_CT")) { const int v = atoi(env); if (v == 16 || v == 32) e->ct = v; }
     if (const char* env = getenv("MCPC_NW")) { const int v = atoi(env); if (v == 4 || (v == 8 && e->ct == 32)) e->nw = v; }
-    // Default schedule: the in-place wave-specialised kernel (32 chains, 4 GEMM + 4 epilogue waves) when the shard is
-    // large enough to give every CU a workgroup, otherwise 16-chain workgroups (twice as many of them).  MCPC_WS=0/2, MCPC_CT,
-    // MCPC_NW override for experiments; a wave-specialised plan that does not fit the LDS falls back below.
-    int want_ws = (d->batch >= 4096 && !getenv("MCPC_CT") && !getenv("MCPC_NW")) ? 2 : 0;
-    if (const char* env = getenv("MCPC_WS")) want_ws = atoi(env) == 2 ? 2 : 0;
-    if (want_ws) { e->ws = 2; e->ct = 32; e->nw = 2 * kWs2Pairs; }
+    // Default schedule: the in-place wave-specialised kernel (4 GEMM + 4 epilogue waves), with 16 chains per workgroup while
+    // that still gives every workgroup a CU of its own (B <= 16 x CUs: 55 us per step at B = 4096 on cfg-M's net, against 72
+    // for the barrier kernel and 93 for 32-chain workgroups) and 32 chains per workgroup beyond (93 us at B = 6000, against
+    // 109 for two 16-chain workgroups per CU).  The barrier kernel below remains the fallback when the in-place LDS plan
+    // does not fit.  MCPC_WS=0 forces it (with MCPC_CT / MCPC_NW choosing its variants), MCPC_WS=2 [MCPC_CT=16|32] forces
+    // the in-place kernel -- for A/B runs and for the tests that pin every variant against the same fixtures.
+    int n_cu = 256;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess || n_cu <= 0) n_cu = 256;
+    int want_ws = (!getenv("MCPC_CT") && !getenv("MCPC_NW")) ? 2 : 0;
+    bool ct16 = (d->batch + 15) / 16 <= n_cu;
+    if (const char* env = getenv("MCPC_WS")) {
+        want_ws = atoi(env) == 2 ? 2 : 0;
+        ct16 = getenv("MCPC_CT") && atoi(getenv("MCPC_CT")) == 16;
+    }
+    if (want_ws) { e->ws = 2; e->ct = ct16 ? 16 : 32; e->nw = 2 * kWs2Pairs; }
     e->nwg = e->Bpad / e->ct;
     for (int l = 0; l < e->L; ++l) e->npad[l] = pad16(d->sizes[l]);
     e->out_pad = pad16(d->n_out);
@@ -496,7 +505,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if ((rc = e->ws == 2 ? build_phases_ws2(e) : build_phases(e))) return bail(rc);
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
     if (hipMemset(e->err, 0, sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
-    const void* kfn = e->ws == 2 ? (const void*)mcpc_steps_ws2_kernel<2>
+    const void* kfn = e->ws == 2 ? (e->ct == 16 ? (const void*)mcpc_steps_ws2_kernel<1> : (const void*)mcpc_steps_ws2_kernel<2>)
                       : e->ct == 16 ? (const void*)mcpc_steps_kernel<1, 4>
                       : (e->nw == 8 ? (const void*)mcpc_steps_kernel<2, 8> : (const void*)mcpc_steps_kernel<2, 4>);
     hipError_t herr = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
@@ -805,7 +814,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             }
             HIP_TRY(hipEventRecord(e->events[e->events_used].first, stream));
         }
-        if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
+        if (e->ws == 2 && e->ct == 16) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
+        else if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
         else if (e->ct == 16) hipLaunchKernelGGL((mcpc_steps_kernel<1, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
         else if (e->nw == 8) hipLaunchKernelGGL((mcpc_steps_kernel<2, 8>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
         else hipLaunchKernelGGL((mcpc_steps_kernel<2, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
@@ -940,7 +950,7 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
 
 const char* mcpc_step_kernel_name(const mcpc_engine* e) {
     if (!e) return "";
-    if (e->ws == 2) return "mcpc::mcpc_steps_ws2_kernel<2>";
+    if (e->ws == 2) return e->ct == 16 ? "mcpc::mcpc_steps_ws2_kernel<1>" : "mcpc::mcpc_steps_ws2_kernel<2>";
     if (e->ct == 16) return "mcpc::mcpc_steps_kernel<1, 4>";
     return e->nw == 8 ? "mcpc::mcpc_steps_kernel<2, 8>" : "mcpc::mcpc_steps_kernel<2, 4>";
 }

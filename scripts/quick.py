@@ -7,9 +7,10 @@ from bench import make_problem, SIZES, N_OUT  # noqa: E402
 from montecarlopredictivecoding_amd import _lib as L  # noqa: E402
 from montecarlopredictivecoding_amd.engine import Engine  # noqa: E402
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
 dev = torch.device("cuda", 0)
-W, b, y, xs = make_problem(6000, 30, dev)
-eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, 6000, device=dev)
+W, b, y, xs = make_problem(B, 30, dev)
+eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=dev)
 eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
 base = dict(noise_mode=L.NOISE_PHILOX, loss_kind=L.LOSS_BERNOULLI, energy_mode=L.ENERGY_ALL, lr=0.03, seed=1)
 out = []
@@ -22,4 +23,4 @@ for name, kw in (("inference", {}), ("learning", dict(acc_begin=K // 5, acc_end=
         eng.run(K, **base, **kw)
         torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / K * 1e6)
     out.append(f"{name} {best:6.1f} us/step")
-print(os.path.basename(os.environ.get("MCPC_LIB", "libmcpc.so")), " | ".join(out), flush=True)
+print(os.path.basename(os.environ.get("MCPC_LIB", "libmcpc.so")), f"B={B}", eng.query()["step_kernel"], " | ".join(out), flush=True)

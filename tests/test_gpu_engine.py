@@ -106,14 +106,17 @@ def check_against_golden(g, ci, call, res, eng, xs_final, sched, x_atol=3e-4, e_
             np.testing.assert_allclose(np.abs(dW.astype(np.float64)).sum(), g.get(ci, f"gW{j}_abs"), rtol=2e-4)
 
 
-@pytest.mark.parametrize("kernel", ["default", "inplace"])
+@pytest.mark.parametrize("kernel", ["default", "inplace", "barrier"])
 @pytest.mark.parametrize("name", fixture_names(exclude=("g9_",)))
 def test_engine_matches_reference_golden(name, kernel, monkeypatch):
-    """Every golden fixture on the kernel a small shard gets by default (16-chain workgroups) AND on the in-place
-    wave-specialised kernel that large shards get (forced with MCPC_WS=2), so that every loss / optimizer / noise /
-    schedule variant the reference's fixtures hold is pinned on the kernel the benchmark runs."""
+    """Every golden fixture on the kernel a small shard gets by default (in-place wave-specialised, 16 chains per workgroup),
+    on the 32-chain form large shards get (forced with MCPC_WS=2: the kernel the benchmark runs) AND on the barrier kernel
+    that remains the fallback (MCPC_WS=0): every loss / optimizer / noise / schedule variant the reference's fixtures hold is
+    pinned on all three."""
     if kernel == "inplace":
         monkeypatch.setenv("MCPC_WS", "2")
+    elif kernel == "barrier":
+        monkeypatch.setenv("MCPC_WS", "0")
     g = Golden(name)
     eng = make_engine(g)
     if kernel == "inplace" and eng.query()["chains_per_wg"] != 32:

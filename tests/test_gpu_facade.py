@@ -21,12 +21,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(params=["default", "inplace"], autouse=True)
+@pytest.fixture(params=["default", "inplace", "barrier"], autouse=True)
 def step_kernel(request, monkeypatch):
-    """Run every facade test on the kernel a small shard gets by default and on the in-place wave-specialised kernel
-    large shards get (MCPC_WS=2 is read when an engine is created; a plan that does not fit falls back by itself)."""
+    """Run every facade test on the kernel a small shard gets by default (in-place, 16 chains per workgroup), on the 32-chain
+    form large shards get (MCPC_WS=2) and on the barrier kernel kept as fallback (MCPC_WS=0); the variable is read when an
+    engine is created, and a plan that does not fit falls back by itself."""
     if request.param == "inplace":
         monkeypatch.setenv("MCPC_WS", "2")
+    elif request.param == "barrier":
+        monkeypatch.setenv("MCPC_WS", "0")
     return request.param
 
 

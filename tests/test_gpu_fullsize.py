@@ -166,12 +166,12 @@ def test_pc_path_is_bitwise_reproducible_and_descends():
 
 
 def test_workgroup_variants_agree():
-    """16-chain / 32-chain workgroups and the wave-specialised kernel (MCPC_CT, MCPC_NW, MCPC_WS = 2: in-place wave-specialised) are different
+    """16-chain / 32-chain workgroups and the wave-specialised kernel (MCPC_CT, MCPC_NW, MCPC_WS = 2: in-place wave-specialised, 32 or 16 chains) are different
     schedules of the same arithmetic."""
     import os
     W, b, y, xs = _problem(640)
     outs = []
-    for ct, nw, ws in (("16", "4", "0"), ("32", "8", "0"), ("32", "4", "0"), ("32", "8", "2")):
+    for ct, nw, ws in (("16", "4", "0"), ("32", "8", "0"), ("32", "4", "0"), ("32", "8", "2"), ("16", "8", "2")):
         os.environ["MCPC_CT"], os.environ["MCPC_NW"], os.environ["MCPC_WS"] = ct, nw, ws
         try:
             eng = _engine(640, W, b, y)
