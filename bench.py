@@ -142,7 +142,10 @@ def main():
 
     learning = args.mode == "learning"
     if Wm > 0:
+        # warm-up: W steps in the timed call's shape, and W steps in the other mode (the untimed secondary figure below; an
+        # inference-only call also runs the mixed 32-/16-chain schedule, which a short mixing phase does not reach)
         one_call(Wm, learning)
+        one_call(Wm, not learning)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -221,6 +224,12 @@ def main():
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "hbm_side": {"achieved": bytes_per_step * steps_per_launch / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS,
                              "unit": "GB/s", "bytes_per_chain_step": 7472},
+                # HIP events bracket the launches of the plain schedule only (all Hebbian stretches); inference stretches
+                # run the mixed 32-/16-chain schedule, two concurrent launches per segment that an event would serialise.
+                # Their rate is given from the wall clock of the untimed inference-only call of the same K steps:
+                "inference_call_wall": (None if other is None or learning is False else
+                                        {"us_per_step": 1e6 / other, "achieved": flops_per_step * other / 1e12,
+                                         "unit": "TFLOP/s", "frac": flops_per_step * other / 1e12 / PEAK_FP32_TFLOPS}),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -172,7 +172,10 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
 const char* mcpc_step_kernel_name(const mcpc_engine* e);
 
 /* Timing hook: HIP-event time (ms) of the step-kernel launches of the most recent mcpc_run
- * whose run had profiling enabled via mcpc_set_profiling(e, 1).  Synchronises the stream. */
+ * whose run had profiling enabled via mcpc_set_profiling(e, 1).  Synchronises the stream.
+ * Launches of the mixed 32-/16-chain schedule (inference stretches of a shard that leaves CUs idle)
+ * are not bracketed -- an event between its two concurrent launches would serialise them -- so the
+ * figures cover the launches of the plain schedule (all Hebbian stretches) only. */
 int mcpc_set_profiling(mcpc_engine* e, int enable);
 int mcpc_last_step_kernel_ms(mcpc_engine* e, float* ms, int32_t* n_launches, int64_t* n_steps);
 

@@ -94,11 +94,20 @@ struct mcpc_engine {
     KPhase* phases = nullptr;
     int n_phases = 0;
     int* err = nullptr;             // device error word written by the kernels
+    // Mixed schedule of the in-place kernel (inference stretches of a shard that leaves CUs idle): most pairs of chain tiles
+    // run as 32-chain workgroups, `mix_ns` pairs per segment are split into two 16-chain workgroups on the spare CUs; the
+    // split set rotates, and after `mix_lc` segments every pair has done the same number of steps.
+    bool mix = false;
+    int mix_ns = 0, mix_np = 0, mix_lc = 0, mix_a = 0;    // pairs split / paired per segment, segments per cycle, splits per pair per cycle
+    int* mix_tab = nullptr;          // device: per segment [np pair ids][np rel][2 ns tile ids][2 ns rel]
+    struct Alt { int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_ws_sync = 0, lds_bytes = 0, n_phases = 0; KPhase* phases = nullptr; } alt16;
+    hipStream_t aux2 = nullptr;
+    hipEvent_t ev_mix[2] = {nullptr, nullptr};
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
-    int64_t prof_steps = 0;
+    double prof_steps = 0;          // whole-shard steps covered by the profiled launches (fractional in mixed segments)
 #ifdef MCPC_STAMPS
     unsigned long long* dbg = nullptr;
 #endif
@@ -114,6 +123,9 @@ int free_all(mcpc_engine* e) {
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (int h = 0; h < 2; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
     if (e->aux) { (void)hipStreamDestroy(e->aux); e->aux = nullptr; }
+    if (e->aux2) { (void)hipStreamDestroy(e->aux2); e->aux2 = nullptr; }
+    for (int h = 0; h < 2; ++h) if (e->ev_mix[h]) { (void)hipEventDestroy(e->ev_mix[h]); e->ev_mix[h] = nullptr; }
+    F(e->mix_tab); F(e->alt16.phases);
     e->events.clear();
     return 0;
 }
@@ -385,6 +397,86 @@ int build_phases(mcpc_engine* e) {
 
 }  // namespace
 
+namespace {
+
+// Mixed schedule (see mcpc_engine::mix): a second LDS plan and phase table for 16-chain workgroups, the rotation tables,
+// a second stream.  A shard of `nwg` 32-chain workgroups leaves n_cu - nwg CUs idle; per segment that many pairs of chain
+// tiles are split into two 16-chain workgroups each, which advance ~1.7x as many steps in the same time.  Rotating the
+// split set cyclically over the pairs, every pair has been split equally often after nwg / gcd(nwg, ns) segments.
+// Per-chain results do not depend on the form a step is computed in (the two kernels run the same arithmetic in the same
+// order per chain), so trajectories are bitwise those of the plain schedule; only the grouping of the energy partials moves.
+int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
+    const int npairs = e->nwg;
+    // MCPC_MIX_SLACK CUs are left free (default 0): with every CU taken, a workgroup that finds its CU still draining has
+    // to wait for another workgroup of its XCD to finish, which doubles that segment
+    static const int slack = getenv("MCPC_MIX_SLACK") ? std::max(0, atoi(getenv("MCPC_MIX_SLACK"))) : 0;
+    const int ns = std::min(n_cu - slack - npairs, npairs);     // npairs + ns workgroups (np pairs + 2 ns singles) <= CUs
+    if (ns < 1) return 0;
+    // second plan: swap the primary one out, plan for 16 chains, swap back
+    mcpc_engine::Alt keep;
+    std::copy(e->lds_a, e->lds_a + kMaxLatent, keep.lds_a); std::copy(e->lds_e, e->lds_e + kMaxLatent, keep.lds_e);
+    keep.lds_eo = e->lds_eo; keep.lds_red = e->lds_red; keep.lds_ws_sync = e->lds_ws_sync; keep.lds_bytes = e->lds_bytes;
+    keep.n_phases = e->n_phases; keep.phases = e->phases;
+    const int k_chunk = e->ws2_chunk, k_ring = e->ws2_ring;
+    e->ct = 16; e->phases = nullptr;
+    int rc = plan_lds_ws2(e);
+    if (!rc) rc = build_phases_ws2(e);
+    mcpc_engine::Alt& a = e->alt16;
+    if (!rc) {
+        std::copy(e->lds_a, e->lds_a + kMaxLatent, a.lds_a); std::copy(e->lds_e, e->lds_e + kMaxLatent, a.lds_e);
+        a.lds_eo = e->lds_eo; a.lds_red = e->lds_red; a.lds_ws_sync = e->lds_ws_sync; a.lds_bytes = e->lds_bytes;
+        a.n_phases = e->n_phases; a.phases = e->phases;
+    }
+    e->ct = 32;
+    std::copy(keep.lds_a, keep.lds_a + kMaxLatent, e->lds_a); std::copy(keep.lds_e, keep.lds_e + kMaxLatent, e->lds_e);
+    e->lds_eo = keep.lds_eo; e->lds_red = keep.lds_red; e->lds_ws_sync = keep.lds_ws_sync; e->lds_bytes = keep.lds_bytes;
+    e->n_phases = keep.n_phases; e->phases = keep.phases;
+    e->ws2_chunk = k_chunk; e->ws2_ring = k_ring;
+    if (rc) { g_err.clear(); return 0; }                     // no 16-chain plan: plain schedule only
+    if (hipFuncSetAttribute((const void*)mcpc_steps_ws2_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)mcpc_steps_ws2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes) != hipSuccess)
+        return fail(MCPC_EHIP, "hipFuncSetAttribute failed for the mixed schedule");
+    // rotation tables
+    int g = npairs, h = ns;
+    while (h) { const int t = g % h; g = h; h = t; }
+    const int lc = npairs / g, np = npairs - ns;
+    std::vector<int> cnt_a(npairs, 0), cnt_b(npairs, 0), tab((size_t)lc * (2 * np + 4 * ns));
+    for (int seg = 0; seg < lc; ++seg) {
+        int* row = tab.data() + (size_t)seg * (2 * np + 4 * ns);
+        int* p_id = row, *p_rel = row + np, *s_id = row + 2 * np, *s_rel = row + 2 * np + 2 * ns;
+        std::vector<char> split(npairs, 0);
+        for (int i = 0; i < ns; ++i) split[((size_t)seg * ns + i) % npairs] = 1;
+        int ip = 0, is = 0;
+        for (int j = 0; j < npairs; ++j) {
+            const int rel = cnt_a[j] | (cnt_b[j] << 16);
+            if (split[j]) { s_id[is] = 2 * j; s_rel[is++] = rel; s_id[is] = 2 * j + 1; s_rel[is++] = rel; ++cnt_a[j]; }
+            else { p_id[ip] = j; p_rel[ip++] = rel; ++cnt_b[j]; }
+        }
+    }
+    for (int j = 1; j < npairs; ++j)
+        if (cnt_a[j] != cnt_a[0] || cnt_b[j] != cnt_b[0]) return fail(MCPC_EINVAL, "mixed schedule: rotation is not balanced");
+    if ((rc = dmalloc(e->mix_tab, tab.size()))) return rc;
+    if (hipMemcpy(e->mix_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(MCPC_EHIP, "hipMemcpy of the mixed-schedule tables failed");
+    if (hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking) != hipSuccess) return fail(MCPC_EHIP, "hipStreamCreateWithFlags failed");
+    for (int i = 0; i < 2; ++i)
+        if (hipEventCreateWithFlags(&e->ev_mix[i], hipEventDisableTiming) != hipSuccess) return fail(MCPC_EHIP, "hipEventCreate failed");
+    e->mix_ns = ns; e->mix_np = np; e->mix_lc = lc; e->mix_a = cnt_a[0];
+    // first use of a stream maps a hardware queue and sizes its scratch: pay for that here, not inside a timed call
+    // (an empty network: no layers, no steps -- the kernel reads its first table entry, requests nothing and exits)
+    {
+        KParams P0{};
+        P0.phases = a.phases; P0.n_phases = a.n_phases; P0.mu1 = e->mu1; P0.err = e->err;
+        P0.wg_list = e->mix_tab; P0.wg_rel = e->mix_tab; P0.lds_ws_sync = a.lds_ws_sync; P0.lds_red = a.lds_red;
+        hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1, true>), dim3(1), dim3(kWs2Threads), a.lds_bytes, e->aux2, P0);
+        if (hipStreamSynchronize(e->aux2) != hipSuccess) return fail(MCPC_EHIP, "warm-up launch of the mixed schedule failed");
+    }
+    e->mix = true;
+    return 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 int mcpc_abi_version(void) { return MCPC_ABI_VERSION; }
@@ -510,6 +602,9 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
                       : (e->nw == 8 ? (const void*)mcpc_steps_kernel<2, 8> : (const void*)mcpc_steps_kernel<2, 4>);
     hipError_t herr = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
     if (herr != hipSuccess) return bail(fail(MCPC_EHIP, "hipFuncSetAttribute(%d bytes LDS) failed: %s", e->lds_bytes, hipGetErrorString(herr)));
+    if (e->ws == 2 && e->ct == 32 && e->nwg < n_cu && !getenv("MCPC_NO_MIX")) {
+        if ((rc = setup_mixed_schedule(e, n_cu))) return bail(rc);
+    }
     *out = e;
     return MCPC_OK;
 }
@@ -705,9 +800,12 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             }
     }
     const size_t erows = r->energy_mode == MCPC_ENERGY_ALL ? (size_t)r->T : 1;
+    // energy partials per step: one slot per workgroup; the in-place kernel indexes them by 16-chain tile (its 32- and 16-chain
+    // forms can then serve the same call)
+    const size_t eslots = e->ws == 2 ? (size_t)e->Bpad / 16 : (size_t)e->nwg;
     if (r->energy_mode != MCPC_ENERGY_NONE && erows > e->epart_rows) {
         if (e->epart) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(e->epart)); e->epart = nullptr; }
-        int rc = dmalloc(e->epart, erows * e->nwg * (kMaxLatent + 1));
+        int rc = dmalloc(e->epart, erows * eslots * (kMaxLatent + 1));
         if (rc) return rc;
         e->epart_rows = erows;
     }
@@ -755,7 +853,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         H.mask_start = r->loss_kind == MCPC_LOSS_NONE ? 0 : r->mask_start;
         H.lds_eo = e->lds_eo; H.ld = kChunkTiles * 16 + kLdPad;
     }
-    P.mu1 = e->mu1; P.epart = e->epart;
+    P.mu1 = e->mu1; P.epart = e->epart; P.epart_slots = (int)eslots;
     P.phases = e->phases; P.n_phases = e->n_phases;
     { const char* v = getenv("MCPC_STAGGER"); P.stagger_cycles = v ? atoi(v) : 0; }
     P.L = e->L; P.has_head = e->has_head; P.B = e->d.batch; P.Bpad = e->Bpad; P.T = r->T;
@@ -785,11 +883,72 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     const int end = r->t_begin + r->n_steps;
     const bool overlap = e->aux != nullptr;
     int half = 0;
+    // mixed schedule for stretches without Hebbian accumulation: the fused SGD (+- Philox) update only -- Adam coefficients
+    // and external noise are indexed by the step within a launch, which differs between the units of a mixed launch
+    bool mix_ok = e->mix && r->update_x && r->xopt_kind == MCPC_XOPT_SGD && r->noise_mode != MCPC_NOISE_EXTERNAL;
+#ifdef MCPC_STAMPS
+    mix_ok = false;
+#endif
+    auto prof_begin = [&]() -> int {
+        if (!e->profiling) return 0;
+        if (e->events_used == e->events.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(MCPC_EHIP, "hipEventCreate failed");
+            e->events.emplace_back(a, b);
+        }
+        return hipEventRecord(e->events[e->events_used].first, stream) == hipSuccess ? 0 : fail(MCPC_EHIP, "hipEventRecord failed");
+    };
+    auto prof_end = [&](double steps) -> int {
+        if (!e->profiling) return 0;
+        if (hipEventRecord(e->events[e->events_used].second, stream) != hipSuccess) return fail(MCPC_EHIP, "hipEventRecord failed");
+        ++e->events_used; e->prof_steps += steps;
+        return 0;
+    };
+    // one cycle of the mixed schedule: mix_lc segments, in each of them the paired units do `mp` steps as 32-chain workgroups
+    // on `stream` while the split ones do `ms` steps as 16-chain workgroups on `aux2`; afterwards every unit is at t0 + cyc
+    auto run_mixed_cycle = [&](int t0, int mp, int ms) -> int {
+        KParams P2 = P, P1 = P;
+        for (int l = 0; l < e->L; ++l) { P1.layer[l].lds_a = e->alt16.lds_a[l]; P1.layer[l].lds_e = e->alt16.lds_e[l]; }
+        P1.head.lds_eo = e->alt16.lds_eo; P1.lds_red = e->alt16.lds_red; P1.lds_ws_sync = e->alt16.lds_ws_sync;
+        P1.phases = e->alt16.phases; P1.n_phases = e->alt16.n_phases;
+        P2.t0 = P1.t0 = t0; P2.spill_t0 = P1.spill_t0 = t0;
+        P2.n_steps = mp; P1.n_steps = ms;
+        P2.mix_mp = P1.mix_mp = mp; P2.mix_ms = P1.mix_ms = ms;
+        const int np = e->mix_np, ns = e->mix_ns;
+        for (int seg = 0; seg < e->mix_lc; ++seg) {
+            const int* row = e->mix_tab + (size_t)seg * (2 * np + 4 * ns);
+            P2.wg_list = row; P2.wg_rel = row + np;
+            P1.wg_list = row + 2 * np; P1.wg_rel = row + 2 * np + 2 * ns;
+            HIP_TRY(hipEventRecord(e->ev_mix[0], stream));
+            HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_mix[0], 0));
+            hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1, true>), dim3(2 * ns), dim3(kWs2Threads), e->alt16.lds_bytes, e->aux2, P1);
+            HIP_TRY(hipEventRecord(e->ev_mix[1], e->aux2));
+            // (no timing events here: an event record between the two launches costs the segment its concurrency -- 110 instead
+            // of 79 us per step; mcpc_last_step_kernel_ms therefore covers the launches of the plain schedule only)
+            hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2, true>), dim3(np), dim3(kWs2Threads), e->lds_bytes, stream, P2);
+            HIP_TRY(hipStreamWaitEvent(stream, e->ev_mix[1], 0));
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
     while (t < end) {
         const bool in_acc = t >= acc_b && t < acc_e;
         int n;
         if (in_acc) n = std::min(std::min(end, acc_e) - t, e->half_slots);
         else n = (t < acc_b ? std::min(end, acc_b) : end) - t;
+        if (!in_acc && mix_ok) {
+            // as many whole cycles as fit, long segments first; what is left runs on the plain schedule below
+            static const int kSeg[2][2] = {{10, 17}, {3, 5}};          // (paired, split) steps per segment: ~ the 1 : 1.7 rate ratio
+            for (const auto& sg : kSeg) {
+                const int cyc = e->mix_a * sg[1] + (e->mix_lc - e->mix_a) * sg[0];
+                while (n >= cyc) {
+                    const int rc = run_mixed_cycle(t, sg[0], sg[1]);
+                    if (rc) return rc;
+                    t += cyc; n -= cyc;
+                }
+            }
+            if (n == 0) continue;
+        }
         const int slot0 = in_acc && overlap ? half * e->half_slots : 0;
         P.t0 = t; P.n_steps = n; P.spill_t0 = t;
         const int s0 = t - r->t_begin;
@@ -806,23 +965,13 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             // this half of the ring may still be read by the flush that was started two segments ago
             if (overlap && e->flush_pending[half]) { HIP_TRY(hipStreamWaitEvent(stream, e->ev_flush[half], 0)); e->flush_pending[half] = false; }
         }
-        if (e->profiling) {
-            if (e->events_used == e->events.size()) {
-                hipEvent_t a, b;
-                HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-                e->events.emplace_back(a, b);
-            }
-            HIP_TRY(hipEventRecord(e->events[e->events_used].first, stream));
-        }
+        { const int rc = prof_begin(); if (rc) return rc; }
         if (e->ws == 2 && e->ct == 16) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
         else if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
         else if (e->ct == 16) hipLaunchKernelGGL((mcpc_steps_kernel<1, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
         else if (e->nw == 8) hipLaunchKernelGGL((mcpc_steps_kernel<2, 8>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
         else hipLaunchKernelGGL((mcpc_steps_kernel<2, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
-        if (e->profiling) {
-            HIP_TRY(hipEventRecord(e->events[e->events_used].second, stream));
-            ++e->events_used; e->prof_steps += n;
-        }
+        { const int rc = prof_end((double)n); if (rc) return rc; }
         HIP_TRY(hipGetLastError());
 #ifdef MCPC_STAMPS
         {
@@ -878,10 +1027,10 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     }
     if (r->energy_mode == MCPC_ENERGY_ALL) {
         hipLaunchKernelGGL(mcpc_energy_reduce_kernel, dim3((r->n_steps + 63) / 64), dim3(64), 0, stream,
-                           e->epart + (size_t)r->t_begin * e->nwg * (kMaxLatent + 1),
-                           r->energies_out + (size_t)r->t_begin * kEnergyCols, r->n_steps, e->nwg, e->L);
+                           e->epart + (size_t)r->t_begin * eslots * (kMaxLatent + 1),
+                           r->energies_out + (size_t)r->t_begin * kEnergyCols, r->n_steps, (int)eslots, e->L);
     } else if (r->energy_mode == MCPC_ENERGY_LAST && end == r->T) {
-        hipLaunchKernelGGL(mcpc_energy_reduce_kernel, dim3(1), dim3(64), 0, stream, e->epart, r->energies_out, 1, e->nwg, e->L);
+        hipLaunchKernelGGL(mcpc_energy_reduce_kernel, dim3(1), dim3(64), 0, stream, e->epart, r->energies_out, 1, (int)eslots, e->L);
     }
     HIP_TRY(hipGetLastError());
     return MCPC_OK;
@@ -950,7 +1099,8 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
 
 const char* mcpc_step_kernel_name(const mcpc_engine* e) {
     if (!e) return "";
-    if (e->ws == 2) return e->ct == 16 ? "mcpc::mcpc_steps_ws2_kernel<1>" : "mcpc::mcpc_steps_ws2_kernel<2>";
+    if (e->ws == 2 && e->mix) return "mcpc::mcpc_steps_ws2_kernel<2, false> (Hebbian stretches) / <2, true> + <1, true> (mixed schedule of inference stretches)";
+    if (e->ws == 2) return e->ct == 16 ? "mcpc::mcpc_steps_ws2_kernel<1, false>" : "mcpc::mcpc_steps_ws2_kernel<2, false>";
     if (e->ct == 16) return "mcpc::mcpc_steps_kernel<1, 4>";
     return e->nw == 8 ? "mcpc::mcpc_steps_kernel<2, 8>" : "mcpc::mcpc_steps_kernel<2, 4>";
 }
@@ -988,7 +1138,7 @@ int mcpc_last_step_kernel_ms(mcpc_engine* e, float* ms, int32_t* n_launches, int
     }
     *ms = total;
     if (n_launches) *n_launches = (int32_t)e->events_used;
-    if (n_steps) *n_steps = e->prof_steps;
+    if (n_steps) *n_steps = (int64_t)std::llround(e->prof_steps);
     return MCPC_OK;
 }
 

@@ -116,6 +116,12 @@ struct KParams {
     int lds_ws_sync;                 // wave-specialised kernel: float offset of the progress counters
     int ws_prio;                     // 1: epilogue waves run at raised static priority
     int* err;                        // device error word (bit 0/1: a progress-counter wait ran out)
+    // in-place kernel, mixed schedule (32- and 16-chain workgroups side by side, see run_mixed in mcpc_api.hip): workgroup ->
+    // unit (pair of chain tiles or single tile) and the steps that unit has already done since the cycle began
+    const int* wg_list;              // [gridDim.x] unit index, or null: unit = blockIdx.x
+    const int* wg_rel;               // [gridDim.x] (segments of the cycle spent split) | (segments spent paired) << 16, or null
+    int mix_ms, mix_mp;              // steps per segment of a split / a paired unit
+    int epart_slots;                 // in-place kernel: energy partials are indexed by 16-chain tile, this many per row
 #ifdef MCPC_STAMPS
     unsigned long long* dbg;   // diagnostic build only: [nwg][kWaves][16] cycle sums per phase
 #endif

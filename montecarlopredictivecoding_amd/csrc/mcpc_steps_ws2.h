@@ -176,7 +176,8 @@ __device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPha
     return lsum;
 }
 
-template <int CTT>
+// MIX: the launch is one half of a mixed schedule -- workgroups take their unit and their step offset from lists
+template <int CTT, bool MIX = false>
 __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps_ws2_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NW = kWs2Pairs, NTW = kWs2NT;
@@ -186,7 +187,11 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
     const bool is_g = wave8 < kWs2Pairs;                   // waves 0..NW-1 and NW..2NW-1 both spread evenly over the 4 SIMDs
     const int k = wave8 & (kWs2Pairs - 1);                 // pair id
     const int c = lane & 15, q = lane >> 4;
-    const int chain0 = blockIdx.x * (16 * CTT);
+    const int unit = MIX ? P.wg_list[blockIdx.x] : (int)blockIdx.x;             // pair of chain tiles (CTT = 2) or single tile
+    const int chain0 = unit * (16 * CTT);
+    // first step of this unit in this launch (mixed schedule: units advance at different rates, so each carries the number
+    // of segments it has spent split / paired since the cycle began)
+    const int t_first = MIX ? P.t0 + (P.wg_rel[blockIdx.x] & 0xffff) * P.mix_ms + (P.wg_rel[blockIdx.x] >> 16) * P.mix_mp : P.t0;
     const int L = P.L;
     const int n_ent = P.n_phases;
     Ws2Sync* sync = reinterpret_cast<Ws2Sync*>(lds + P.lds_ws_sync);
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                              ? (P.noise_mode == MCPC_NOISE_PHILOX ? 2 : (P.noise_mode == MCPC_NOISE_NONE ? 1 : 0)) : 0;
     STAMP_DECL
     for (int s = 0; s < P.n_steps; ++s) {
-        const int t = P.t0 + s;
+        const int t = t_first + s;
         const int base = s * n_ent;
         const bool do_energy = (P.energy_mode == MCPC_ENERGY_ALL) || (P.energy_mode == MCPC_ENERGY_LAST && t == P.T - 1);
         const int slot = (t >= P.acc_begin && t < P.acc_end) ? (t - P.spill_t0) : -1;
@@ -326,7 +331,12 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                             for (int w = 0; w < kWs2Pairs; ++w) v += (double)red[lane * kMaxWaves + w];
                         }
                         const int erow = (P.energy_mode == MCPC_ENERGY_ALL) ? t : 0;
-                        P.epart[((size_t)erow * gridDim.x + blockIdx.x) * (kMaxLatent + 1) + lane] = v;
+                        // a row has one slot per 16-chain tile: a 32-chain workgroup writes the slot of its first tile and
+                        // clears the other (a 16-chain workgroup may have written it for the same step of an earlier call)
+                        double* const ep = P.epart + (MIX ? (size_t)erow * P.epart_slots + (size_t)unit * CTT
+                                                          : (size_t)erow * (CTT * gridDim.x) + (size_t)blockIdx.x * CTT) * (kMaxLatent + 1) + lane;
+                        ep[0] = v;
+                        if (CTT == 2) ep[kMaxLatent + 1] = 0.0;
                     }
                 }
                 if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);

@@ -14,6 +14,8 @@ eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=dev)
 eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
 base = dict(noise_mode=L.NOISE_PHILOX, loss_kind=L.LOSS_BERNOULLI, energy_mode=L.ENERGY_ALL, lr=0.03, seed=1)
 out = []
+if os.environ.get("QUICK_PROFILE"): eng.set_profiling(True)
+if os.environ.get("QUICK_REC"): base.update(rec_begin=0, rec_stride=100, rec_count=(K + 99) // 100, rec_x=True)
 for name, kw in (("inference", {}), ("learning", dict(acc_begin=K // 5, acc_end=K))):
     best = 1e9
     for rep in range(3):
@@ -23,4 +25,12 @@ for name, kw in (("inference", {}), ("learning", dict(acc_begin=K // 5, acc_end=
         eng.run(K, **base, **kw)
         torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / K * 1e6)
     out.append(f"{name} {best:6.1f} us/step")
+    if os.environ.get("QUICK_MIXING"):       # the bench's call shape: K/5 mixing + 4K/5 sampling, every repetition reported
+        ts = []
+        for rep in range(4):
+            eng.load_state(xs)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            eng.run(K, **base, **(dict(acc_begin=K // 5, acc_end=K) if name == "learning" else {}))
+            torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / K * 1e6)
+        out.append("reps " + " ".join(f"{v:.1f}" for v in ts))
 print(os.path.basename(os.environ.get("MCPC_LIB", "libmcpc.so")), f"B={B}", eng.query()["step_kernel"], " | ".join(out), flush=True)

@@ -140,6 +140,30 @@ def test_sharding_and_launch_slicing_do_not_change_trajectories():
     np.testing.assert_allclose(flat_sum, flat_whole, rtol=1e-4, atol=1e-6 * np.abs(flat_whole).max())
 
 
+def test_mixed_schedule_matches_plain_schedule(monkeypatch):
+    """Inference stretches of a shard that leaves CUs idle run on the mixed schedule (most chain-tile pairs as 32-chain
+    workgroups, a rotating subset split into 16-chain workgroups on the spare CUs).  Per chain the arithmetic is the same, so
+    trajectories and records must be BITWISE those of the plain schedule; energies regroup fp32 partial sums."""
+    W, b, y, xs = _problem()
+    T = 420                                    # two short cycles (175 steps each) + 70 plain steps; mixing then Hebbian steps
+    outs = []
+    for no_mix in (False, True):
+        if no_mix:
+            monkeypatch.setenv("MCPC_NO_MIX", "1")
+        eng = _engine(B, W, b, y)
+        res, out = _run(eng, xs, T, acc_begin=400, acc_end=T, rec_begin=0, rec_stride=60, rec_count=7, rec_x=True)
+        outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x],
+                     eng.read_param_grads_flat().cpu().numpy()))
+        eng.close()
+    for a, c in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, c)
+    for a, c in zip(outs[0][2], outs[1][2]):
+        assert np.array_equal(a, c)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-6)
+    assert np.all(np.isfinite(outs[0][0]))
+    assert np.array_equal(outs[0][3], outs[1][3])            # the Hebbian steps run on the plain schedule either way
+
+
 def test_pc_path_is_bitwise_reproducible_and_descends():
     """cfg-PC: noise = 0.  Two runs are bit-identical (energies included: fixed-order reductions, no float atomics),
     and F = loss + energy never increases under plain gradient descent with a small step."""
