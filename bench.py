@@ -15,8 +15,10 @@ Workload (cfg-M of BASELINE.md section 4, synthetic data, random-init weights):
     single all-reduce of the 276 146-float gradient bucket.  One "step" = one Langevin step of all
     6000 chains of a GPU; value = N*K / wall time.
 
-Everything in the timed region goes through the C ABI (libmcpc.so); inputs are resident in HBM
-before the clock starts.  `cpu_baseline` (rank 0, N = 1 only) times oracle/torch_port.py -- a
+The mixing steps of the call (no Hebbian sums) run the library's mixed 32-/16-chain schedule on all
+256 CUs, the sampling steps the plain schedule with the Hebbian flush on the idle CUs (DESIGN.md
+section 4).  Everything in the timed region goes through the C ABI (libmcpc.so); inputs are resident
+in HBM before the clock starts.  `cpu_baseline` (rank 0, N = 1 only) times oracle/torch_port.py -- a
 torch-autograd port with the reference's op mix -- on the host cores for a bounded sample.
 """
 import argparse
