@@ -883,9 +883,9 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     const int end = r->t_begin + r->n_steps;
     const bool overlap = e->aux != nullptr;
     int half = 0;
-    // mixed schedule for stretches without Hebbian accumulation: the fused SGD (+- Philox) update only -- Adam coefficients
-    // and external noise are indexed by the step within a launch, which differs between the units of a mixed launch
-    bool mix_ok = e->mix && r->update_x && r->xopt_kind == MCPC_XOPT_SGD && r->noise_mode != MCPC_NOISE_EXTERNAL;
+    // mixed schedule for stretches without Hebbian accumulation (fused x updates only: the gradients-only mode hands dF/dx to
+    // the caller after every single step)
+    bool mix_ok = e->mix && r->update_x;
 #ifdef MCPC_STAMPS
     mix_ok = false;
 #endif
@@ -912,6 +912,11 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         P1.head.lds_eo = e->alt16.lds_eo; P1.lds_red = e->alt16.lds_red; P1.lds_ws_sync = e->alt16.lds_ws_sync;
         P1.phases = e->alt16.phases; P1.n_phases = e->alt16.n_phases;
         P2.t0 = P1.t0 = t0; P2.spill_t0 = P1.spill_t0 = t0;
+        // per-step tables start at the cycle's first step; a unit indexes them with its own step minus t0
+        const int s0 = t0 - r->t_begin;
+        P2.adam_coef = P1.adam_coef = r->xopt_kind == MCPC_XOPT_ADAM ? e->adam_coef + 2 * (size_t)s0 : nullptr;
+        if (r->noise_mode == MCPC_NOISE_EXTERNAL)
+            for (int l = 0; l < e->L; ++l) P2.layer[l].ext_noise = P1.layer[l].ext_noise = r->ext_noise[l] + (size_t)s0 * e->d.batch * e->d.sizes[l];
         P2.n_steps = mp; P1.n_steps = ms;
         P2.mix_mp = P1.mix_mp = mp; P2.mix_ms = P1.mix_ms = ms;
         const int np = e->mix_np, ns = e->mix_ns;
@@ -925,7 +930,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             HIP_TRY(hipEventRecord(e->ev_mix[1], e->aux2));
             // (no timing events here: an event record between the two launches costs the segment its concurrency -- 110 instead
             // of 79 us per step; mcpc_last_step_kernel_ms therefore covers the launches of the plain schedule only)
-            hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2, true>), dim3(np), dim3(kWs2Threads), e->lds_bytes, stream, P2);
+            if (np > 0)        // (a shard with no more pairs than spare CUs runs entirely split)
+                hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2, true>), dim3(np), dim3(kWs2Threads), e->lds_bytes, stream, P2);
             HIP_TRY(hipStreamWaitEvent(stream, e->ev_mix[1], 0));
         }
         HIP_TRY(hipGetLastError());

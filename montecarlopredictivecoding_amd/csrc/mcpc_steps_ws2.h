@@ -306,6 +306,7 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
     STAMP_DECL
     for (int s = 0; s < P.n_steps; ++s) {
         const int t = t_first + s;
+        const int s_tab = MIX ? t - P.t0 : s;          // index into per-step tables (Adam coefficients, external noise): they start at P.t0
         const int base = s * n_ent;
         const bool do_energy = (P.energy_mode == MCPC_ENERGY_ALL) || (P.energy_mode == MCPC_ENERGY_LAST && t == P.T - 1);
         const int slot = (t >= P.acc_begin && t < P.acc_end) ? (t - P.spill_t0) : -1;
@@ -385,9 +386,9 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                 float lsum = ws2_headf_epilogue<CTT, NW, NTW>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx, do_energy);
                 if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[kMaxLatent * kMaxWaves + k] += lsum; }
             } else if (ph.type == PH_BWD) {
-                if (Ly.act == MCPC_ACT_RELU) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_RELU, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s, t, upd_mode, lds);
-                else if (Ly.act == MCPC_ACT_TANH) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_TANH, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s, t, upd_mode, lds);
-                else bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_IDENTITY, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s, t, upd_mode, lds);
+                if (Ly.act == MCPC_ACT_RELU) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_RELU, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s_tab, t, upd_mode, lds);
+                else if (Ly.act == MCPC_ACT_TANH) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_TANH, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s_tab, t, upd_mode, lds);
+                else bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_IDENTITY, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s_tab, t, upd_mode, lds);
             }
             if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
             if (ph.type == PH_FWD) STAMP(11); else if (ph.type == PH_HEADF) STAMP(12); else STAMP(13);

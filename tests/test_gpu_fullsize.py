@@ -164,6 +164,33 @@ def test_mixed_schedule_matches_plain_schedule(monkeypatch):
     assert np.array_equal(outs[0][3], outs[1][3])            # the Hebbian steps run on the plain schedule either way
 
 
+@pytest.mark.parametrize("mode", ["adam", "external_noise"])
+def test_mixed_schedule_with_per_step_tables(mode, monkeypatch):
+    """Adam's bias-correction table and injected noise are indexed by the step, which differs between the units of a mixed
+    launch: the MAP warm-up (Adam on x, no noise) and an SGD run with external normals must still be bitwise those of the
+    plain schedule."""
+    from montecarlopredictivecoding_amd import _lib as L
+    W, b, y, xs = _problem()
+    xs_small = [x * 0.1 for x in xs]
+    T = 200                                    # one short cycle (175 steps) + 25 plain steps
+    kw = dict(noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.05)
+    if mode == "external_noise":
+        g = torch.Generator().manual_seed(3)
+        ext = [torch.randn(T, B, n, generator=g).to(DEV) for n in SIZES]
+        kw = dict(noise_mode=L.NOISE_EXTERNAL, ext_noise=ext, noise_var=2.0, lr=0.03)
+    outs = []
+    for no_mix in (False, True):
+        if no_mix:
+            monkeypatch.setenv("MCPC_NO_MIX", "1")
+        eng = _engine(B, W, b, y)
+        res, out = _run(eng, xs_small, T, **kw)
+        outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out]))
+        eng.close()
+    for a, c in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, c)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-6)
+
+
 def test_pc_path_is_bitwise_reproducible_and_descends():
     """cfg-PC: noise = 0.  Two runs are bit-identical (energies included: fixed-order reductions, no float atomics),
     and F = loss + energy never increases under plain gradient descent with a small step."""
