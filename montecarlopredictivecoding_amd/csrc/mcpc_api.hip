@@ -944,7 +944,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         else n = (t < acc_b ? std::min(end, acc_b) : end) - t;
         if (!in_acc && mix_ok) {
             // as many whole cycles as fit, long segments first; what is left runs on the plain schedule below
-            static const int kSeg[2][2] = {{10, 17}, {3, 5}};          // (paired, split) steps per segment: ~ the 1 : 1.7 rate ratio
+            static const int kSeg[3][2] = {{20, 34}, {10, 17}, {3, 5}};   // (paired, split) steps per segment: ~ the 1 : 1.7 rate ratio
             for (const auto& sg : kSeg) {
                 const int cyc = e->mix_a * sg[1] + (e->mix_lc - e->mix_a) * sg[0];
                 while (n >= cyc) {
