@@ -77,7 +77,7 @@ typedef struct mcpc_net_desc {
     int32_t n_out;                       /* width of the read-out Linear; 0 = model ends with a PCLayer */
     int32_t batch;                       /* chains held by this engine (local shard) */
     int32_t device;                      /* HIP device ordinal */
-    int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default (2 GiB) */
+    int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default (6 GiB, at most 128 steps) */
 } mcpc_net_desc;
 
 /* One train_on_batch call (or a slice of it).  Steps are numbered 0..T-1 inside the call. */

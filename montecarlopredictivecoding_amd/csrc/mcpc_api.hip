@@ -571,8 +571,10 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     for (int l = 0; l < e->L; ++l) per_slot += (size_t)e->Bpad * e->npad[l] * (l >= 1 ? 2 : 1);
     per_slot += (size_t)e->Bpad * e->out_pad;
     per_slot *= sizeof(float);
-    int64_t budget = d->spill_budget_bytes > 0 ? d->spill_budget_bytes : (int64_t)2 << 30;
-    int slot_cap = 64;
+    // defaults sized for 288 GB of HBM per GPU: a 6 GiB ring (128 steps of cfg-M) gives Hebbian segments of 64 steps; a
+    // 2 GiB ring (segments of 24) cost 1.4 % more per step
+    int64_t budget = d->spill_budget_bytes > 0 ? d->spill_budget_bytes : (int64_t)6 << 30;
+    int slot_cap = 128;
     if (const char* v = getenv("MCPC_SPILL_GB")) budget = (int64_t)atoi(v) << 30;      // tuning knobs
     if (const char* v = getenv("MCPC_SLOT_CAP")) slot_cap = std::max(2, atoi(v));
     e->slots = (int)std::max<int64_t>(1, std::min<int64_t>(slot_cap, budget / (int64_t)per_slot));
