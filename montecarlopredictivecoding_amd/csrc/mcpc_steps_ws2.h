@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
 #ifdef MCPC_STAMPS
         st_sum[6] = mcpc_stamp() - clk_m0;          // whole launch in s_memtime ticks ...
         st_sum[7] = wall_clock64() - clk_r0;        // ... and in 100 MHz wall-clock ticks: their ratio is the shader clock
-        if (lane == 0)
+        if (lane == 0 && P.dbg != nullptr)      // (null in the warm-up launch of setup_mixed_schedule)
             for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * (2 * kWs2Pairs) + wave8) * 16 + i] = st_sum[i];
 #endif
         return;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
         }
     }
 #ifdef MCPC_STAMPS
-    if (lane == 0)
+    if (lane == 0 && P.dbg != nullptr)
         for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * 8 + wave8) * 16 + i] = st_sum[i];
 #endif
 }
