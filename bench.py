@@ -1,25 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- Langevin steps/s of the MCPC hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 5000 --warmup 500
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (cfg-M of BASELINE.md section 4, synthetic data, random-init weights):
+One bench "step" = ONE CALL of the hot path in BASELINE.json's configuration (cfg-M of BASELINE.md section 4):
     net 30-256-256-784 ReLU (get_model shape, reference utils/model.py:47-69), Bernoulli read-out,
     6000 chains PER GPU (weak scaling; global chain ids keep the Philox noise shard-invariant),
-    SGD-x lr 0.03 + Langevin noise var 2, one call of K steps = K/5 mixing + 4K/5 sampling with the
-    Hebbian sums accumulated over the sampling steps (the reference's training=True call,
-    utils/training_evaluation.py:43-56), loss + layer energies recorded every step, x recorded
-    every 100 steps, followed by the normalised parameter-gradient read-out and -- for N > 1 -- the
-    single all-reduce of the 276 146-float gradient bucket.  One "step" = one Langevin step of all
-    6000 chains of a GPU; value = N*K / wall time.
+    SGD-x lr 0.03 + Langevin noise var 2, T = 5000 Langevin steps = 1000 mixing + 4000 sampling (--T overrides it),
+    loss + layer energies recorded every step, x recorded every 100 steps; synthetic data, random-init weights.
+--warmup W untimed calls, then --steps K timed calls (barrier + synchronize on both sides, max over ranks):
 
-The mixing steps of the call (no Hebbian sums) run the library's mixed 32-/16-chain schedule on all
-256 CUs, the sampling steps the plain schedule with the Hebbian flush on the idle CUs (DESIGN.md
-section 4).  Everything in the timed region goes through the C ABI (libmcpc.so); inputs are resident
-in HBM before the clock starts.  `cpu_baseline` (rank 0, N = 1 only) times oracle/torch_port.py -- a
-torch-autograd port with the reference's op mix -- on the host cores for a bounded sample.
+    learning call (the timed `value`): the reference's training=True call (utils/training_evaluation.py:43-56) -- Hebbian
+        sums accumulated over the 4000 sampling steps, the normalised parameter-gradient read-out and, for N > 1, the
+        single RCCL all-reduce of the 276 146-float gradient bucket.   value = N * K * T / wall   [Langevin steps/s]
+    inference-only call (training=False, no Hebbian sums): K calls timed the same way right after, reported beside it.
+
+Everything in the timed region goes through the C ABI (libmcpc.so); inputs are resident in HBM before the clock starts.
+`roofline` is computed from HIP events the library records on its launch stream (mcpc_set_profiling) during the timed
+calls.  `cpu_baseline` (rank 0, N = 1 only) times oracle/torch_port.py -- a torch-autograd port with the reference's op
+mix -- on the host cores for a bounded sample.
 """
 import argparse
 import json
@@ -88,12 +89,13 @@ def cpu_baseline(batch, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5000)
-    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=10, help="timed CALLS of T Langevin steps each")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up calls (of each kind)")
+    ap.add_argument("--T", type=int, default=5000, help="Langevin steps per call: T/5 mixing + 4T/5 sampling (BASELINE: 5000)")
     ap.add_argument("--batch", type=int, default=6000, help="chains per GPU")
-    ap.add_argument("--mode", choices=["learning", "inference"], default="learning")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed second call (other mode); used for clean PMC passes")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the inference-only calls (clean PMC passes of the learning call)")
+    ap.add_argument("--only-inference", action="store_true", help="time inference-only calls only (clean PMC passes of the mixed schedule)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -116,7 +118,8 @@ def main():
     from montecarlopredictivecoding_amd import _lib as L
     from montecarlopredictivecoding_amd.engine import Engine
 
-    B, K, Wm = args.batch, args.steps, args.warmup
+    B, K, Wm, T = args.batch, max(args.steps, 1), max(args.warmup, 0), args.T
+    mixing = T // 5
     W, b, y, xs = make_problem(B, 30 + rank, device)
     # parameters are replicated: every rank uses rank 0's draw
     W0, b0, _, _ = make_problem(8, 30, device)
@@ -128,9 +131,7 @@ def main():
     eng.load_state(xs)
     n_params = eng.param_count()
 
-    def one_call(T, learning, profile=False):
-        mixing = T // 5
-        eng.set_profiling(profile)
+    def one_call(learning):
         res = eng.run(T, loss_kind=L.LOSS_BERNOULLI, xopt=L.XOPT_SGD, lr=0.03,
                       noise_mode=L.NOISE_PHILOX, noise_var=2.0, seed=30, chain_base=rank * B,
                       acc_begin=mixing if learning else 0, acc_end=T if learning else 0,
@@ -142,60 +143,87 @@ def main():
                 dist.all_reduce(flat)           # RCCL over xGMI: the path's only exchange step
         return res, flat
 
-    learning = args.mode == "learning"
-    if Wm > 0:
-        # warm-up: W steps in the timed call's shape, and W steps in the other mode (the untimed secondary figure below; an
-        # inference-only call also runs the mixed 32-/16-chain schedule, which a short mixing phase does not reach)
-        one_call(Wm, learning)
-        one_call(Wm, not learning)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res, flat = one_call(K, learning, profile=True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    eng.sync_check()          # raises if a kernel reported a device-side fault during the timed call
-    kernel_ms, n_launch, n_ksteps = eng.last_step_kernel_ms()
-    eng.set_profiling(False)
-    if dist is not None:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(learning, n_calls):
+        """n_calls back-to-back calls between barrier + synchronize on both sides; max over ranks."""
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.set_profiling(True)
+        t0 = time.perf_counter()
+        for _ in range(n_calls):
+            res, flat = one_call(learning)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng.sync_check()          # raises if a kernel reported a device-side fault during the timed calls
+        plain = eng.last_step_kernel_ms()
+        mixed = eng.last_mixed_cycles_ms()
+        eng.set_profiling(False)
+        if dist is not None:
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, res, plain, mixed
 
-    # secondary figure: the same K steps without Hebbian accumulation (training=False call)
-    other = None
-    if world == 1 and not args.no_secondary:
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        one_call(K, not learning)
-        torch.cuda.synchronize()
-        other = K / (time.perf_counter() - t1)
+    for _ in range(Wm):
+        if not args.only_inference:
+            one_call(True)
+        if not args.no_secondary:
+            one_call(False)
+    dt_learn = res = plain_l = mixed_l = None
+    if not args.only_inference:
+        dt_learn, res, plain_l, mixed_l = timed(True, K)
+    dt_inf = plain_i = mixed_i = None
+    if not args.no_secondary or args.only_inference:
+        dt_inf, res_i, plain_i, mixed_i = timed(False, K)
+        res = res if res is not None else res_i
+    primary_learning = dt_learn is not None
+    dt = dt_learn if primary_learning else dt_inf
 
     en = res.energies[-1].tolist()
     finite = all(abs(v) < 1e30 for v in en)
     if rank == 0:
         q = eng.query()
-        avg_launch_s = kernel_ms * 1e-3 / max(n_launch, 1)
-        steps_per_launch = n_ksteps / max(n_launch, 1)
-        flops_per_step = 4.0 * S_MACS * B    # algorithmic FLOPs: forward 2*S + back-projection 2*S per chain-step
-        achieved_tf = flops_per_step * steps_per_launch / avg_launch_s / 1e12
+        flops_inf = 4.0 * S_MACS * B     # algorithmic FLOPs per step: forward 2*S + back-projection 2*S per chain (BASELINE.md s5)
+        flops_heb = 2.0 * S_MACS * B     # + the Hebbian sums e^T f(x) on accumulating steps
         bytes_per_step = 7472.0 * B
-        # HBM traffic of K1 per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled as the
-        # gfx950 guide prescribes, + WRITE_SIZE), stored by scripts/collect_traffic.py; None if never collected
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and B == 6000 and learning:
-            with open(tpath) as fh:
-                tj = json.load(fh)
-            traffic = tj.get("bytes_per_step", 0.0) * steps_per_launch if tj.get("bytes_per_step") else None
+
+        def kernel_line(kernel, ms_n_steps, flops_per_step, note):
+            ms, n, steps = ms_n_steps
+            if not n or not steps:
+                return None
+            avg_s = ms * 1e-3 / n
+            spl = steps / n
+            tf = flops_per_step * spl / avg_s / 1e12
+            return {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / PEAK_FP32_TFLOPS, "traffic": None, "brackets": n, "steps_per_bracket": spl,
+                    "avg_bracket_ms": avg_s * 1e3, "us_per_step": avg_s / spl * 1e6,
+                    "flop_per_chain_step": 4 * S_MACS,
+                    "hbm_side": {"achieved": bytes_per_step * spl / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "bytes_per_chain_step": 7472},
+                    "note": note}
+
+        # the dominant kernel of the timed call: the step kernel's launches of the plain schedule (in a learning call: the
+        # 4000 Hebbian steps, one launch per half of the spill ring); algorithmic FLOPs of the STEP kernel = 4 S per chain-step
+        # (the Hebbian GEMMs are a different kernel).  `traffic` (PMC) cannot be measured inside this run: the per-launch
+        # figure of the same command lives in profiles/ (README there) and is deliberately not copied into this line.
+        roof = kernel_line("mcpc::mcpc_steps_ws2_kernel<2, false>" if q["chains_per_wg"] == 32 else q["step_kernel"],
+                           plain_l if primary_learning else plain_i, flops_inf,
+                           "HIP events around every launch of the plain schedule during the timed "
+                           + ("learning calls (Hebbian stretches; the Hebbian GEMMs of the previous segment run beside it)" if primary_learning else "inference calls"))
+        mixed_line = kernel_line("mcpc::mcpc_steps_ws2_kernel<2, true> + <1, true> (mixed 32-/16-chain schedule, two concurrent launches per segment)",
+                                 mixed_i if mixed_i is not None else mixed_l, flops_inf,
+                                 "HIP events around whole cycles of the mixed schedule during the timed "
+                                 + ("inference-only calls" if mixed_i is not None else "learning calls (mixing steps)"))
+        if roof is None:
+            roof = mixed_line
+        value = world * K * T / dt
         out = {
             "metric": "Langevin inference steps/sec (whole node), MNIST MCPC 784-256-256-30, batch 6000",
-            "value": world * K / dt,
+            "value": value,
             "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt / K * 1e3,
@@ -205,35 +233,32 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "cfg-M: 30-256-256-784 ReLU MCPC, Bernoulli read-out, %d chains/GPU, SGD-x lr 0.03 + Langevin noise var 2, "
-                            "one call of K steps (K/5 mixing + 4K/5 sampling), energies every step, x every 100 steps" % B,
-                "mode": args.mode + (" (Hebbian sums over the sampling steps + normalised grad read-out"
-                                     + (" + 1 RCCL all-reduce of %d floats" % n_params if world > 1 else "") + ")" if learning else ""),
+                "workload": "cfg-M: 30-256-256-784 ReLU MCPC, Bernoulli read-out, %d chains/GPU, SGD-x lr 0.03 + Langevin noise var 2; "
+                            "bench step = ONE CALL of T = %d Langevin steps (%d mixing + %d sampling), energies every step, "
+                            "x every 100 steps; value = n_gpus * steps * T / wall; ms_per_step = ms per call" % (B, T, mixing, T - mixing),
+                "T": T, "mixing": mixing, "sampling": T - mixing, "steps_are": "calls",
+                "timed_mode": ("learning call: Hebbian sums over the sampling steps + normalised grad read-out"
+                               + (" + 1 RCCL all-reduce of %d floats" % n_params if world > 1 else "")) if primary_learning
+                              else "inference-only call (no Hebbian sums)",
+                "us_per_langevin_step": dt / (K * T) * 1e6,
                 "chains_total": B * world,
-                "chain_steps_per_s": world * K * B / dt,
+                "chain_steps_per_s": value * B,
                 "final_overall_energy": en[-1], "finite": finite,
-                ("inference_only_steps_per_s" if learning else "learning_steps_per_s"): other,
+                "inference_only": None if (dt_inf is None or not primary_learning) else {
+                    "steps_per_s": world * K * T / dt_inf, "us_per_langevin_step": dt_inf / (K * T) * 1e6, "calls": K,
+                    "achieved_tflops": flops_inf * K * T / dt_inf / 1e12,
+                    "frac_of_fp32_peak": flops_inf * K * T / dt_inf / 1e12 / PEAK_FP32_TFLOPS},
+                "learning_call_flops": None if not primary_learning else {
+                    "achieved_tflops": (flops_inf * T + flops_heb * (T - mixing)) * K / dt / 1e12,
+                    "frac_of_fp32_peak": (flops_inf * T + flops_heb * (T - mixing)) * K / dt / 1e12 / PEAK_FP32_TFLOPS,
+                    "note": "whole call, wall clock: 4S per chain-step + 2S on the accumulating steps"},
                 "lds_bytes_per_wg": q["lds_bytes"], "chains_per_wg": q["chains_per_wg"],
                 "workgroups": q["n_workgroups"], "spill_slots": q["spill_slots"],
             },
-            "roofline": {
-                "kernel": q["step_kernel"],
-                "bound": "mfma",
-                "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tf / PEAK_FP32_TFLOPS,
-                "traffic": traffic,
-                "flop_per_chain_step": 4 * S_MACS, "launches": n_launch, "steps_per_launch": steps_per_launch,
-                "avg_launch_ms": avg_launch_s * 1e3,
-                "hbm_side": {"achieved": bytes_per_step * steps_per_launch / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "bytes_per_chain_step": 7472},
-                # HIP events bracket the launches of the plain schedule only (all Hebbian stretches); inference stretches
-                # run the mixed 32-/16-chain schedule, two concurrent launches per segment that an event would serialise.
-                # Their rate is given from the wall clock of the untimed inference-only call of the same K steps:
-                "inference_call_wall": (None if other is None or learning is False else
-                                        {"us_per_step": 1e6 / other, "achieved": flops_per_step * other / 1e12,
-                                         "unit": "TFLOP/s", "frac": flops_per_step * other / 1e12 / PEAK_FP32_TFLOPS}),
-            },
+            "roofline": roof,
         }
+        if mixed_line is not None and mixed_line is not roof:
+            out["roofline"]["mixed_schedule"] = mixed_line
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, args.cpu_budget)
             out["config"]["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]

@@ -18,8 +18,11 @@
  * code; mcpc_last_error() returns a human-readable message for the calling thread.
  *
  * Threading: one engine per (device, stream); an engine is not re-entrant.  All launches are
- * asynchronous on the given stream; the only host-synchronising calls are mcpc_create /
- * mcpc_destroy (allocation), mcpc_sync_check and mcpc_last_step_kernel_ms.
+ * asynchronous on the given stream; the only calls that wait for the device are mcpc_create /
+ * mcpc_destroy, mcpc_sync_check and mcpc_last_step_kernel_ms.  mcpc_run never waits for the stream:
+ * buffers that have to grow (per-step tables, energy partials) are replaced and the old ones retired
+ * until mcpc_destroy; the first run that accumulates Hebbian sums allocates the spill ring (hipMalloc).
+ * The library reads no environment variables.
  */
 #ifndef MCPC_H
 #define MCPC_H
@@ -30,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MCPC_ABI_VERSION 1
+#define MCPC_ABI_VERSION 2
 #define MCPC_MAX_LATENT 6
 
 /* status codes */
@@ -78,6 +81,11 @@ typedef struct mcpc_net_desc {
     int32_t batch;                       /* chains held by this engine (local shard) */
     int32_t device;                      /* HIP device ordinal */
     int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default (6 GiB, at most 128 steps) */
+    const char* tuning;                  /* NULL, or developer overrides of the schedule heuristics as "key=value,key=value"
+                                          * (parsed once by mcpc_create, not kept): ws=0|2 step kernel (barrier / in-place),
+                                          * ct=16|32 chains per workgroup, nw=4|8, no_mix=1, no_overlap=1, slot_cap=N,
+                                          * spill_gb=N, mix_slack=N, dw_ksplit=N, ws_prio=0|1|2, stagger=N.  Unknown keys are
+                                          * an error.  Used by A/B runs and by the tests that pin every kernel variant. */
 } mcpc_net_desc;
 
 /* One train_on_batch call (or a slice of it).  Steps are numbered 0..T-1 inside the call. */
@@ -141,6 +149,11 @@ int mcpc_bind_target(mcpc_engine* e, const float* target, void* stream);
 int mcpc_load_state(mcpc_engine* e, const float* const* x, void* stream);
 int mcpc_store_state(mcpc_engine* e, float* const* x, void* stream);
 
+/* Adam moments of the x optimizer after a run with MCPC_XOPT_ADAM: exp_avg / exp_avg_sq per latent layer, [batch][n_l]
+ * (torch.optim.Adam's per-parameter state, reference pc_trainer.py:465-475).  Lets the caller keep optimizer_x alive across
+ * calls the way the reference does when neither reset flag of train_on_batch is set (pc_trainer.py:742-752). */
+int mcpc_store_adam_state(mcpc_engine* e, float* const* m, float* const* v, void* stream);
+
 /* The hot loop: n_steps iterations of pc_trainer.py:712-981 (+ random_step) on every chain. */
 int mcpc_run(mcpc_engine* e, const mcpc_run_desc* run, void* stream);
 
@@ -171,13 +184,16 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
 /* Name of the step kernel this engine launches, as it appears in a rocprofv3 kernel trace (static string). */
 const char* mcpc_step_kernel_name(const mcpc_engine* e);
 
-/* Timing hook: HIP-event time (ms) of the step-kernel launches of the most recent mcpc_run
- * whose run had profiling enabled via mcpc_set_profiling(e, 1).  Synchronises the stream.
- * Launches of the mixed 32-/16-chain schedule (inference stretches of a shard that leaves CUs idle)
- * are not bracketed -- an event between its two concurrent launches would serialise them -- so the
- * figures cover the launches of the plain schedule (all Hebbian stretches) only. */
+/* Timing hooks.  While profiling is enabled (mcpc_set_profiling(e, 1); every call of it resets the tallies), mcpc_run
+ * brackets with HIP events on its stream
+ *   - every step-kernel launch of the plain schedule (all Hebbian stretches, plain inference stretches), and
+ *   - every whole CYCLE of the mixed 32-/16-chain schedule (inference stretches of a shard that leaves CUs idle): its two
+ *     concurrent launches per segment cannot be bracketed one by one -- an event between them would serialise them.
+ * The two getters synchronise on the recorded events and return the summed time, the number of brackets and the
+ * whole-shard steps they cover, accumulated over all runs since profiling was enabled. */
 int mcpc_set_profiling(mcpc_engine* e, int enable);
 int mcpc_last_step_kernel_ms(mcpc_engine* e, float* ms, int32_t* n_launches, int64_t* n_steps);
+int mcpc_last_mixed_cycles_ms(mcpc_engine* e, float* ms, int32_t* n_cycles, int64_t* n_steps);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import os
 
 MAX_LATENT = 6
 ENERGY_COLS = MAX_LATENT + 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_IDENTITY, ACT_RELU, ACT_TANH = 0, 1, 2
 LOSS_NONE, LOSS_GAUSSIAN, LOSS_BERNOULLI = 0, 1, 2
@@ -45,6 +45,7 @@ class NetDesc(C.Structure):
         ("batch", C.c_int32),
         ("device", C.c_int32),
         ("spill_budget_bytes", C.c_int64),
+        ("tuning", C.c_char_p),
     ]
 
 
@@ -81,6 +82,7 @@ SYMBOLS = {
     "mcpc_bind_target": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mcpc_load_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
     "mcpc_store_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]),
+    "mcpc_store_adam_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
     "mcpc_run": (C.c_int, [C.c_void_p, C.POINTER(RunDesc), C.c_void_p]),
     "mcpc_read_param_grads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "mcpc_read_param_grads_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
@@ -94,6 +96,8 @@ SYMBOLS = {
     "mcpc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mcpc_last_step_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                            C.POINTER(C.c_int64)]),
+    "mcpc_last_mixed_cycles_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int64)]),
 }
 
 _lib = None

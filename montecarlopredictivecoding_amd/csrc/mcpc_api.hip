@@ -49,12 +49,63 @@ struct Lin {
     float* G = nullptr;            // gradient sums [out_pad][g_ld]
     float* Gb = nullptr;           // [out_pad]
     int g_ld = 0;
+    size_t slab_off = 0;           // float offset of this Linear's split-K slabs inside mcpc_engine::slab
+    size_t slab_floats = 0;        // ... and their size
 };
+
+// Developer overrides of the schedule heuristics, parsed ONCE from mcpc_net_desc::tuning at mcpc_create
+// ("key=value,key=value"; see include/mcpc.h).  The library itself reads no environment variables.
+struct Knobs {
+    int ws = -1;              // -1: automatic; 0: barrier kernel; 2: in-place wave-specialised kernel
+    int ct = 0;               // 0: automatic; 16 / 32 chains per workgroup
+    int nw = 0;               // 0: automatic; 4 / 8 waves per workgroup of the barrier kernel
+    int no_mix = 0;           // 1: never use the mixed 32-/16-chain schedule
+    int no_overlap = 0;       // 1: Hebbian flushes run serially on the caller's stream (one ring segment = the whole ring)
+    int slot_cap = 128;       // upper bound on spill-ring slots
+    int spill_gb = 0;         // > 0: spill budget in GiB (overrides mcpc_net_desc::spill_budget_bytes)
+    int mix_slack = 0;        // CUs the mixed schedule leaves free
+    int dw_ksplit = 0;        // > 0: K-splits per workgroup tile of the Hebbian GEMM (0: one wave of workgroups over the chip)
+    int ws_prio = 1;          // 1: epilogue waves at raised priority, 2: GEMM waves, 0: neither
+    int stagger = 0;          // barrier kernel: start cycles of the second workgroup of a CU
+};
+
+int parse_tuning(const char* str, Knobs& k) {
+    if (!str) return 0;
+    std::string s(str);
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t end = s.find_first_of(",;", pos);
+        if (end == std::string::npos) end = s.size();
+        std::string item = s.substr(pos, end - pos);
+        pos = end + 1;
+        while (!item.empty() && item.front() == ' ') item.erase(item.begin());
+        while (!item.empty() && item.back() == ' ') item.pop_back();
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        const std::string key = item.substr(0, eq);
+        const int val = eq == std::string::npos ? 1 : atoi(item.c_str() + eq + 1);
+        struct { const char* name; int* dst; } table[] = {
+            {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
+            {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"dw_ksplit", &k.dw_ksplit},
+            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}};
+        bool found = false;
+        for (auto& t : table)
+            if (key == t.name) { *t.dst = val; found = true; }
+        if (!found) return fail(MCPC_EINVAL, "unknown tuning key '%s' in mcpc_net_desc::tuning", key.c_str());
+    }
+    if (k.ws != -1 && k.ws != 0 && k.ws != 2) return fail(MCPC_EINVAL, "tuning ws=%d: 0 (barrier kernel) or 2 (in-place kernel)", k.ws);
+    if (k.ct != 0 && k.ct != 16 && k.ct != 32) return fail(MCPC_EINVAL, "tuning ct=%d: 16 or 32", k.ct);
+    if (k.nw != 0 && k.nw != 4 && k.nw != 8) return fail(MCPC_EINVAL, "tuning nw=%d: 4 or 8", k.nw);
+    if (k.slot_cap < 2) k.slot_cap = 2;
+    if (k.mix_slack < 0) k.mix_slack = 0;
+    return 0;
+}
 
 }  // namespace
 
 struct mcpc_engine {
     mcpc_net_desc d{};
+    Knobs knobs;
     int L = 0, Bpad = 0, nwg = 0, has_head = 0;
     int ct = kCT;                   // chains per workgroup: 16 (two workgroups per CU) or 32
     int nw = kWaves;                // waves per workgroup: 4, or 8 with 32 chains (two waves per SIMD, one workgroup per CU)
@@ -85,9 +136,14 @@ struct mcpc_engine {
     // energies
     double* epart = nullptr;
     size_t epart_rows = 0;
-    float* adam_coef = nullptr;
+    float* adam_coef = nullptr;     // device table [steps][2]; grown buffers are retired, never freed under a running kernel
     size_t adam_cap = 0;
-    std::vector<float> adam_host;
+    float* adam_host[2] = {nullptr, nullptr};     // pinned staging, double-buffered: a run never rewrites a table whose upload may be pending
+    size_t adam_host_cap[2] = {0, 0};
+    hipEvent_t adam_ev[2] = {nullptr, nullptr};
+    int adam_next = 0;
+    std::vector<void*> retired;     // device buffers replaced by larger ones while earlier launches may still read them: freed at destroy
+    bool spill_ready = false;       // the spill ring, its stream/events and the slabs exist (allocated by the first accumulating run)
     // LDS plan
     int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_bytes = 0;
     // per-step phase table (device copy)
@@ -105,9 +161,9 @@ struct mcpc_engine {
     hipEvent_t ev_mix[2] = {nullptr, nullptr};
     // profiling
     bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    size_t events_used = 0;
-    double prof_steps = 0;          // whole-shard steps covered by the profiled launches (fractional in mixed segments)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events, events_mix;   // plain-schedule launches / whole mixed cycles
+    size_t events_used = 0, events_mix_used = 0;
+    double prof_steps = 0, prof_steps_mix = 0;      // whole-shard steps covered by the bracketed launches / cycles
 #ifdef MCPC_STAMPS
     unsigned long long* dbg = nullptr;
 #endif
@@ -121,11 +177,19 @@ int free_all(mcpc_engine* e) {
     F(e->e0sum); F(e->mu1); F(e->ypad); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err);
     for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : e->events_mix) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    e->events_mix.clear();
     for (int h = 0; h < 2; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
     if (e->aux) { (void)hipStreamDestroy(e->aux); e->aux = nullptr; }
     if (e->aux2) { (void)hipStreamDestroy(e->aux2); e->aux2 = nullptr; }
     for (int h = 0; h < 2; ++h) if (e->ev_mix[h]) { (void)hipEventDestroy(e->ev_mix[h]); e->ev_mix[h] = nullptr; }
     F(e->mix_tab); F(e->alt16.phases);
+    for (void* q : e->retired) (void)hipFree(q);
+    e->retired.clear();
+    for (int i = 0; i < 2; ++i) {
+        if (e->adam_host[i]) { (void)hipHostFree(e->adam_host[i]); e->adam_host[i] = nullptr; }
+        if (e->adam_ev[i]) { (void)hipEventDestroy(e->adam_ev[i]); e->adam_ev[i] = nullptr; }
+    }
     e->events.clear();
     return 0;
 }
@@ -409,7 +473,7 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
     const int npairs = e->nwg;
     // MCPC_MIX_SLACK CUs are left free (default 0): with every CU taken, a workgroup that finds its CU still draining has
     // to wait for another workgroup of its XCD to finish, which doubles that segment
-    static const int slack = getenv("MCPC_MIX_SLACK") ? std::max(0, atoi(getenv("MCPC_MIX_SLACK"))) : 0;
+    const int slack = e->knobs.mix_slack;
     const int ns = std::min(n_cu - slack - npairs, npairs);     // npairs + ns workgroups (np pairs + 2 ns singles) <= CUs
     if (ns < 1) return 0;
     // second plan: swap the primary one out, plan for 16 chains, swap back
@@ -503,24 +567,26 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     e->L = d->n_latent;
     e->has_head = d->n_out > 0;
     e->Bpad = (d->batch + kCT - 1) / kCT * kCT;
-    // 16 chains per workgroup lets two workgroups share a CU (LDS <= 80 KiB, <= 256 registers): one
-    // workgroup's MFMA phases cover the other's epilogues, barriers and load latencies.
-    e->ct = 16; e->nw = 4;
-    if (const char* env = getenv("MCPC_CT")) { const int v = atoi(env); if (v == 16 || v == 32) e->ct = v; }
-    if (const char* env = getenv("MCPC_NW")) { const int v = atoi(env); if (v == 4 || (v == 8 && e->ct == 32)) e->nw = v; }
+    { const int rc = parse_tuning(d->tuning, e->knobs); if (rc) { delete e; return rc; } }
+    e->d.tuning = nullptr;                   // the caller's string is not kept
+    const Knobs& kn = e->knobs;
     // Default schedule: the in-place wave-specialised kernel (4 GEMM + 4 epilogue waves), with 16 chains per workgroup while
     // that still gives every workgroup a CU of its own (B <= 16 x CUs: 55 us per step at B = 4096 on cfg-M's net, against 72
     // for the barrier kernel and 93 for 32-chain workgroups) and 32 chains per workgroup beyond (93 us at B = 6000, against
-    // 109 for two 16-chain workgroups per CU).  The barrier kernel below remains the fallback when the in-place LDS plan
-    // does not fit.  MCPC_WS=0 forces it (with MCPC_CT / MCPC_NW choosing its variants), MCPC_WS=2 [MCPC_CT=16|32] forces
-    // the in-place kernel -- for A/B runs and for the tests that pin every variant against the same fixtures.
+    // 109 for two 16-chain workgroups per CU).  The barrier kernel (16 chains per workgroup: two workgroups share a CU, one's
+    // MFMA phases cover the other's epilogues) remains the fallback when the in-place LDS plan does not fit.  Tuning keys
+    // force a variant for A/B runs and for the tests that pin every variant against the same fixtures: ws=0 the barrier
+    // kernel (ct / nw choose its forms), ws=2 [ct=16|32] the in-place kernel.
+    e->ct = 16; e->nw = 4;
+    if (kn.ct) e->ct = kn.ct;
+    if (kn.nw == 4 || (kn.nw == 8 && e->ct == 32)) e->nw = kn.nw;
     int n_cu = 256;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess || n_cu <= 0) n_cu = 256;
-    int want_ws = (!getenv("MCPC_CT") && !getenv("MCPC_NW")) ? 2 : 0;
+    int want_ws = (!kn.ct && !kn.nw) ? 2 : 0;
     bool ct16 = (d->batch + 15) / 16 <= n_cu;
-    if (const char* env = getenv("MCPC_WS")) {
-        want_ws = atoi(env) == 2 ? 2 : 0;
-        ct16 = getenv("MCPC_CT") && atoi(getenv("MCPC_CT")) == 16;
+    if (kn.ws != -1) {
+        want_ws = kn.ws;
+        ct16 = kn.ct == 16;
     }
     if (want_ws) { e->ws = 2; e->ct = ct16 ? 16 : 32; e->nw = 2 * kWs2Pairs; }
     e->nwg = e->Bpad / e->ct;
@@ -574,27 +640,11 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     // defaults sized for 288 GB of HBM per GPU: a 6 GiB ring (128 steps of cfg-M) gives Hebbian segments of 64 steps; a
     // 2 GiB ring (segments of 24) cost 1.4 % more per step
     int64_t budget = d->spill_budget_bytes > 0 ? d->spill_budget_bytes : (int64_t)6 << 30;
-    int slot_cap = 128;
-    if (const char* v = getenv("MCPC_SPILL_GB")) budget = (int64_t)atoi(v) << 30;      // tuning knobs
-    if (const char* v = getenv("MCPC_SLOT_CAP")) slot_cap = std::max(2, atoi(v));
-    e->slots = (int)std::max<int64_t>(1, std::min<int64_t>(slot_cap, budget / (int64_t)per_slot));
+    if (kn.spill_gb > 0) budget = (int64_t)kn.spill_gb << 30;
+    e->slots = (int)std::max<int64_t>(1, std::min<int64_t>(kn.slot_cap, budget / (int64_t)per_slot));
     if (e->slots >= 2) { e->slots &= ~1; e->half_slots = e->slots / 2; } else { e->half_slots = 1; }
-    if (getenv("MCPC_NO_OVERLAP")) e->half_slots = e->slots;       // tuning knob: serial flushes on the caller's stream
-    if (e->half_slots < e->slots) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least urgent
-        if (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, lo) != hipSuccess) return bail(fail(MCPC_EHIP, "hipStreamCreateWithPriority failed"));
-        for (int h = 0; h < 2; ++h)
-            if (hipEventCreateWithFlags(&e->ev_steps[h], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&e->ev_flush[h], hipEventDisableTiming) != hipSuccess)
-                return bail(fail(MCPC_EHIP, "hipEventCreate failed"));
-    }
-    for (int l = 0; l < e->L; ++l) {
-        const size_t n = (size_t)e->slots * e->Bpad * e->npad[l];
-        if ((rc = dmalloc(e->spill_a[l], n))) return bail(rc);
-        if (l >= 1 && (rc = dmalloc(e->spill_e[l], n))) return bail(rc);
-    }
-    if (e->has_head && (rc = dmalloc(e->spill_eo, (size_t)e->slots * e->Bpad * e->out_pad))) return bail(rc);
+    if (kn.no_overlap) e->half_slots = e->slots;             // serial flushes on the caller's stream
+    // (the ring itself -- up to 6 GiB -- is allocated by the first run that accumulates Hebbian sums: ensure_spill)
 
     if ((rc = e->ws == 2 ? build_phases_ws2(e) : build_phases(e))) return bail(rc);
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
@@ -604,7 +654,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
                       : (e->nw == 8 ? (const void*)mcpc_steps_kernel<2, 8> : (const void*)mcpc_steps_kernel<2, 4>);
     hipError_t herr = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
     if (herr != hipSuccess) return bail(fail(MCPC_EHIP, "hipFuncSetAttribute(%d bytes LDS) failed: %s", e->lds_bytes, hipGetErrorString(herr)));
-    if (e->ws == 2 && e->ct == 32 && e->nwg < n_cu && !getenv("MCPC_NO_MIX")) {
+    if (e->ws == 2 && e->ct == 32 && e->nwg < n_cu && !kn.no_mix) {
         if ((rc = setup_mixed_schedule(e, n_cu))) return bail(rc);
     }
     *out = e;
@@ -694,48 +744,152 @@ int mcpc_store_state(mcpc_engine* e, float* const* x, void* stream_) {
     return MCPC_OK;
 }
 
+int mcpc_store_adam_state(mcpc_engine* e, float* const* m, float* const* v, void* stream_) {
+    if (!e || !m || !v) return fail(MCPC_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(e->d.device));
+    for (int l = 0; l < e->L; ++l) {
+        if (!m[l] || !v[l]) return fail(MCPC_EINVAL, "null Adam state pointer for layer %d", l);
+        const size_t total = (size_t)e->d.batch * e->d.sizes[l];
+        hipLaunchKernelGGL(mcpc_unpad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, e->m[l], m[l],
+                           e->d.batch, e->d.sizes[l], e->npad[l]);
+        hipLaunchKernelGGL(mcpc_unpad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, e->v[l], v[l],
+                           e->d.batch, e->d.sizes[l], e->npad[l]);
+    }
+    HIP_TRY(hipGetLastError());
+    return MCPC_OK;
+}
+
 }  // extern "C"
 
 namespace {
 
-// One Hebbian flush: fold `n_slots` spilled steps into the gradient sums of every Linear j >= 1.
+// How the Hebbian sums of Linear j are computed for `rows` spilled rows: the LDS-tiled kernel (mcpc_hebbian.h) for wide
+// Linears, the register-streaming kernel for narrow ones (few output tiles: HBM-bound whatever the tiling).
+struct HebPlan {
+    bool tiled = false;
+    int te = 0, ra = 0, n_mt = 1, n_nt = 1;       // tiled kernel: template choice and tile groups
+    int wave_tiles = 0;                            // streaming kernel: 64 x 64 wave tiles
+    int ksplit = 1, rps = 0;
+    int ksplit_cap = 1;                            // upper bound of ksplit that never decreases with `rows`: sizes the slabs
+};
+
+HebPlan plan_hebbian(const mcpc_engine* e, int ne, int na, int rows) {
+    HebPlan h;
+    const int et = ne / 16, at = na / 16;
+    h.tiled = et >= 8 && at % 8 == 0 && (at <= 16 || at % 16 == 0);
+    if (h.tiled) {
+        h.te = et > 16 ? 17 : (et > 8 ? 16 : 8);
+        h.ra = at >= 16 ? 2 : 1;
+        h.n_mt = (et + h.te - 1) / h.te;
+        h.n_nt = at / (8 * h.ra);
+        // ~48 stages of 32 rows per workgroup (0.3 ms at cfg-M): short enough that the step kernel's next segment never
+        // waits long for CUs, long enough that the slab traffic stays at a few percent of the spill's
+        int want = e->knobs.dw_ksplit > 0 ? e->knobs.dw_ksplit : std::max(1, rows / (48 * kHebKB));
+        want = std::min(want, std::max(1, rows / kHebKB));
+        h.ksplit_cap = want;
+        h.rps = ((rows + want - 1) / want + kHebKB - 1) / kHebKB * kHebKB;
+        h.ksplit = (rows + h.rps - 1) / h.rps;
+        // (a multiple of 8 workgroups lets the kernel pair the workgroups of a split on one XCD)
+    } else {
+        h.wave_tiles = ((ne + 63) / 64) * ((na + 63) / 64);
+        int ksplit = std::max(1, std::min(4096 / h.wave_tiles, rows / 64));
+        h.ksplit_cap = ksplit;
+        h.rps = ((rows + ksplit - 1) / ksplit + 15) / 16 * 16;
+        h.ksplit = (rows + h.rps - 1) / h.rps;
+    }
+    return h;
+}
+
+template <int TE, int RA>
+int launch_heb(const HebArgs& a, hipStream_t stream) {
+    constexpr int lds_bytes = 2 * kHebKB * 16 * (TE + 8 * RA) * (int)sizeof(float);
+    static bool attr_set[16] = {false};      // per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)mcpc_heb_kernel<TE, RA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return fail(MCPC_EHIP, "hipFuncSetAttribute failed for the Hebbian kernel");
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((mcpc_heb_kernel<TE, RA>), dim3(a.n_mt * a.n_nt * a.ksplit), dim3(kHebThreads), lds_bytes, stream, a);
+    return 0;
+}
+
+// Allocated by the first run that accumulates Hebbian sums (inference-only engines never pay for it): the spill ring, the
+// slabs of the split-K partial sums (sized for a flush of half the ring), the low-priority stream and events of the
+// overlapped flush.
+int ensure_spill(mcpc_engine* e) {
+    if (e->spill_ready) return 0;
+    int rc;
+    if (e->half_slots < e->slots && !e->aux) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least urgent
+        if (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, lo) != hipSuccess) return fail(MCPC_EHIP, "hipStreamCreateWithPriority failed");
+        for (int h = 0; h < 2; ++h)
+            if (hipEventCreateWithFlags(&e->ev_steps[h], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&e->ev_flush[h], hipEventDisableTiming) != hipSuccess)
+                return fail(MCPC_EHIP, "hipEventCreate failed");
+    }
+    for (int l = 0; l < e->L; ++l) {
+        const size_t n = (size_t)e->slots * e->Bpad * e->npad[l];
+        if (!e->spill_a[l] && (rc = dmalloc(e->spill_a[l], n))) return rc;
+        if (l >= 1 && !e->spill_e[l] && (rc = dmalloc(e->spill_e[l], n))) return rc;
+    }
+    if (e->has_head && !e->spill_eo && (rc = dmalloc(e->spill_eo, (size_t)e->slots * e->Bpad * e->out_pad))) return rc;
+    const int nlin = e->L + (e->has_head ? 1 : 0);
+    const int max_rows = e->half_slots * e->Bpad;
+    size_t total = 0;
+    for (int j = 1; j < nlin; ++j) {
+        Lin& ln = e->lin[j];
+        const HebPlan h = plan_hebbian(e, ln.out_pad, ln.in_pad, max_rows);
+        ln.slab_off = total;
+        ln.slab_floats = (size_t)h.ksplit_cap * ((size_t)ln.out_pad * ln.in_pad + ln.out_pad);
+        total += ln.slab_floats;
+    }
+    if (!e->slab && (rc = dmalloc(e->slab, total))) return rc;
+    e->slab_floats = total;
+    e->spill_ready = true;
+    return 0;
+}
+
+// One Hebbian flush: fold `n_slots` spilled steps into the gradient sums of every Linear j >= 1.  Every Linear has its own
+// slab region, so the GEMMs of a flush are independent launches and ONE reduction launch follows them.
 int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
     const int rows = n_slots * e->Bpad;
     const int nlin = e->L + (e->has_head ? 1 : 0);
+    ReduceJobs jobs{};
+    unsigned max_blocks = 1;
     for (int j = 1; j < nlin; ++j) {
         Lin& ln = e->lin[j];
         const int ne = ln.out_pad, na = ln.in_pad;
         const float* E = (j < e->L ? e->spill_e[j] : e->spill_eo) + (size_t)slot0 * e->Bpad * ne;
         const float* A = e->spill_a[j - 1] + (size_t)slot0 * e->Bpad * na;
-        const int wave_tiles = ((ne + 63) / 64) * ((na + 63) / 64);
-        // enough K-splits for ~4096 waves (3 resident per SIMD at ~150 registers): the kernel streams the
-        // spill from HBM, and occupancy + the two-block prefetch hide its latency
-        static const int target_waves = getenv("MCPC_DW_WAVES") ? std::max(256, atoi(getenv("MCPC_DW_WAVES"))) : 4096;
-        int ksplit = std::max(1, std::min(target_waves / wave_tiles, rows / 64));
-        int rps = ((rows + ksplit - 1) / ksplit + 15) / 16 * 16;
-        ksplit = (rows + rps - 1) / rps;
-        const size_t g_floats = (size_t)ksplit * ne * na, b_floats = (size_t)ksplit * ne;
-        const size_t need = g_floats + b_floats;
-        if (need > e->slab_floats) {
-            if (e->slab) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(e->slab)); e->slab = nullptr; }
-            int rc = dmalloc(e->slab, need);
+        const HebPlan h = plan_hebbian(e, ne, na, rows);
+        float* slab = e->slab + ln.slab_off;
+        float* slab_b = slab + (size_t)h.ksplit * ne * na;
+        if ((size_t)h.ksplit * ((size_t)ne * na + ne) > ln.slab_floats)
+            return fail(MCPC_ESTATE, "internal: Hebbian slabs of Linear %d (%d splits) exceed their allocation", j, h.ksplit);
+        if (h.tiled) {
+            HebArgs a{E, A, slab, slab_b, rows, ne, na, h.rps, h.n_mt, h.n_nt, h.ksplit};
+            int rc = 0;
+            if (h.te == 17 && h.ra == 2) rc = launch_heb<17, 2>(a, stream);
+            else if (h.te == 16 && h.ra == 2) rc = launch_heb<16, 2>(a, stream);
+            else if (h.te == 8 && h.ra == 2) rc = launch_heb<8, 2>(a, stream);
+            else if (h.te == 17) rc = launch_heb<17, 1>(a, stream);
+            else if (h.te == 16) rc = launch_heb<16, 1>(a, stream);
+            else rc = launch_heb<8, 1>(a, stream);
             if (rc) return rc;
-            e->slab_floats = need;
+        } else {
+            hipLaunchKernelGGL(mcpc_dw_kernel, dim3((h.wave_tiles + 3) / 4, h.ksplit), dim3(256), 0, stream, E, A, slab, slab_b,
+                               rows, ne, na, h.rps);
         }
-        float* slab_b = e->slab + g_floats;
-        hipLaunchKernelGGL(mcpc_dw_kernel, dim3((wave_tiles + 3) / 4, ksplit), dim3(256), 0, stream, E, A, e->slab, slab_b,
-                           rows, ne, na, rps);
         const float sign = j < e->L ? -1.0f : 1.0f;
-        // few elements and many splits: 16 waves per 64 elements; otherwise one thread per element
-        auto reduce = [&](const float* slab, float* dst, size_t n) {
-            if (n <= 16384 && ksplit >= 128)
-                hipLaunchKernelGGL(mcpc_reduce_slabs_wide_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, stream, slab, dst, (int)n, ksplit, sign, 1);
-            else
-                hipLaunchKernelGGL(mcpc_reduce_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, stream, slab, dst, n, ksplit, sign, 1);
-        };
-        reduce(e->slab, ln.G, (size_t)ne * na);
-        reduce(slab_b, ln.Gb, (size_t)ne);
+        jobs.job[jobs.n_jobs++] = ReduceJob{slab, ln.G, ne * na, h.ksplit, sign};
+        jobs.job[jobs.n_jobs++] = ReduceJob{slab_b, ln.Gb, ne, h.ksplit, sign};
+        max_blocks = std::max(max_blocks, (unsigned)std::min<size_t>(((size_t)ne * na + 255) / 256, 2048));
     }
+    if (jobs.n_jobs > 0)
+        hipLaunchKernelGGL(mcpc_reduce_jobs_kernel, dim3(max_blocks, jobs.n_jobs), dim3(256), 0, stream, jobs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -779,22 +933,39 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
 
     // ---- per-run device tables ----------------------------------------------------------------
     if (r->xopt_kind == MCPC_XOPT_ADAM) {
-        if ((size_t)r->n_steps * 2 > e->adam_cap) {
-            if (e->adam_coef) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(e->adam_coef)); e->adam_coef = nullptr; }
-            int rc = dmalloc(e->adam_coef, (size_t)r->n_steps * 2);
+        const size_t need = (size_t)r->n_steps * 2;
+        if (need > e->adam_cap) {
+            // earlier launches may still read the old table: retire it instead of synchronising
+            if (e->adam_coef) e->retired.push_back(e->adam_coef);
+            e->adam_coef = nullptr;
+            size_t cap = 1024;
+            while (cap < need) cap *= 2;
+            int rc = dmalloc(e->adam_coef, cap);
             if (rc) return rc;
-            e->adam_cap = (size_t)r->n_steps * 2;
+            e->adam_cap = cap;
         }
-        HIP_TRY(hipStreamSynchronize(stream));          // host table may still feed a previous async copy
-        e->adam_host.resize((size_t)r->n_steps * 2);
+        // pinned staging table, double-buffered; the event wait below is a no-op unless the upload issued two Adam runs ago
+        // has still not executed
+        const int hb = e->adam_next; e->adam_next ^= 1;
+        if (!e->adam_ev[hb]) HIP_TRY(hipEventCreateWithFlags(&e->adam_ev[hb], hipEventDisableTiming));
+        else HIP_TRY(hipEventSynchronize(e->adam_ev[hb]));
+        if (need > e->adam_host_cap[hb]) {
+            if (e->adam_host[hb]) HIP_TRY(hipHostFree(e->adam_host[hb]));
+            e->adam_host[hb] = nullptr;
+            void* q = nullptr;
+            HIP_TRY(hipHostMalloc(&q, e->adam_cap * sizeof(float), hipHostMallocDefault));
+            e->adam_host[hb] = (float*)q; e->adam_host_cap[hb] = e->adam_cap;
+        }
+        float* tab = e->adam_host[hb];
         for (int s = 0; s < r->n_steps; ++s) {
             const double step = (double)(r->adam_step0 + s + 1);
             const double bc1 = 1.0 - std::pow((double)r->beta1, step);
             const double bc2 = 1.0 - std::pow((double)r->beta2, step);
-            e->adam_host[2 * s] = (float)((double)r->lr / bc1);
-            e->adam_host[2 * s + 1] = (float)(1.0 / std::sqrt(bc2));
+            tab[2 * s] = (float)((double)r->lr / bc1);
+            tab[2 * s + 1] = (float)(1.0 / std::sqrt(bc2));
         }
-        HIP_TRY(hipMemcpyAsync(e->adam_coef, e->adam_host.data(), (size_t)r->n_steps * 2 * sizeof(float), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(e->adam_coef, tab, need * sizeof(float), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(e->adam_ev[hb], stream));
         if (r->adam_step0 == 0)
             for (int l = 0; l < e->L; ++l) {
                 HIP_TRY(hipMemsetAsync(e->m[l], 0, (size_t)e->Bpad * e->npad[l] * 4, stream));
@@ -806,7 +977,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     // forms can then serve the same call)
     const size_t eslots = e->ws == 2 ? (size_t)e->Bpad / 16 : (size_t)e->nwg;
     if (r->energy_mode != MCPC_ENERGY_NONE && erows > e->epart_rows) {
-        if (e->epart) { HIP_TRY(hipStreamSynchronize(stream)); HIP_TRY(hipFree(e->epart)); e->epart = nullptr; }
+        if (e->epart) e->retired.push_back(e->epart);     // earlier launches may still write it
+        e->epart = nullptr;
         int rc = dmalloc(e->epart, erows * eslots * (kMaxLatent + 1));
         if (rc) return rc;
         e->epart_rows = erows;
@@ -819,6 +991,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
                            e->d.batch, e->d.n_in, e->d.sizes[0], e->Bpad, e->npad[0]);
     }
     const bool run_accumulates = acc_b < acc_e && r->t_begin < acc_e && r->t_begin + r->n_steps > acc_b;
+    if (run_accumulates) { const int rc = ensure_spill(e); if (rc) return rc; }
     if (r->acc_reset && run_accumulates) {
         for (int j = 0; j < nlin; ++j) {
             HIP_TRY(hipMemsetAsync(e->lin[j].G, 0, (size_t)e->lin[j].out_pad * e->lin[j].g_ld * 4, stream));
@@ -857,7 +1030,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     }
     P.mu1 = e->mu1; P.epart = e->epart; P.epart_slots = (int)eslots;
     P.phases = e->phases; P.n_phases = e->n_phases;
-    { const char* v = getenv("MCPC_STAGGER"); P.stagger_cycles = v ? atoi(v) : 0; }
+    P.stagger_cycles = e->knobs.stagger;
     P.L = e->L; P.has_head = e->has_head; P.B = e->d.batch; P.Bpad = e->Bpad; P.T = r->T;
     P.xopt = r->xopt_kind; P.update_x = r->update_x ? 1 : 0;
     P.lr = r->lr; P.beta2 = r->beta2;
@@ -870,14 +1043,12 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     P.rec_begin = r->rec_begin; P.rec_stride = std::max(r->rec_stride, 1); P.rec_count = r->rec_count;
     P.lds_red = e->lds_red;
     P.lds_ws_sync = e->lds_ws_sync;
-    { const char* v = getenv("MCPC_WS_PRIO"); P.ws_prio = v ? atoi(v) : 1; }
+    P.ws_prio = e->knobs.ws_prio;
     P.err = e->err;
 #ifdef MCPC_STAMPS
     if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * 2 * kMaxWaves * 16); if (rc) return rc; }
     P.dbg = e->dbg;
 #endif
-
-    if (e->profiling) { e->events_used = 0; e->prof_steps = 0; }
 
     // ---- step segments: non-accumulating stretches run as one persistent launch; accumulating
     //      stretches are cut at the spill ring's capacity and followed by a Hebbian flush ----------
@@ -891,19 +1062,24 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
 #ifdef MCPC_STAMPS
     mix_ok = false;
 #endif
-    auto prof_begin = [&]() -> int {
+    // HIP events around the launches of the plain schedule (set 0) and around whole cycles of the mixed schedule (set 1)
+    auto prof_begin = [&](bool mixed = false) -> int {
         if (!e->profiling) return 0;
-        if (e->events_used == e->events.size()) {
+        auto& ev = mixed ? e->events_mix : e->events;
+        size_t& used = mixed ? e->events_mix_used : e->events_used;
+        if (used == ev.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(MCPC_EHIP, "hipEventCreate failed");
-            e->events.emplace_back(a, b);
+            ev.emplace_back(a, b);
         }
-        return hipEventRecord(e->events[e->events_used].first, stream) == hipSuccess ? 0 : fail(MCPC_EHIP, "hipEventRecord failed");
+        return hipEventRecord(ev[used].first, stream) == hipSuccess ? 0 : fail(MCPC_EHIP, "hipEventRecord failed");
     };
-    auto prof_end = [&](double steps) -> int {
+    auto prof_end = [&](double steps, bool mixed = false) -> int {
         if (!e->profiling) return 0;
-        if (hipEventRecord(e->events[e->events_used].second, stream) != hipSuccess) return fail(MCPC_EHIP, "hipEventRecord failed");
-        ++e->events_used; e->prof_steps += steps;
+        auto& ev = mixed ? e->events_mix : e->events;
+        size_t& used = mixed ? e->events_mix_used : e->events_used;
+        if (hipEventRecord(ev[used].second, stream) != hipSuccess) return fail(MCPC_EHIP, "hipEventRecord failed");
+        ++used; (mixed ? e->prof_steps_mix : e->prof_steps) += steps;
         return 0;
     };
     // one cycle of the mixed schedule: mix_lc segments, in each of them the paired units do `mp` steps as 32-chain workgroups
@@ -950,8 +1126,11 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             for (const auto& sg : kSeg) {
                 const int cyc = e->mix_a * sg[1] + (e->mix_lc - e->mix_a) * sg[0];
                 while (n >= cyc) {
+                    // (events around a whole cycle only: one between the two concurrent launches of a segment serialises them)
+                    { const int rc = prof_begin(true); if (rc) return rc; }
                     const int rc = run_mixed_cycle(t, sg[0], sg[1]);
                     if (rc) return rc;
+                    { const int rc2 = prof_end((double)cyc, true); if (rc2) return rc2; }
                     t += cyc; n -= cyc;
                 }
             }
@@ -1028,17 +1207,17 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     if (run_accumulates) {
         // Linear 0 sees a constant input: fold sum_t e_1 now, then clear the running sum
         Lin& l0 = e->lin[0];
-        const int total = std::max(l0.n_out * l0.n_in, l0.n_out);
-        hipLaunchKernelGGL(mcpc_dw0_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, e->e0sum, e->inputs, l0.G, l0.Gb,
-                           e->d.batch, l0.n_out, e->npad[0], l0.n_in, l0.g_ld, 1);
+        // one block per (unit, input column | bias): a fixed-order tree over the chains
+        hipLaunchKernelGGL(mcpc_dw0_kernel, dim3(l0.n_out, e->inputs != nullptr ? l0.n_in + 1 : 1), dim3(256), 0, stream, e->e0sum,
+                           e->inputs, l0.G, l0.Gb, e->d.batch, l0.n_out, e->npad[0], l0.n_in, l0.g_ld);
         HIP_TRY(hipMemsetAsync(e->e0sum, 0, (size_t)e->Bpad * e->npad[0] * 4, stream));
     }
     if (r->energy_mode == MCPC_ENERGY_ALL) {
-        hipLaunchKernelGGL(mcpc_energy_reduce_kernel, dim3((r->n_steps + 63) / 64), dim3(64), 0, stream,
+        hipLaunchKernelGGL(mcpc_energy_reduce_kernel, dim3((r->n_steps + 3) / 4), dim3(256), 0, stream,
                            e->epart + (size_t)r->t_begin * eslots * (kMaxLatent + 1),
                            r->energies_out + (size_t)r->t_begin * kEnergyCols, r->n_steps, (int)eslots, e->L);
     } else if (r->energy_mode == MCPC_ENERGY_LAST && end == r->T) {
-        hipLaunchKernelGGL(mcpc_energy_reduce_kernel, dim3(1), dim3(64), 0, stream, e->epart, r->energies_out, 1, (int)eslots, e->L);
+        hipLaunchKernelGGL(mcpc_energy_reduce_kernel, dim3(1), dim3(256), 0, stream, e->epart, r->energies_out, 1, (int)eslots, e->L);
     }
     HIP_TRY(hipGetLastError());
     return MCPC_OK;
@@ -1129,24 +1308,41 @@ int mcpc_sync_check(mcpc_engine* e, void* stream_) {
 int mcpc_set_profiling(mcpc_engine* e, int enable) {
     if (!e) return fail(MCPC_EINVAL, "null engine");
     e->profiling = enable != 0;
-    e->events_used = 0;
-    e->prof_steps = 0;
+    e->events_used = e->events_mix_used = 0;
+    e->prof_steps = e->prof_steps_mix = 0;
     return MCPC_OK;
 }
+
+namespace {
+int sum_events(const std::vector<std::pair<hipEvent_t, hipEvent_t>>& ev, size_t used, float* total) {
+    *total = 0.f;
+    for (size_t i = 0; i < used; ++i) {
+        HIP_TRY(hipEventSynchronize(ev[i].second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, ev[i].first, ev[i].second));
+        *total += t;
+    }
+    return 0;
+}
+}  // namespace
 
 int mcpc_last_step_kernel_ms(mcpc_engine* e, float* ms, int32_t* n_launches, int64_t* n_steps) {
     if (!e || !ms) return fail(MCPC_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(e->d.device));
-    float total = 0.f;
-    for (size_t i = 0; i < e->events_used; ++i) {
-        HIP_TRY(hipEventSynchronize(e->events[i].second));
-        float t = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t, e->events[i].first, e->events[i].second));
-        total += t;
-    }
-    *ms = total;
+    const int rc = sum_events(e->events, e->events_used, ms);
+    if (rc) return rc;
     if (n_launches) *n_launches = (int32_t)e->events_used;
     if (n_steps) *n_steps = (int64_t)std::llround(e->prof_steps);
+    return MCPC_OK;
+}
+
+int mcpc_last_mixed_cycles_ms(mcpc_engine* e, float* ms, int32_t* n_cycles, int64_t* n_steps) {
+    if (!e || !ms) return fail(MCPC_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(e->d.device));
+    const int rc = sum_events(e->events_mix, e->events_mix_used, ms);
+    if (rc) return rc;
+    if (n_cycles) *n_cycles = (int32_t)e->events_mix_used;
+    if (n_steps) *n_steps = (int64_t)std::llround(e->prof_steps_mix);
     return MCPC_OK;
 }
 

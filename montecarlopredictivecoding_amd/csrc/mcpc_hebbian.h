@@ -1,0 +1,216 @@
+// K3 -- Hebbian sums  G[u][i] = sum_r E[r][u] * A[r][i]  over the spilled (error, activation) rows, for the wide Linears.
+// Replaces the parameter part of overall.backward() (reference predictive_coding/pc_trainer.py:862).
+//
+// A plain fp32 GEMM with a tiny output (ne x na, at most 784 x 256 at cfg-M) and a huge K (rows = steps x chains, 385 k per
+// flush of 64 steps): split-K over the grid, every split writes its partial tile to a slab, the slabs are summed in a fixed
+// order by mcpc_reduce_jobs_kernel (bitwise reproducible; no float atomics).
+//
+// Workgroup = 8 waves (two per SIMD), tile = TE x TA MFMA tiles of 16 x 16 (TE <= 17 error tiles x TA = 8 RA activation
+// tiles: 272 x 256 outputs for the read-out Linear), so that a spilled byte is read once per workgroup column and every
+// k-row of the tile costs (TE + TA) x 64 B for TE x TA x 256 MACs: 8.2 B per CU-cycle at the full fp32 MFMA rate, which
+// HBM + L2 deliver (the first kernel read its operands straight into registers, 64 x 64 per wave: 32 B per CU-cycle).
+//   * operands travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no staging registers),
+//     32 rows per stage, two stages; the DMA of stage s+1 is issued before the MFMAs of stage s (17 k cycles per SIMD);
+//   * LDS images are the row-major panels themselves ([32][16 TE] and [32][16 TA] floats, lane-linear as LDS-DMA requires);
+//     MFMA operand (tile t, k-step ks) = one ds_read_b32 at [4 ks + lane/16][16 t + lane%16];
+//   * wave w owns activation tiles RA w .. RA w + RA - 1 against all TE error tiles: TE x RA accumulators (136 VGPRs at
+//     17 x 2), TE + RA LDS reads per TE x RA MFMAs;
+//   * bias sums (column sums of E) are taken from the LDS panel by the VALU (one thread per column), not by extra MFMAs.
+#pragma once
+
+namespace mcpc {
+
+constexpr int kHebKB = 32;           // spilled rows per stage
+constexpr int kHebThreads = 512;
+
+struct HebArgs {
+    const float* E;                  // [rows][ne]   spilled errors (row stride ne: padded width)
+    const float* A;                  // [rows][na]   spilled activations
+    float* slab;                     // [ksplit][ne][na]
+    float* slab_b;                   // [ksplit][ne]
+    int rows, ne, na;                // rows % 32 == 0; ne, na multiples of 16
+    int rows_per_split;              // multiple of 32
+    int n_mt, n_nt, ksplit;          // error-tile groups, activation-tile groups, K splits: grid = n_mt * n_nt * ksplit workgroups
+};
+
+__device__ __forceinline__ void heb_glds16(const float* gsrc, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int TE, int RA>
+__global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs P) {
+    constexpr int TA = 8 * RA;
+    constexpr int LDE = 16 * TE, LDA = 16 * TA;               // panel row lengths (floats)
+    constexpr int E_PIECES = kHebKB * LDE / 256;               // 1 KiB pieces per stage
+    constexpr int A_PIECES = kHebKB * LDA / 256;
+    constexpr int PIECES = E_PIECES + A_PIECES;
+    constexpr int PPW = (PIECES + 7) / 8;                      // pieces per wave
+    constexpr int STAGE = kHebKB * (LDE + LDA);                // floats per stage
+    static_assert(kHebKB * LDE % 256 == 0 && kHebKB * LDA % 256 == 0, "panels must be whole 1 KiB pieces");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kq = lane >> 4;
+
+    // workgroup -> (split, activation group, error group).  Consecutive LOGICAL ids share a K split (the same rows of A and,
+    // across activation groups, of E), so they are put on one XCD (hardware workgroup id % 8) and meet in its L2.
+    const int total = P.n_mt * P.n_nt * P.ksplit;
+    int id = blockIdx.x;
+    if (total % 8 == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int per_split = P.n_mt * P.n_nt;
+    const int split = id / per_split, rem = id - split * per_split;
+    const int nt = rem / P.n_mt, mt = rem - nt * P.n_mt;
+    const int e_col0 = mt * LDE, a_col0 = nt * LDA;
+    const int r0 = split * P.rows_per_split;
+    const int r1 = min(P.rows, r0 + P.rows_per_split);
+    const int n_stage = (r1 - r0) / kHebKB;
+
+    // masked panel columns (tiles past ne / na) are never written by the DMA: they stay zero
+    for (int i = tid; i < 2 * STAGE / 4; i += kHebThreads) reinterpret_cast<f32x4*>(lds)[i] = splat(0.f);
+    __syncthreads();
+
+    // this wave's pieces: (global offset relative to the stage's first row, LDS offset inside a stage); fixed for the kernel
+    int g_off[PPW], l_off[PPW];
+    bool p_on[PPW], p_is_a[PPW];
+#pragma unroll
+    for (int k = 0; k < PPW; ++k) {
+        const int p = w + 8 * k;
+        const bool is_a = p >= E_PIECES;
+        const int c = (is_a ? p - E_PIECES : p) * 64 + lane;            // 16-byte chunk of the panel
+        const int cpr = (is_a ? LDA : LDE) / 4;                         // chunks per row
+        const int row = c / cpr, col = 4 * (c - row * cpr);
+        const int gcol = (is_a ? a_col0 : e_col0) + col;
+        p_is_a[k] = is_a;
+        p_on[k] = p < PIECES && gcol < (is_a ? P.na : P.ne);
+        g_off[k] = row * (is_a ? P.na : P.ne) + gcol;
+        l_off[k] = (is_a ? kHebKB * LDE + (p - E_PIECES) * 256 : p * 256);
+    }
+    auto issue_stage = [&](int s, int buf) {
+        const size_t rbase = (size_t)(r0 + s * kHebKB);
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const float* src = (p_is_a[k] ? P.A + rbase * P.na : P.E + rbase * P.ne) + g_off[k];
+            if (p_on[k]) heb_glds16(src, lds + buf * STAGE + l_off[k]);
+        }
+    };
+
+    f32x4 acc[TE][RA];
+#pragma unroll
+    for (int i = 0; i < TE; ++i)
+#pragma unroll
+        for (int j = 0; j < RA; ++j) acc[i][j] = splat(0.f);
+    float bsum = 0.f;                                         // column sum of E for column e_col0 + tid (threads < LDE, nt == 0)
+    const bool does_bias = nt == 0 && tid < LDE;
+
+    if (n_stage > 0) issue_stage(0, 0);
+    __syncthreads();                                          // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
+    const int e_rd = kq * LDE + m;                            // lane's operand offset inside a k-step's four rows
+    const int a_rd = kHebKB * LDE + kq * LDA + 16 * RA * w + m;
+    for (int s = 0; s < n_stage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < n_stage) issue_stage(s + 1, buf ^ 1);
+        const float* Ep = lds + buf * STAGE + e_rd;
+        const float* Ap = lds + buf * STAGE + a_rd;
+        float eA[TE], aA[RA], eB[TE], aB[RA];
+#define HEB_LOAD(e_, a_, ks_)                                                                   \
+        do {                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < TE; ++i) e_[i] = Ep[(ks_) * 4 * LDE + 16 * i]; \
+            _Pragma("unroll") for (int j = 0; j < RA; ++j) a_[j] = Ap[(ks_) * 4 * LDA + 16 * j]; \
+        } while (0)
+#define HEB_MFMA(e_, a_)                                                                        \
+        do {                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < TE; ++i)                                      \
+                _Pragma("unroll") for (int j = 0; j < RA; ++j) acc[i][j] = mfma16(e_[i], a_[j], acc[i][j]); \
+        } while (0)
+        // operands of k-step ks+1 are requested before the MFMAs of k-step ks; the sched_barriers keep hipcc from sinking
+        // every read next to its first use (it then waited out an LDS round trip in front of every fourth MFMA)
+        HEB_LOAD(eA, aA, 0);
+#pragma unroll
+        for (int ks = 0; ks < kHebKB / 4; ks += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            HEB_LOAD(eB, aB, ks + 1);
+            HEB_MFMA(eA, aA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < kHebKB / 4) HEB_LOAD(eA, aA, ks + 2);
+            HEB_MFMA(eB, aB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#undef HEB_LOAD
+#undef HEB_MFMA
+        if (does_bias) {
+            const float* col = lds + buf * STAGE + tid;
+#pragma unroll 8
+            for (int r = 0; r < kHebKB; ++r) bsum += col[r * LDE];
+        }
+        __syncthreads();      // stage s+1 has landed (vmcnt(0) in front of the barrier); every wave is done with stage s
+    }
+
+    // C layout of tile (i, j): row 4 kq + reg -> error unit, column m -> activation unit
+    float* out = P.slab + (size_t)split * P.ne * P.na;
+#pragma unroll
+    for (int i = 0; i < TE; ++i) {
+        const int u0 = e_col0 + 16 * i + 4 * kq;
+        if (u0 >= P.ne) continue;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int a = a_col0 + 16 * (RA * w + j) + m;
+            if (a >= P.na) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) out[(size_t)(u0 + reg) * P.na + a] = acc[i][j][reg];
+        }
+    }
+    if (does_bias && e_col0 + tid < P.ne) P.slab_b[(size_t)split * P.ne + e_col0 + tid] = bsum;
+}
+
+// ---- fixed-order slab reduction for every Linear of a flush in ONE launch ---------------------------------------------
+struct ReduceJob {
+    const float* slab;     // [ksplit][n]
+    float* dst;            // [n]
+    int n, ksplit;
+    float sign;
+};
+constexpr int kMaxReduceJobs = 2 * (kMaxLatent + 1);
+struct ReduceJobs {
+    ReduceJob job[kMaxReduceJobs];
+    int n_jobs;
+};
+
+// dst[i] += sign * sum_k slab[k][i]; k ascending in groups of 8 independent loads -> bitwise reproducible.  blockIdx.y = job.
+// Short vectors with many splits (bias slabs) take the wide form: the block's 4 waves each sum every 4th split of the same
+// 64 elements, partial sums added in wave order through LDS.
+__global__ __launch_bounds__(256) void mcpc_reduce_jobs_kernel(const ReduceJobs J) {
+    __shared__ float part[4][64];
+    const ReduceJob jb = J.job[blockIdx.y];
+    const size_t n = (size_t)jb.n;
+    if (jb.n <= 4096) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int base = blockIdx.x * 64; base < jb.n; base += gridDim.x * 64) {
+            const int idx = base + lane;
+            float s = 0.f;
+            if (idx < jb.n)
+                for (int k = wv; k < jb.ksplit; k += 4) s += __builtin_nontemporal_load(jb.slab + (size_t)k * n + idx);
+            part[wv][lane] = s;
+            __syncthreads();
+            if (wv == 0 && idx < jb.n) jb.dst[idx] += jb.sign * ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+            __syncthreads();
+        }
+        return;
+    }
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        int k = 0;
+        for (; k + 8 <= jb.ksplit; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(jb.slab + (size_t)(k + j) * n + idx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; k < jb.ksplit; ++k) s += __builtin_nontemporal_load(jb.slab + (size_t)k * n + idx);
+        jb.dst[idx] += jb.sign * s;
+    }
+}
+
+}  // namespace mcpc

@@ -981,39 +981,59 @@ __global__ __launch_bounds__(1024) void mcpc_reduce_slabs_wide_kernel(const floa
     }
 }
 
-// Linear 0 (constant input): G_W0[u][k] = -sum_chain esum[chain][u] * inputs[chain][k];  G_b0[u] = -sum_chain esum[chain][u]
-__global__ void mcpc_dw0_kernel(const float* __restrict__ esum, const float* __restrict__ inputs,
-                                float* __restrict__ gW, float* __restrict__ gb, int B, int n1, int npad1, int n_in,
-                                int gw_ld, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n1 * n_in) {
-        const int u = idx / n_in, k = idx % n_in;
-        float s = 0.f;
-        if (inputs != nullptr)
-            for (int ch = 0; ch < B; ++ch) s = fmaf(esum[(size_t)ch * npad1 + u], inputs[(size_t)ch * n_in + k], s);
-        float* d = gW + (size_t)u * gw_ld + k;
-        *d = accumulate ? *d - s : -s;
+// Linear 0 (constant input): G_W0[u][k] -= sum_chain esum[chain][u] * inputs[chain][k];  G_b0[u] -= sum_chain esum[chain][u].
+// One block per (unit u, column k) -- blockIdx.y == n_in is the bias -- 256 threads stride over the chains, partial sums
+// meet in a fixed-order LDS tree: bitwise reproducible.  (One thread per output looping over 6000 chains took 2.3 ms.)
+__global__ __launch_bounds__(256) void mcpc_dw0_kernel(const float* __restrict__ esum, const float* __restrict__ inputs,
+                                                       float* __restrict__ gW, float* __restrict__ gb, int B, int n1, int npad1,
+                                                       int n_in, int gw_ld) {
+    __shared__ float part[256];
+    const int u = blockIdx.x, k = blockIdx.y;
+    const bool is_bias = inputs == nullptr || k == n_in;
+    float s = 0.f;
+    for (int ch = threadIdx.x; ch < B; ch += 256) {
+        const float ev = esum[(size_t)ch * npad1 + u];
+        s = is_bias ? s + ev : fmaf(ev, inputs[(size_t)ch * n_in + k], s);
     }
-    if (idx < n1) {
-        float s = 0.f;
-        for (int ch = 0; ch < B; ++ch) s += esum[(size_t)ch * npad1 + idx];
-        gb[idx] = accumulate ? gb[idx] - s : -s;
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (is_bias) gb[u] -= part[0];
+        else gW[(size_t)u * gw_ld + k] -= part[0];
     }
 }
 
-// energies_out[row][:] = {loss, E_1..E_L, 0.., overall} from per-workgroup partials (fixed order, fp64)
-__global__ void mcpc_energy_reduce_kernel(const double* __restrict__ epart, double* __restrict__ out, int rows, int nwg, int L) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+// energies_out[row][:] = {loss, E_1..E_L, 0.., overall} from per-workgroup partials: one wave per row, lane i sums the
+// slots i, i+64, ... of every column, then a butterfly over the lanes -- fixed order, fp64, bitwise reproducible.
+__global__ __launch_bounds__(256) void mcpc_energy_reduce_kernel(const double* __restrict__ epart, double* __restrict__ out, int rows,
+                                                                 int nwg, int L) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    double loss = 0.0, overall = 0.0;
-    double* o = out + (size_t)row * kEnergyCols;
-    for (int l = 0; l <= kMaxLatent; ++l) {
-        double s = 0.0;
-        for (int w = 0; w < nwg; ++w) s += epart[((size_t)row * nwg + w) * (kMaxLatent + 1) + l];
-        if (l < kMaxLatent) { o[1 + l] = s; overall += s; } else { loss = s; }
+    double col[kMaxLatent + 1];
+#pragma unroll
+    for (int l = 0; l <= kMaxLatent; ++l) col[l] = 0.0;
+    for (int w = lane; w < nwg; w += 64) {
+        const double* p = epart + ((size_t)row * nwg + w) * (kMaxLatent + 1);
+#pragma unroll
+        for (int l = 0; l <= kMaxLatent; ++l) col[l] += p[l];
     }
-    o[0] = loss;
-    o[kEnergyCols - 1] = overall + loss;
+#pragma unroll
+    for (int l = 0; l <= kMaxLatent; ++l)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) col[l] += __shfl_xor(col[l], off, 64);
+    if (lane == 0) {
+        double* o = out + (size_t)row * kEnergyCols;
+        double overall = 0.0;
+#pragma unroll
+        for (int l = 0; l < kMaxLatent; ++l) { o[1 + l] = col[l]; overall += col[l]; }
+        o[0] = col[kMaxLatent];
+        o[kEnergyCols - 1] = overall + col[kMaxLatent];
+    }
 }
 
 // out[scale * G] with un-padding: dst[u][i] (=|+=) scale * G[u][i_pad]
@@ -1052,3 +1072,4 @@ __global__ void mcpc_philox_kernel(uint64_t seed, uint64_t step, int layer, uint
 
 #include "mcpc_steps_ws.h"
 #include "mcpc_steps_ws2.h"
+#include "mcpc_hebbian.h"

@@ -33,6 +33,17 @@ def allreduce_flat(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+def sum_over_group(value: int, group=None) -> int:
+    """Sum of a per-rank integer over the group (the global batch of a sharded job); the value itself without one."""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return int(value)
+    backend = torch.distributed.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
+    return int(t.item())
+
+
 def assign_flat_grads(linears, flat: torch.Tensor) -> None:
     """Point every parameter's ``.grad`` at its slice of the flat bucket (layout of mcpc_read_param_grads_flat)."""
     if flat.numel() != flat_param_count(linears):

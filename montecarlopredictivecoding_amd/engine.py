@@ -5,6 +5,7 @@ handed to the library as ``data_ptr()`` + sizes.  The computation is the hand-wr
 ``csrc/`` -- this module contains no arithmetic and no fallback.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -42,7 +43,8 @@ class Engine:
     """One MCPC engine = one network shape + one shard of chains on one GPU."""
 
     def __init__(self, sizes: Sequence[int], acts: Sequence[int], n_in: int, n_out: int, batch: int,
-                 device=None, ecoef: Optional[Sequence[float]] = None, spill_budget_bytes: int = 0):
+                 device=None, ecoef: Optional[Sequence[float]] = None, spill_budget_bytes: int = 0,
+                 tuning: Optional[str] = None):
         self._h = C.c_void_p()
         self._lib = L.load()
         if not torch.cuda.is_available():
@@ -62,6 +64,10 @@ class Engine:
         d.n_latent, d.n_in, d.n_out, d.batch = self.L, self.n_in, self.n_out, self.batch
         d.device = self.device.index
         d.spill_budget_bytes = int(spill_budget_bytes)
+        # developer overrides of the schedule heuristics ("ws=2,ct=32", see include/mcpc.h).  The library reads no
+        # environment; this harness-side variable lets the test-suite pin every kernel variant through the facade too.
+        self.tuning = tuning if tuning is not None else os.environ.get("MCPC_TUNING")
+        d.tuning = self.tuning.encode() if self.tuning else None
         for i in range(self.L):
             d.sizes[i], d.acts[i], d.ecoef[i] = self.sizes[i], self.acts[i], self.ecoef[i]
         L.check(self._lib.mcpc_create(C.byref(d), C.byref(self._h)))
@@ -127,6 +133,10 @@ class Engine:
 
     def store_state(self, xs: Sequence[torch.Tensor]):
         L.check(self._lib.mcpc_store_state(self._h, self._ptr_array(xs, "x"), self._stream()))
+
+    def store_adam_state(self, ms: Sequence[torch.Tensor], vs: Sequence[torch.Tensor]):
+        L.check(self._lib.mcpc_store_adam_state(self._h, self._ptr_array(ms, "exp_avg"), self._ptr_array(vs, "exp_avg_sq"),
+                                                self._stream()))
 
     # ---- the hot loop ----------------------------------------------------------------------------
     def run(self, T: int, t_begin: int = 0, n_steps: Optional[int] = None, *,
@@ -225,6 +235,11 @@ class Engine:
     def last_step_kernel_ms(self):
         ms, n, s = C.c_float(), C.c_int32(), C.c_int64()
         L.check(self._lib.mcpc_last_step_kernel_ms(self._h, C.byref(ms), C.byref(n), C.byref(s)))
+        return ms.value, n.value, s.value
+
+    def last_mixed_cycles_ms(self):
+        ms, n, s = C.c_float(), C.c_int32(), C.c_int64()
+        L.check(self._lib.mcpc_last_mixed_cycles_ms(self._h, C.byref(ms), C.byref(n), C.byref(s)))
         return ms.value, n.value, s.value
 
 

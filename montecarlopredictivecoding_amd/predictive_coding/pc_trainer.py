@@ -22,6 +22,8 @@ rejected  anything the kernels do not express (S/M masks, non-quadratic ``energy
           optimised inputs, non-Sequential models ...) raises ``NotImplementedError`` naming the
           reason.  There is no silent torch or CPU execution of the loop.
 """
+import collections
+import os
 import typing
 import warnings
 
@@ -40,9 +42,13 @@ from .pc_layer import PCLayer
 # Philox step counter shared by every trainer of the process: consecutive calls never reuse noise,
 # and all ranks of a sharded job (same sequence of calls) stay in lock-step.
 _PHILOX_STEPS = [0]
-# engines are keyed by (network shape, batch, device) and shared between trainers of one model
-# (the scripts build a PC and an MCPC trainer over the same nn.Sequential).
-_ENGINES = {}
+# engines are keyed by (network shape, batch, device, tuning) and shared between trainers -- the scripts build a PC and an
+# MCPC trainer over the same nn.Sequential, and figure_4 / table_1 run several models of one architecture side by side.
+# WHICH parameters an engine is bound to is therefore tracked on the engine (``_bound_sig``), never on a trainer.  The
+# cache is a small LRU: every distinct (shape, batch) -- e.g. the ragged last batch of a data loader -- owns device
+# memory, evicted engines are closed.
+_ENGINES = collections.OrderedDict()
+_ENGINE_CACHE_SIZE = 8
 
 
 def _take_philox_steps(n):
@@ -144,11 +150,11 @@ class PCTrainer(object):
         self.is_disable_warning_energy_from_different_batch_sizes = is_disable_warning_energy_from_different_batch_sizes
 
         # ---- engine-side state (no counterpart in the reference) ------------------------------------
-        self._param_versions = None
         self.mcpc_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF   # Philox key; follows torch.manual_seed
         self.mcpc_chain_base = 0              # global id of this shard's first chain
         self.mcpc_process_group = None        # torch.distributed group for the Hebbian all-reduce (or None)
         self.mcpc_world_batch = None          # global batch for the 1/(n*B) normalisation when sharded
+        self._derived_world_batch = {}
         self.mcpc_sharded = False
         self.mcpc_materialize_unused_grads = False   # reference quirk: autograd fills .grad even if never used
         self.last_call_mode = None            # 'fused' | 'stepwise' (for tests / diagnostics)
@@ -278,8 +284,22 @@ class PCTrainer(object):
         """
         self.mcpc_process_group = process_group
         self.mcpc_chain_base = int(chain_base)
-        self.mcpc_world_batch = world_batch
+        if world_batch is not None and int(world_batch) < 1:
+            raise ValueError("world_batch must be positive")
+        self.mcpc_world_batch = None if world_batch is None else int(world_batch)
+        self._derived_world_batch = {}        # local batch -> all-reduced total, when world_batch is not given
         self.mcpc_sharded = True
+
+    def _global_batch(self, local_batch: int) -> int:
+        """Batch the reference divides by (``len(inputs)``, pc_trainer.py:905): the local one for an unsharded trainer,
+        the job-wide one for a shard -- given to set_shard, or else the sum of the local batches over the group."""
+        if not self.mcpc_sharded:
+            return local_batch
+        if self.mcpc_world_batch is not None:
+            return self.mcpc_world_batch
+        if local_batch not in self._derived_world_batch:
+            self._derived_world_batch[local_batch] = dist.sum_over_group(local_batch, self.mcpc_process_group)
+        return self._derived_world_batch[local_batch]
 
     # ---- the call --------------------------------------------------------------------------------------
     def train_on_batch(
@@ -349,6 +369,13 @@ class PCTrainer(object):
                       is_reset_optimizer_p_at_batch_start=is_reset_optimizer_p_at_batch_start,
                       is_return_results_every_t=is_return_results_every_t, is_return_outputs=is_return_outputs,
                       is_return_representations=is_return_representations, is_return_xs=is_return_xs)
+        if (plan["mode"] == "fused" and plan["xopt"].kind == L.XOPT_ADAM and self._optimizer_x is not None
+                and not is_sample_x_at_batch_start and not is_reset_optimizer_x_at_batch_start):
+            # the reference keeps the Adam moments and step count of optimizer_x across calls in this case
+            # (pc_trainer.py:742-752 recreates it only behind one of the two flags); the fused kernel restarts them, so the
+            # call is replayed step-wise with the trainer's own persistent torch optimizer
+            plan["mode"] = "stepwise"
+            plan["why_stepwise"] = "Adam state of optimizer_x carried over from the previous call"
         if plan["mode"] == "fused":
             self.last_call_mode = "fused"
             return self._run_fused(plan, **common)
@@ -422,25 +449,35 @@ class PCTrainer(object):
     # ---- engine plumbing ----------------------------------------------------------------------------------
     def _engine_for(self, plan) -> Engine:
         net, B, device = plan["net"], plan["B"], plan["device"]
-        key = net.key(B, device)
+        key = (net.key(B, device), os.environ.get("MCPC_TUNING"))
         eng = _ENGINES.get(key)
         if eng is None:
             eng = Engine(net.sizes, net.acts, net.n_in, net.n_out, B, device=device, ecoef=net.ecoef)
+            eng._bound_sig = None
             _ENGINES[key] = eng
+            while len(_ENGINES) > _ENGINE_CACHE_SIZE:
+                _, old = _ENGINES.popitem(last=False)
+                old.close()
+        else:
+            _ENGINES.move_to_end(key)
         return eng
 
     def _sync_params(self, eng: Engine, net, force=False):
         """(Re)bind + re-pack the Linear parameters when their storage or contents changed."""
         sig = tuple((lin.weight.data_ptr(), lin.weight._version,
                      None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version)) for lin in net.linears)
-        sig = (id(eng),) + sig
-        if force or sig != self._param_versions:
+        # the signature lives on the ENGINE: two models of one architecture share it, and a trainer whose own weights did
+        # not change must still rebind after another trainer ran on the engine
+        if force or sig != eng._bound_sig:
             for lin in net.linears:
                 if not lin.weight.is_contiguous():
                     lin.weight.data = lin.weight.data.contiguous()
             eng.bind_params([lin.weight.data for lin in net.linears],
                             [None if lin.bias is None else lin.bias.data for lin in net.linears])
-            self._param_versions = sig
+            # (contiguous() above may have replaced storage: take the signature after binding)
+            eng._bound_sig = tuple((lin.weight.data_ptr(), lin.weight._version,
+                                    None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
+                                   for lin in net.linears)
 
     def _initial_state(self, plan, inputs, is_sample_x_at_batch_start):
         """Draw / validate x exactly as the first forward of the reference does (pc_trainer.py:717-733,
@@ -511,7 +548,7 @@ class PCTrainer(object):
 
     def _apply_p_step(self, plan, eng, net, n_acc):
         """Normalise (pc_trainer.py:905-913), all-reduce across shards, hand to the user's optimizer_p."""
-        B_global = self.mcpc_world_batch if self.mcpc_world_batch is not None else plan["B"]
+        B_global = self._global_batch(plan["B"])
         flat = eng.read_param_grads_flat(scale=dist.grad_scale(n_acc, B_global))
         if self.mcpc_sharded:
             dist.allreduce_flat(flat, self.mcpc_process_group)     # RCCL: one bucket per call
@@ -567,6 +604,14 @@ class PCTrainer(object):
             rec_begin=rec_begin, rec_stride=1, rec_count=n_rec if any_rec else 0,
             rec_x=rec_layers, rec_out=is_return_outputs and net.n_out > 0)
         eng.store_state([x.data for x in xs])
+        if xopt.kind == L.XOPT_ADAM and isinstance(self._optimizer_x, optim.Adam):
+            # the reference's optimizer_x object outlives the call (pc_trainer.py:742-752 recreates it only behind a flag):
+            # leave it in the state T fused steps produce, so that a later call that keeps it continues correctly
+            ms = [torch.empty_like(x.data) for x in xs]
+            vs = [torch.empty_like(x.data) for x in xs]
+            eng.store_adam_state(ms, vs)
+            for x, m_, v_ in zip(xs, ms, vs):
+                self._optimizer_x.state[x] = {"step": torch.tensor(float(T)), "exp_avg": m_, "exp_avg_sq": v_}
         if do_update:
             self._apply_p_step(plan, eng, net, len(self._accumulate_p_at))
             self._sync_params(eng, net, force=True)
@@ -609,7 +654,7 @@ class PCTrainer(object):
         energies = torch.zeros(T, L.ENERGY_COLS, dtype=torch.float64, device=plan["device"])
         params = [p for lin in net.linears for p in ([lin.weight] if lin.bias is None else [lin.weight, lin.bias])]
         nl = len(net.sizes)
-        B_global = self.mcpc_world_batch if self.mcpc_world_batch is not None else plan["B"]
+        B_global = self._global_batch(plan["B"])
         for t in range(T):
             self._sync_params(eng, net)
             eng.load_state([x.data for x in xs])
@@ -670,6 +715,7 @@ class PCTrainer(object):
                         raise RuntimeError(
                             "If you do <model.eval()> in <callback_after_t()>, you need to put model back to train mode "
                             "when leaving <callback_after_t()>. ")
+        eng.sync_check()           # surfaces a device-side fault word of any of the T single-step launches
         return results
 
     # ---- schedules (reference :1068-1108) ---------------------------------------------------------------------

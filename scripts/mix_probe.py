@@ -13,7 +13,7 @@ dev = torch.device("cuda", 0)
 base = dict(noise_mode=L.NOISE_PHILOX, loss_kind=L.LOSS_BERNOULLI, energy_mode=L.ENERGY_ALL, lr=0.03, seed=1)
 
 def make(B, ct):
-    os.environ["MCPC_WS"] = "2"; os.environ["MCPC_CT"] = str(ct)
+    os.environ["MCPC_TUNING"] = f"ws=2,ct={ct}"
     W, b, y, xs = make_problem(B, 30, dev)
     eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=dev)
     eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y); eng.load_state(xs)

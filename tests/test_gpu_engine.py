@@ -110,13 +110,13 @@ def check_against_golden(g, ci, call, res, eng, xs_final, sched, x_atol=3e-4, e_
 @pytest.mark.parametrize("name", fixture_names(exclude=("g9_",)))
 def test_engine_matches_reference_golden(name, kernel, monkeypatch):
     """Every golden fixture on the kernel a small shard gets by default (in-place wave-specialised, 16 chains per workgroup),
-    on the 32-chain form large shards get (forced with MCPC_WS=2: the kernel the benchmark runs) AND on the barrier kernel
-    that remains the fallback (MCPC_WS=0): every loss / optimizer / noise / schedule variant the reference's fixtures hold is
+    on the 32-chain form large shards get (forced with tuning ws=2: the kernel the benchmark runs) AND on the barrier kernel
+    that remains the fallback (tuning ws=0): every loss / optimizer / noise / schedule variant the reference's fixtures hold is
     pinned on all three."""
     if kernel == "inplace":
-        monkeypatch.setenv("MCPC_WS", "2")
+        monkeypatch.setenv("MCPC_TUNING", "ws=2")
     elif kernel == "barrier":
-        monkeypatch.setenv("MCPC_WS", "0")
+        monkeypatch.setenv("MCPC_TUNING", "ws=0")
     g = Golden(name)
     eng = make_engine(g)
     if kernel == "inplace" and eng.query()["chains_per_wg"] != 32:
@@ -139,6 +139,40 @@ def test_engine_matches_reference_golden(name, kernel, monkeypatch):
             W = [g.get(ci, f"W{j}_after") for j in range(len(W))]
             b = [g.get(ci, f"b{j}_after") if bb is not None else None for j, bb in enumerate(b)]
             keep = bind(eng, g, W, b)   # noqa: F841
+    eng.close()
+
+
+def _per_slot_bytes(case):
+    """Bytes of one spill-ring slot (mcpc_create: activations of every latent layer, errors of layers >= 2, read-out error)."""
+    pad16 = lambda n: (n + 15) // 16 * 16   # noqa: E731
+    bpad = (case["B"] + 31) // 32 * 32
+    floats = sum(pad16(n) * (2 if l >= 1 else 1) for l, n in enumerate(case["sizes"])) + pad16(case["n_out"])
+    return bpad * floats * 4
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("slots", [2, 4, 8])
+@pytest.mark.parametrize("name", ["g2_cfgM_b64", "g8_ragged", "g6_nonzero_inputs"])
+def test_hebbian_ring_reuse_matches_reference_golden(name, slots, overlap):
+    """The learning call at T = 5000 re-uses each half of the Hebbian spill ring dozens of times, with the flush of one half
+    overlapped with the steps that fill the other (pc_trainer.py:853-862,904-914 is what the sums must equal).  Here the ring
+    is shrunk through mcpc_net_desc::spill_budget_bytes to 2, 4 and 8 slots, so the 80 / 15 / 8 accumulating steps of the
+    fixtures wrap it up to 40 times -- with the overlapped flush (two halves, low-priority stream, ev_flush waits) and with the
+    serial one -- and dW / db must still be the reference's.  g2_cfgM_b64 runs the LDS-tiled Hebbian kernel (784 x 256 and
+    256 x 256) plus the streaming one (256 x 32); the small nets the streaming kernel only."""
+    g = Golden(name)
+    eng = make_engine(g, spill_budget_bytes=slots * _per_slot_bytes(g.case), tuning=None if overlap else "no_overlap=1")
+    assert eng.query()["spill_slots"] == slots
+    bind(eng, g)
+    dev = _dev()
+    xs = [torch.from_numpy(x).to(dev) for x in g.X0]
+    call = g.case["calls"][0]
+    eng.load_state(xs)
+    res, sched = run_call(eng, g, 0, call)
+    xs = [torch.empty_like(x) for x in xs]
+    eng.store_state(xs)
+    eng.sync_check()
+    check_against_golden(g, 0, call, res, eng, xs, sched)
     eng.close()
 
 

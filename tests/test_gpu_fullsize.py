@@ -149,7 +149,7 @@ def test_mixed_schedule_matches_plain_schedule(monkeypatch):
     outs = []
     for no_mix in (False, True):
         if no_mix:
-            monkeypatch.setenv("MCPC_NO_MIX", "1")
+            monkeypatch.setenv("MCPC_TUNING", "no_mix=1")
         eng = _engine(B, W, b, y)
         res, out = _run(eng, xs, T, acc_begin=400, acc_end=T, rec_begin=0, rec_stride=60, rec_count=7, rec_x=True)
         outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x],
@@ -162,6 +162,95 @@ def test_mixed_schedule_matches_plain_schedule(monkeypatch):
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-6)
     assert np.all(np.isfinite(outs[0][0]))
     assert np.array_equal(outs[0][3], outs[1][3])            # the Hebbian steps run on the plain schedule either way
+
+
+def test_mixed_schedule_all_segment_sizes_match_plain_schedule(monkeypatch):
+    """A T = 5000 call runs whole cycles of the mixed schedule with (20, 34), then (10, 17), then (3, 5) steps per segment
+    (1178 + 589 + 175 steps at B = 6000) before the plain schedule takes what is left.  T = 1960 runs one cycle of each
+    size and 18 plain steps: final state and every record must be BITWISE those of the plain schedule."""
+    W, b, y, xs = _problem()
+    T = 1178 + 589 + 175 + 18
+    outs = []
+    for no_mix in (False, True):
+        if no_mix:
+            monkeypatch.setenv("MCPC_TUNING", "no_mix=1")
+        eng = _engine(B, W, b, y)
+        eng.set_profiling(True)
+        res, out = _run(eng, xs, T, rec_begin=0, rec_stride=89, rec_count=23, rec_x=True)
+        ms, n_cycles, n_steps = eng.last_mixed_cycles_ms()
+        assert (n_cycles, n_steps) == ((0, 0) if no_mix else (3, 1178 + 589 + 175))
+        outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x]))
+        eng.close()
+    for a, c in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, c)
+    for a, c in zip(outs[0][2], outs[1][2]):
+        assert np.array_equal(a, c)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-6)
+    assert np.all(np.isfinite(outs[0][0]))
+
+
+def test_hebbian_ring_wraps_full_size():
+    """B = 6000, Hebbian sums over 400 steps (pc_trainer.py:853-862: autograd adds dF/dtheta of every accumulating step).
+    The default ring (128 slots, halves of 64, overlapped flush) wraps three times.  Checked against
+      (1) the serial flush with the same segment length (no_overlap, 64 slots): BITWISE -- the overlap (second stream,
+          ev_flush waits, ring halves) must not change a single bit of the bucket;
+      (2) a ring that never wraps (448 slots, one flush of all 400 steps): equal up to summation order;
+      (3) an fp64 torch reduction of the recorded trajectory: every dF/dW and dF/db of the three GEMM Linears recomputed
+          from x_t (errors and activations rebuilt in fp64 from the recorded states), i.e. independent of the spill ring,
+          the split-K slabs and both Hebbian kernels."""
+    from montecarlopredictivecoding_amd import _lib as L
+    W, b, y, xs = _problem()
+    T, acc0 = 420, 20
+    n_acc = T - acc0
+    runs = {}
+    for key, tuning in (("overlap", None), ("serial", "no_overlap=1,slot_cap=64"), ("nowrap", "no_overlap=1,slot_cap=448,spill_gb=24")):
+        eng = _engine(B, W, b, y, tuning=tuning)
+        kw = dict(acc_begin=acc0, acc_end=T)
+        if key == "overlap":
+            kw.update(rec_begin=acc0, rec_stride=1, rec_count=n_acc, rec_x=True)
+        res, out = _run(eng, xs, T, **kw)
+        assert eng.query()["spill_slots"] == {"overlap": 128, "serial": 64, "nowrap": 448}[key]
+        runs[key] = eng.read_param_grads_flat().cpu().numpy()
+        if key == "overlap":
+            rec = res.rec_x
+        eng.close()
+    assert np.array_equal(runs["overlap"], runs["serial"])
+    scale = np.abs(runs["nowrap"]).max()
+    np.testing.assert_allclose(runs["overlap"], runs["nowrap"], rtol=2e-4, atol=2e-6 * scale)
+    # (3) fp64 anchor from the recorded states x_t, t = acc0 .. T-1
+    Wd, bd = [w.double() for w in W], [v.double() for v in b]
+    yd = y.double()
+    gW = [torch.zeros_like(w) for w in Wd]
+    gb = [torch.zeros_like(v) for v in bd]
+    aW = [torch.zeros_like(w) for w in Wd]                          # sums of |terms|: the scale rounding errors are relative to
+    ab = [torch.zeros_like(v) for v in bd]
+    for k in range(0, n_acc, 20):
+        x1, x2, x3 = (r[k:k + 20].double() for r in rec)            # [20, B, n]
+        f1, f2, f3 = x1.clamp_min(0), x2.clamp_min(0), x3.clamp_min(0)
+        e1 = x1 - bd[0]                                             # mu_1 = b0 (inputs are zeros)
+        e2 = x2 - (f1 @ Wd[1].T + bd[1])
+        e3 = x3 - (f2 @ Wd[2].T + bd[2])
+        eo = torch.sigmoid(f3 @ Wd[3].T + bd[3]) - yd
+        gb[0] -= e1.sum((0, 1))
+        ab[0] += e1.abs().sum((0, 1))
+        for j, (e, f, sgn) in enumerate(((e2, f1, -1.0), (e3, f2, -1.0), (eo, f3, 1.0)), start=1):
+            gW[j] += sgn * torch.einsum("tbu,tbi->ui", e, f)
+            gb[j] += sgn * e.sum((0, 1))
+            aW[j] += torch.einsum("tbu,tbi->ui", e.abs(), f)
+            ab[j] += e.abs().sum((0, 1))
+    want = torch.cat([torch.cat([gw.reshape(-1), g_.reshape(-1)]) for gw, g_ in zip(gW, gb)]).cpu().numpy()
+    mag = torch.cat([torch.cat([gw.reshape(-1), g_.reshape(-1)]) for gw, g_ in zip(aW, ab)]).cpu().numpy()
+    got = runs["overlap"].astype(np.float64)
+    # fp32 sums of 2.4 M terms per element (an fp32 MFMA accumulation chain per K split, fp32 sums of the slabs and of the
+    # flushes; the states themselves are fp32): 1e-5 of the sum of |terms|, per tensor
+    off = 0
+    for j in range(4):
+        for n in (W[j].numel(), b[j].numel()):
+            if j == 0 and n == W[0].numel():
+                assert not got[off:off + n].any()                  # dF/dW0 == 0 exactly: the pseudo-input is zero
+            else:
+                np.testing.assert_allclose(got[off:off + n], want[off:off + n], rtol=0, atol=1e-5 * mag[off:off + n].max())
+            off += n
 
 
 @pytest.mark.parametrize("mode", ["adam", "external_noise"])
@@ -181,7 +270,7 @@ def test_mixed_schedule_with_per_step_tables(mode, monkeypatch):
     outs = []
     for no_mix in (False, True):
         if no_mix:
-            monkeypatch.setenv("MCPC_NO_MIX", "1")
+            monkeypatch.setenv("MCPC_TUNING", "no_mix=1")
         eng = _engine(B, W, b, y)
         res, out = _run(eng, xs_small, T, **kw)
         outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out]))
@@ -217,21 +306,16 @@ def test_pc_path_is_bitwise_reproducible_and_descends():
 
 
 def test_workgroup_variants_agree():
-    """16-chain / 32-chain workgroups and the wave-specialised kernel (MCPC_CT, MCPC_NW, MCPC_WS = 2: in-place wave-specialised, 32 or 16 chains) are different
+    """16-chain / 32-chain workgroups and the wave-specialised kernel (tuning keys ct, nw, ws = 2: in-place wave-specialised, 32 or 16 chains) are different
     schedules of the same arithmetic."""
-    import os
     W, b, y, xs = _problem(640)
     outs = []
     for ct, nw, ws in (("16", "4", "0"), ("32", "8", "0"), ("32", "4", "0"), ("32", "8", "2"), ("16", "8", "2")):
-        os.environ["MCPC_CT"], os.environ["MCPC_NW"], os.environ["MCPC_WS"] = ct, nw, ws
-        try:
-            eng = _engine(640, W, b, y)
-            assert eng.query()["chains_per_wg"] == int(ct)
-            res, out = _run(eng, xs, 15, acc_begin=3, acc_end=15)
-            outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], eng.read_param_grads_flat().cpu().numpy()))
-            eng.close()
-        finally:
-            del os.environ["MCPC_CT"], os.environ["MCPC_NW"], os.environ["MCPC_WS"]
+        eng = _engine(640, W, b, y, tuning=f"ct={ct},nw={nw},ws={ws}")
+        assert eng.query()["chains_per_wg"] == int(ct)
+        res, out = _run(eng, xs, 15, acc_begin=3, acc_end=15)
+        outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], eng.read_param_grads_flat().cpu().numpy()))
+        eng.close()
     for k in range(1, len(outs)):
         np.testing.assert_allclose(outs[k][0], outs[0][0], rtol=1e-6)      # per-wave fp32 partial sums differ in grouping
         for a, c in zip(outs[k][1], outs[0][1]):
