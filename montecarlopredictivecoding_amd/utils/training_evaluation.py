@@ -44,6 +44,14 @@ def get_mcpc_trainer_one_sample(gen_pc, config, training=True):
 
 
 # ---- ancestral sampler and evaluators (reference utils/training_evaluation.py:72-100,140-206) -------------
+def _cpu_normal_like(temp):
+    """Standard normals of temp's shape drawn from torch's CPU generator and moved to temp's device -- the stream the
+    reference consumes (training_evaluation.py:73-79 draws `torch.randn((N, n, 1))` on the CPU and `.cuda()`s it), so that a
+    `torch.manual_seed` pins the ancestral sample on the GPU exactly as it does in the reference."""
+    import torch
+    return torch.randn(tuple(temp.shape)).to(temp.device)
+
+
 def sample_pc(num_samples, model, config, use_cuda=False, is_return_hidden=False):
     """Ancestral sample of the generative model: unit-variance Gaussian noise is added at every PCLayer
     (the prior of a PC layer with the default energy), the read-out is sampled from the sensory
@@ -55,13 +63,13 @@ def sample_pc(num_samples, model, config, use_cuda=False, is_return_hidden=False
     with torch.no_grad():
         for module in model:
             if isinstance(module, pc.PCLayer):
-                temp = temp + torch.randn_like(temp)
+                temp = temp + _cpu_normal_like(temp)
             else:
                 temp = module(temp)
         if is_return_hidden:
             return temp.detach()
         if config["loss_fn"] is fe_fn:
-            temp = temp + (config["input_var"] ** 0.5) * torch.randn_like(temp)
+            temp = temp + (config["input_var"] ** 0.5) * _cpu_normal_like(temp)
         elif config["loss_fn"] is bernoulli_fn:
             temp = (torch.rand_like(temp) <= temp.sigmoid()).double()
     return temp.detach()
@@ -93,23 +101,30 @@ def get_mse_rec(gen_pc, config, dataloader, use_cuda):
     return mse / n_data
 
 
-def get_marginal_likelihood(gen_pc, config, dataloader, use_cuda, n_samples=5000):
-    """Importance-sampled log marginal likelihood per datum (Bernoulli read-out), samples from the prior."""
+def marginal_likelihood_from_logits(logits, dataloader):
+    """log (1/S) sum_s p(y | o_s), averaged over the data, for read-out logits o_s [S, n0] (clamped to +-20 as the reference
+    does, training_evaluation.py:177) -- the likelihood core of get_marginal_likelihood as a function of the prior samples.
+    BCE(o, y) summed over pixels = sum softplus(o) - y.o, so the [B, S, n0] tensor the reference materialises per batch
+    (:190-193) becomes one [B, n0] x [n0, S] product."""
     import torch
-    from ..utils.model import bernoulli_fn
-    if config["loss_fn"] is not bernoulli_fn:
-        raise NotImplementedError("the reference implements the Bernoulli read-out only (training_evaluation.py:196)")
-    logits = sample_pc(n_samples, gen_pc, config, use_cuda=use_cuda, is_return_hidden=True).clamp(-20, 20)   # [S, n0]
-    softplus = torch.nn.functional.softplus
-    sp = softplus(logits).sum(1)                                                                           # sum_j log(1+e^o)
+    logits = logits.clamp(-20, 20)
+    sp = torch.nn.functional.softplus(logits).sum(1)                                                       # sum_j log(1+e^o)
     total, count = 0.0, 0
     with torch.no_grad():
         for data, _ in dataloader:
             data = data.to(logits.device).to(logits.dtype)
-            # BCE(o, y) summed over pixels = sum softplus(o) - y.o
             nll = sp.unsqueeze(0) - data @ logits.t()                                                       # [B, S]
             m = nll.min(1).values
             p = torch.exp(-(nll - m.unsqueeze(1))).mean(1)
             total += float((torch.log(p) - m).sum())
             count += data.shape[0]
     return total / count
+
+
+def get_marginal_likelihood(gen_pc, config, dataloader, use_cuda, n_samples=5000):
+    """Importance-sampled log marginal likelihood per datum (Bernoulli read-out), samples from the prior."""
+    from ..utils.model import bernoulli_fn
+    if config["loss_fn"] is not bernoulli_fn:
+        raise NotImplementedError("the reference implements the Bernoulli read-out only (training_evaluation.py:196)")
+    logits = sample_pc(n_samples, gen_pc, config, use_cuda=use_cuda, is_return_hidden=True)                 # [S, n0]
+    return marginal_likelihood_from_logits(logits, dataloader)

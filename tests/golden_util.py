@@ -18,6 +18,9 @@ def fixture_names(prefix="", exclude=()):
     dynamic x learning rate, user callbacks, custom x optimizers -- that only the facade replays, not the
     closed-form oracle or a single mcpc_run)."""
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    # g10_* / g11_* / g12_* are the evaluator, checkpoint and learning-run fixtures of oracle/gen_golden_eval.py: another
+    # format, consumed by tests/test_evaluators_golden.py and tests/test_gpu_widening.py / test_gpu_learning.py
+    exclude = tuple(exclude) + ("g10_", "g11_", "g12_")
     return [n for n in names if not any(n.startswith(x) for x in exclude)]
 
 

@@ -1,0 +1,67 @@
+"""The sharded learning path on the GPU with the real collective backend: one process, a 1-rank "nccl" (= RCCL) group.
+A learning call through PCTrainer._apply_p_step (flat Hebbian bucket written by mcpc_read_param_grads_flat, all-reduced ON
+DEVICE by torch.distributed, normalised by the job-wide batch, handed to the user's optimizer_p) must leave exactly the weights
+of the unsharded run.  World sizes > 1 are covered on the CPU by tests/test_dist_gloo.py (gloo, world_size 2); the driver
+measures N = 2, 4, 8 on a whole node."""
+import os
+import socket
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _learning_call(sharded, world_batch):
+    import montecarlopredictivecoding_amd.utils.model as um
+    from montecarlopredictivecoding_amd.utils.training_evaluation import get_mcpc_trainer
+    torch.manual_seed(3)
+    cfg = dict(input_size=8, hidden_size=32, hidden2_size=32, output_size=64, activation_fn="relu", mixing=6, sampling=10,
+               optimizer_x_kwargs_mcpc={"lr": 0.03}, optimizer_p_fn_mcpc=torch.optim.SGD, optimizer_p_kwargs_mcpc={"lr": 0.5})
+    x0 = [torch.rand(24, n, generator=torch.Generator().manual_seed(40 + i)).to(DEV) for i, n in enumerate((8, 32, 32))]
+    model = um.get_model(cfg, True, sample_x_fn=lambda inp: None)
+    for layer, x in zip([m for m in model if hasattr(m, "get_x")], x0):
+        layer._sample_x_fn = lambda inp, _x=x: _x.clone()
+    tr = get_mcpc_trainer(model, cfg, training=True)
+    if sharded:
+        tr.set_shard(process_group=dist.group.WORLD, chain_base=0, world_batch=world_batch)
+    data = (torch.rand(24, 64, generator=torch.Generator().manual_seed(1)) < 0.3).float().to(DEV)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr.train_on_batch(inputs=torch.zeros(24, 8, device=DEV), loss_fn=um.bernoulli_fn,
+                          loss_fn_kwargs={"_target": data, "_var": None}, callback_after_t=um.random_step,
+                          callback_after_t_kwargs={"_pc_trainer": tr}, is_log_progress=False, is_checking_after_callback_after_t=False)
+    assert tr.last_call_mode == "fused"
+    return [p.detach().clone() for p in model.parameters() if p.dim() <= 2 and p.shape[0] != 24], \
+        [m.weight.grad.clone() for m in model if isinstance(m, torch.nn.Linear)]
+
+
+@pytest.mark.parametrize("world_batch", [24, None])
+def test_one_rank_rccl_group_matches_unsharded_run(world_batch):
+    import montecarlopredictivecoding_amd.predictive_coding.pc_trainer as pt
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base_steps = pt._PHILOX_STEPS[0]
+    plain_w, plain_g = _learning_call(False, None)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        pt._PHILOX_STEPS[0] = base_steps                  # same Philox step counter as the unsharded run
+        shard_w, shard_g = _learning_call(True, world_batch)   # world_batch=None: derived by all-reducing the local batch
+    finally:
+        dist.destroy_process_group()
+    for a, c in zip(plain_g, shard_g):
+        assert a.is_cuda and torch.equal(a, c)
+    for a, c in zip(plain_w, shard_w):
+        assert torch.equal(a, c)
+    assert any(float(g.abs().max()) > 0 for g in plain_g)

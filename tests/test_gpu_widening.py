@@ -156,3 +156,56 @@ def test_adam_state_carried_across_calls_runs_stepwise():
     np.testing.assert_allclose(r1["overall"] + r2["overall"], r_long["overall"], rtol=2e-5)
     for p, q in zip(x_short, x_long):
         np.testing.assert_allclose(p.cpu().numpy(), q.cpu().numpy(), rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("loss", ["bernoulli", "gaussian"])
+def test_get_mse_rec_matches_reference(loss):
+    """Masked-reconstruction error (reference utils/training_evaluation.py:143-170) on the fixture of
+    oracle/gen_golden_eval.py: seeded weights and data, x0 = sample_x_fn_cte, 60 Adam MAP steps per batch on the HIP engine;
+    the reference's scalar and its read-out of the MAP state are the expected values."""
+    from montecarlopredictivecoding_amd.utils.training_evaluation import get_mse_rec
+    from tests.test_evaluators_golden import load_eval_fixture
+    z, meta, cfg, model, loader = load_eval_fixture(loss, device=DEV)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mse = get_mse_rec(model, cfg, loader, True)
+    with torch.no_grad():
+        last = model[-1](model[-2](model[-3].get_x().detach())).cpu().numpy()       # read-out of the last batch's MAP state
+    np.testing.assert_allclose(last, z["map_readout"][-last.shape[0]:], rtol=0, atol=2e-3)
+    if loss == "gaussian":
+        assert mse == pytest.approx(float(z["mse_rec"]), rel=1e-4)
+    else:
+        # thresholded logits: a pixel whose logit is within the trajectory tolerance of 0 may flip -- at most two of 48 x 32
+        assert abs(mse - float(z["mse_rec"])) <= 2.0 / (48 * 32) + 1e-9
+
+
+def test_shipped_checkpoint_map_energies_match_reference():
+    """figure_2.py:184 / table_1.py:76: a shipped state_dict (models/mcpc_fid_3, copied byte for byte as a data fixture) is
+    loaded with strict=False and drives the engine unchanged: 20 Adam MAP steps on 32 seeded images give the reference's
+    loss / energy per step and its final latent state."""
+    import json
+    import os
+    import montecarlopredictivecoding_amd.utils.model as um
+    from montecarlopredictivecoding_amd.utils.training_evaluation import get_pc_trainer
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(gold, "g11_checkpoint_mcpc_fid_3.npz"))
+    meta = json.loads(str(z["meta_json"]))
+    cfg = dict(meta["config"], loss_fn=um.bernoulli_fn, input_var=None, optimizer_x_fn_pc=torch.optim.Adam,
+               optimizer_x_kwargs_pc={"lr": meta["lr"]})
+    model = um.get_model(cfg, True, sample_x_fn=um.sample_x_fn_cte)
+    sd = torch.load(os.path.join(gold, meta["ckpt"]), map_location=DEV)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not missing and sorted(unexpected) == sorted(meta["unexpected"])
+    tr = get_pc_trainer(model, cfg, training=False, is_mcpc=True)
+    data = torch.from_numpy(z["data"]).to(DEV)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = tr.train_on_batch(inputs=torch.zeros(meta["batch"], cfg["input_size"], device=DEV), loss_fn=um.bernoulli_fn,
+                                loss_fn_kwargs={"_target": data, "_var": None}, is_log_progress=False,
+                                is_return_results_every_t=True, is_checking_after_callback_after_t=False)
+    assert tr.last_call_mode == "fused"
+    np.testing.assert_allclose(res["loss"], z["loss"], rtol=3e-5)
+    np.testing.assert_allclose(res["energy"], z["energy"], rtol=3e-5)
+    np.testing.assert_allclose(res["overall"], z["overall"], rtol=3e-5)
+    for l, x in enumerate(tr.get_model_xs()):
+        np.testing.assert_allclose(x.detach().cpu().numpy(), z[f"x_final_l{l}"], rtol=0, atol=3e-4)
