@@ -1170,6 +1170,32 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             HIP_TRY(hipStreamSynchronize(stream));
             std::vector<unsigned long long> h((size_t)e->nwg * e->nw * 16);
             HIP_TRY(hipMemcpy(h.data(), e->dbg, h.size() * 8, hipMemcpyDeviceToHost));
+#ifdef MCPC_STAMPS_ENTRY
+            {
+                // per table entry: mean / max over the G (q = 1, 2) or E (q = 3, 4) waves, cycles per step
+                static const char* what[5] = {"", "G wait (deps)", "G total", "E wait for block", "E total"};
+                static const char* tname[5] = {"FWD", "HEADF", "HEADB", "BWD", "ENERGY"};
+                std::vector<KPhase> tab(e->n_phases);
+                HIP_TRY(hipMemcpy(tab.data(), e->phases, tab.size() * sizeof(KPhase), hipMemcpyDeviceToHost));
+                const bool want_g = MCPC_STAMPS_ENTRY <= 2;
+                fprintf(stderr, "[stamps] launch t0=%d n=%d: %s per table entry, cycles per step (mean / max over the %s waves)\n", t, n,
+                        what[MCPC_STAMPS_ENTRY], want_g ? "G" : "E");
+                double tot = 0;
+                for (int i = 0; i < 16 && i < e->n_phases; ++i) {
+                    double sum = 0, mx = 0; size_t cnt = 0;
+                    for (size_t w = 0; w < (size_t)e->nwg * e->nw; ++w) {
+                        const bool is_g = (int)(w % e->nw) < e->nw / 2;
+                        if (is_g != want_g) continue;
+                        const double v = (double)h[w * 16 + i];
+                        sum += v; mx = std::max(mx, v); ++cnt;
+                    }
+                    tot += sum / cnt / n;
+                    fprintf(stderr, "[stamps]   entry %2d %-6s layer %d tiles %2d nkb %2d  mean %8.0f  max %8.0f\n", i, tname[tab[i].type], tab[i].layer,
+                            tab[i].ntiles, tab[i].nkb, sum / cnt / n, mx / n);
+                }
+                fprintf(stderr, "[stamps]   sum over entries: %.0f cycles per step\n", tot);
+            }
+#else
             double tot = 0, sum[16] = {0}, mx[16] = {0};
             for (size_t w = 0; w < (size_t)e->nwg * e->nw; ++w)
                 for (int i = 0; i < 16; ++i) { sum[i] += (double)h[w * 16 + i]; mx[i] = std::max(mx[i], (double)h[w * 16 + i]); }
@@ -1182,6 +1208,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             for (int i = 0; i < 16; ++i)
                 fprintf(stderr, "[stamps]   %-18s %5.1f%%  mean %8.0f  max %8.0f cycles/step\n", (e->ws == 2 ? names_ws2 : names)[i], 100.0 * sum[i] / tot,
                         sum[i] / (e->nwg * e->nw) / n, mx[i] / n);
+#endif
         }
 #endif
         if (in_acc) {

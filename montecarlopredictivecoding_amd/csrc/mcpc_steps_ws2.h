@@ -44,6 +44,28 @@ constexpr int kWs2Threads = 2 * kWs2Pairs * 64;
 static_assert(kWs2Pairs == 4 || kWs2Pairs == 8, "4 or 8 pairs");
 enum : int { PHF_WS2_HANDOFF = 64 };   // BWD entry without GEMM whose block (accb) still comes from G
 
+// Diagnostic build variant -DMCPC_STAMPS -DMCPC_STAMPS_ENTRY=q: the 16 slots hold, per TABLE ENTRY p (p < 16),
+//   q = 1: cycles the G wave waits in front of / behind the GEMM of entry p (dep_e, dep_g, dep_se)
+//   q = 2: cycles the G wave spends in entry p altogether
+//   q = 3: cycles the E wave waits for its partner's block of entry p
+//   q = 4: cycles the E wave spends in entry p altogether
+#ifdef MCPC_STAMPS_ENTRY
+#define STAMP_ENTRY_ADD(p_, d_)                                                                      \
+    do {                                                                                             \
+        const unsigned long long dd_ = (d_);                                                         \
+        switch (p_) {                                                                                \
+            case 0: st_sum[0] += dd_; break; case 1: st_sum[1] += dd_; break; case 2: st_sum[2] += dd_; break;     \
+            case 3: st_sum[3] += dd_; break; case 4: st_sum[4] += dd_; break; case 5: st_sum[5] += dd_; break;     \
+            case 6: st_sum[6] += dd_; break; case 7: st_sum[7] += dd_; break; case 8: st_sum[8] += dd_; break;     \
+            case 9: st_sum[9] += dd_; break; case 10: st_sum[10] += dd_; break; case 11: st_sum[11] += dd_; break; \
+            case 12: st_sum[12] += dd_; break; case 13: st_sum[13] += dd_; break; case 14: st_sum[14] += dd_; break; \
+            default: st_sum[15] += dd_; break;                                                       \
+        }                                                                                            \
+    } while (0)
+#undef STAMP
+#define STAMP(i) do {} while (0)
+#endif
+
 struct Ws2Sync {
     int prog_e[kWs2Pairs];
     int prog_g[kWs2Pairs];
@@ -246,8 +268,15 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
 #pragma unroll
                     for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = splat(0.f);
                 STAMP(0);
+#ifdef MCPC_STAMPS_ENTRY
+                const unsigned long long ge0 = mcpc_stamp();
+                unsigned long long gwait = 0;
+#endif
                 if (works) {
                     if (ph.dep_e >= 0) ws2_wait_all(sync->prog_e, ws2_need(base, n_ent, p, ph.dep_e), P.err, dead);
+#ifdef MCPC_STAMPS_ENTRY
+                    gwait = mcpc_stamp() - ge0;
+#endif
                     STAMP(1);
                     if (is_headb) {
                         if (nt > 0 MCPC_EXP_GEMM_GATE) gemm_tiles<kWs2NT, CTT, NW>(accb, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
@@ -270,8 +299,14 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                 if (stores) {
                     // write-after-read: the rows this block goes to may still be read by GEMMs (dep_g) or epilogues (dep_se)
                     // of entries that share them -- waited for here, behind the GEMM, not in front of it
+#ifdef MCPC_STAMPS_ENTRY
+                    const unsigned long long gw0 = mcpc_stamp();
+#endif
                     if (ph.dep_g >= 0) ws2_wait_all(sync->prog_g, ws2_need(base, n_ent, p, ph.dep_g), P.err, dead);
                     if (ph.dep_se >= 0) ws2_wait_all(sync->prog_e, ws2_need(base, n_ent, p, ph.dep_se), P.err, dead);
+#ifdef MCPC_STAMPS_ENTRY
+                    gwait += mcpc_stamp() - gw0;
+#endif
                     // the block goes where its consumer reads it; E_k finishes it in place
                     const int kk = (k + ph.rot) & (NW - 1);
                     int ntw = (ph.ntiles - kk + NW - 1) / NW;
@@ -288,11 +323,17 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                 }
                 if (lane == 0) ws_publish(&sync->prog_g[k], base + p + 1);
                 STAMP(5);
+#ifdef MCPC_STAMPS_ENTRY
+                if (MCPC_STAMPS_ENTRY == 1) STAMP_ENTRY_ADD(p, gwait);
+                else if (MCPC_STAMPS_ENTRY == 2) STAMP_ENTRY_ADD(p, mcpc_stamp() - ge0);
+#endif
             }
         }
-#ifdef MCPC_STAMPS
+#if defined(MCPC_STAMPS) && !defined(MCPC_STAMPS_ENTRY)
         st_sum[6] = mcpc_stamp() - clk_m0;          // whole launch in s_memtime ticks ...
         st_sum[7] = wall_clock64() - clk_r0;        // ... and in 100 MHz wall-clock ticks: their ratio is the shader clock
+#endif
+#ifdef MCPC_STAMPS
         if (lane == 0 && P.dbg != nullptr)      // (null in the warm-up launch of setup_mixed_schedule)
             for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * (2 * kWs2Pairs) + wave8) * 16 + i] = st_sum[i];
 #endif
@@ -320,6 +361,10 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
 #pragma unroll 1
         for (int p = 0; p < n_ent; ++p) {
             const KPhase ph = load_phase(P.phases, p);
+#ifdef MCPC_STAMPS_ENTRY
+            const unsigned long long ee0 = mcpc_stamp();
+            unsigned long long ewait = 0;
+#endif
             if (ph.type == PH_ENERGY) {
                 if (do_energy && k == 0) {
                     // every E wave has finished the entries of this step that add to red[]
@@ -362,7 +407,13 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
             STAMP(9);
             const bool from_g = ((ph.flags & PHF_WS_GEMM) && ph.nkb > 0) || (ph.flags & PHF_WS2_HANDOFF);
             if (from_g) {
+#ifdef MCPC_STAMPS_ENTRY
+                const unsigned long long ew0 = mcpc_stamp();
+#endif
                 ws_wait_one(&sync->prog_g[k], base + p + 1, P.err, dead);
+#ifdef MCPC_STAMPS_ENTRY
+                ewait = mcpc_stamp() - ew0;
+#endif
                 STAMP(10);
                 const float* const src = lds + ph.out_lds;
                 const int col0 = (ph.type == PH_HEADF) ? 0 : 16 * ph.tile0;
@@ -392,6 +443,10 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
             }
             if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
             if (ph.type == PH_FWD) STAMP(11); else if (ph.type == PH_HEADF) STAMP(12); else STAMP(13);
+#ifdef MCPC_STAMPS_ENTRY
+            if (MCPC_STAMPS_ENTRY == 3) STAMP_ENTRY_ADD(p, ewait);
+            else if (MCPC_STAMPS_ENTRY == 4) STAMP_ENTRY_ADD(p, mcpc_stamp() - ee0);
+#endif
         }
     }
 #ifdef MCPC_STAMPS
