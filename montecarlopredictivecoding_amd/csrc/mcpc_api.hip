@@ -67,6 +67,7 @@ struct Knobs {
     int dw_ksplit = 0;        // > 0: K-splits per workgroup tile of the Hebbian GEMM (0: one wave of workgroups over the chip)
     int ws_prio = 1;          // 1: epilogue waves at raised priority, 2: GEMM waves, 0: neither
     int stagger = 0;          // barrier kernel: start cycles of the second workgroup of a CU
+    int no_lean = 0;          // 1: the in-place kernel's E waves use the generic epilogues everywhere (A/B, parity tests)
 };
 
 int parse_tuning(const char* str, Knobs& k) {
@@ -87,7 +88,7 @@ int parse_tuning(const char* str, Knobs& k) {
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
             {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"dw_ksplit", &k.dw_ksplit},
-            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}};
+            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}};
         bool found = false;
         for (auto& t : table)
             if (key == t.name) { *t.dst = val; found = true; }
@@ -1044,6 +1045,11 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     P.lds_red = e->lds_red;
     P.lds_ws_sync = e->lds_ws_sync;
     P.ws_prio = e->knobs.ws_prio;
+    {
+        int widest = e->out_pad;
+        for (int l = 0; l < e->L; ++l) widest = std::max(widest, e->npad[l]);
+        P.lean_ok = e->Bpad < (1 << 24) && (uint64_t)e->Bpad * (uint64_t)widest * 4u < (1ull << 32) && !e->knobs.no_lean;
+    }
     P.err = e->err;
 #ifdef MCPC_STAMPS
     if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * 2 * kMaxWaves * 16); if (rc) return rc; }

@@ -122,6 +122,7 @@ struct KParams {
     const int* wg_rel;               // [gridDim.x] (segments of the cycle spent split) | (segments spent paired) << 16, or null
     int mix_ms, mix_mp;              // steps per segment of a split / a paired unit
     int epart_slots;                 // in-place kernel: energy partials are indexed by 16-chain tile, this many per row
+    int lean_ok;                     // in-place kernel: every [Bpad][npad] image is < 4 GiB and Bpad < 2^24 (32-bit lane offsets)
 #ifdef MCPC_STAMPS
     unsigned long long* dbg;   // diagnostic build only: [nwg][kWaves][16] cycle sums per phase
 #endif
@@ -1071,5 +1072,6 @@ __global__ void mcpc_philox_kernel(uint64_t seed, uint64_t step, int layer, uint
 }  // namespace mcpc
 
 #include "mcpc_steps_ws.h"
+#include "mcpc_ws2_lean.h"
 #include "mcpc_steps_ws2.h"
 #include "mcpc_hebbian.h"

@@ -16,6 +16,7 @@ namespace mcpc {
 constexpr int kWsSpinLimit = 1 << 22;  // iterations (~0.1-0.2 us each): ~0.5 s, far beyond any legitimate wait (< 1 ms)
 
 enum : int { PHF_WS_GEMM = 16, PHF_WS_EPI = 32 };   // which role has work in a table entry
+enum : int { PHF_WS2_HANDOFF = 64 };                // in-place kernel: BWD entry without GEMM whose block (accb) still comes from G
 
 // Everything the two roles hand to each other lives in LDS (global data written by an E wave -- x, spills, energies --
 // is only re-read by the same lane or by later kernels), so the hand-off fences order LDS accesses only: a full

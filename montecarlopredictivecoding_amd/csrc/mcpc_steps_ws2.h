@@ -42,7 +42,6 @@ constexpr int kWs2Pairs = MCPC_WS2_PAIRS;          // (G, E) pairs per workgroup
 constexpr int kWs2NT = MCPC_WS2_SPAN / kWs2Pairs;   // unit tiles per pair per table entry: an entry hands out 16 tiles
 constexpr int kWs2Threads = 2 * kWs2Pairs * 64;
 static_assert(kWs2Pairs == 4 || kWs2Pairs == 8, "4 or 8 pairs");
-enum : int { PHF_WS2_HANDOFF = 64 };   // BWD entry without GEMM whose block (accb) still comes from G
 
 // Diagnostic build variant -DMCPC_STAMPS -DMCPC_STAMPS_ENTRY=q: the 16 slots hold, per TABLE ENTRY p (p < 16),
 //   q = 1: cycles the G wave waits in front of / behind the GEMM of entry p (dep_e, dep_g, dep_se)
@@ -344,6 +343,12 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
     if (P.ws_prio == 1) __builtin_amdgcn_s_setprio(2);
     const int upd_mode = (P.update_x && P.xopt == MCPC_XOPT_SGD)
                              ? (P.noise_mode == MCPC_NOISE_PHILOX ? 2 : (P.noise_mode == MCPC_NOISE_NONE ? 1 : 0)) : 0;
+    // lean epilogues (mcpc_ws2_lean.h): fused SGD update, every chain of the workgroup inside the batch, 32-bit offsets fit
+    const bool lean = upd_mode != 0 && chain0 + 16 * CTT <= P.B && P.lean_ok;
+    LeanLane<CTT> LL;
+    LL.c = c; LL.q = q;
+#pragma unroll
+    for (int ct = 0; ct < CTT; ++ct) { LL.chain[ct] = (uint32_t)(chain0 + 16 * ct + c); LL.lrow[ct] = (uint32_t)(16 * ct + c); }
     STAMP_DECL
     for (int s = 0; s < P.n_steps; ++s) {
         const int t = t_first + s;
@@ -395,6 +400,38 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
             const int kk = (k + ph.rot) & (NW - 1);
             int nt = (ph.ntiles - kk + NW - 1) / NW;
             nt = nt < 0 ? 0 : (nt > kWs2NT ? kWs2NT : nt);
+#ifndef MCPC_EXP_NOLEAN
+            if (lean) {
+                const int act = P.layer[ph.layer].act;
+                const int* const pg = &sync->prog_g[k];
+                const int need = base + p + 1;
+#ifdef MCPC_EXP_NOEPI
+                if (P.n_steps < 0)
+#endif
+                if (ph.type == PH_FWD) {
+                    float esum;
+                    if (act == MCPC_ACT_RELU) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_RELU>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead);
+                    else if (act == MCPC_ACT_TANH) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_TANH>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead);
+                    else esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_IDENTITY>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead);
+                    if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[ph.layer * kMaxWaves + k] += esum; }
+                } else if (ph.type == PH_HEADF) {
+                    float lsum = lean_headf<CTT, NW, NTW>(P, ph, lds, nt, kk, LL, slot, rec_idx, do_energy, pg, need, P.err, dead);
+                    if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[kMaxLatent * kMaxWaves + k] += lsum; }
+                } else if (ph.type == PH_BWD) {
+                    if (upd_mode == 2) {
+                        if (act == MCPC_ACT_RELU) lean_bwd<CTT, NW, NTW, MCPC_ACT_RELU, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
+                        else if (act == MCPC_ACT_TANH) lean_bwd<CTT, NW, NTW, MCPC_ACT_TANH, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
+                        else lean_bwd<CTT, NW, NTW, MCPC_ACT_IDENTITY, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
+                    } else {
+                        if (act == MCPC_ACT_RELU) lean_bwd<CTT, NW, NTW, MCPC_ACT_RELU, false>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
+                        else if (act == MCPC_ACT_TANH) lean_bwd<CTT, NW, NTW, MCPC_ACT_TANH, false>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
+                        else lean_bwd<CTT, NW, NTW, MCPC_ACT_IDENTITY, false>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
+                    }
+                }
+                if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
+                continue;
+            }
+#endif
             f32x4 acc[kWs2NT][CTT], pa[kWs2NT][CTT], pb[kWs2NT][CTT];
 #pragma unroll
             for (int i = 0; i < kWs2NT; ++i)

@@ -1,0 +1,296 @@
+// Lean epilogues of the in-place step kernel's E waves for the paths every script of the reference runs per step:
+// SGD on x with or without the fused Philox kick, fused x update, workgroup fully inside the batch.
+//
+// Why they exist (measured, round 2): on gfx950 the fp32 MFMA and the VALU never co-execute
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0 for this kernel), so every VALU instruction an E wave issues is taken out of its
+// partner's MFMA stream -- the step kernel's time is MFMA cycles + VALU cycles + what neither fills.  With the GEMMs
+// switched off the E waves alone needed 35 us of a 94 us step.  The generic epilogues (mcpc_kernels.h) spend much of
+// their instruction count on things these paths do not need:
+//   * 64-bit per-lane addresses for every access   -> wave-uniform base (SGPR pair) + one 32-bit byte offset per lane:
+//     a row offset per chain tile computed once per entry (v_mul_u32_u24), one v_add per tile;
+//   * per-element `live` / padding / mask predicates -> the workgroup is known to be fully live; padded units and partial
+//     loss masks are handled by a wave-uniform branch on the one tile that has them;
+//   * three loads per slot whatever the entry type   -> each entry type requests exactly its operands.
+// The arithmetic per element is the generic epilogue's, operation for operation: trajectories stay bitwise those of the
+// other kernel forms (tests/test_gpu_fullsize.py::test_workgroup_variants_agree, the mixed-schedule tests).
+#pragma once
+
+namespace mcpc {
+
+typedef const char __attribute__((address_space(1)))* gbytes_t;
+typedef char __attribute__((address_space(1)))* gbytes_w_t;
+
+__device__ __forceinline__ f32x4 gld4(const float* base, uint32_t boff) {
+    return *reinterpret_cast<const gf32x4*>((gbytes_t)base + boff);
+}
+__device__ __forceinline__ f32x4 gld4s(const float* base, uint32_t boff) {
+    return __builtin_nontemporal_load(reinterpret_cast<const gf32x4*>((gbytes_t)base + boff));
+}
+__device__ __forceinline__ void gst4s(float* base, uint32_t boff, f32x4 v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<gf32x4*>((gbytes_w_t)base + boff));
+}
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+
+// per-lane constants of an E wave, fixed for the launch
+template <int CTT>
+struct LeanLane {
+    int c, q;
+    uint32_t chain[CTT];       // global row (chain) of this lane in chain tile ct
+    uint32_t lrow[CTT];        // 16 ct + c: row inside the workgroup's LDS images
+};
+
+// tiles of this wave in an entry: tile(i) = tile0 + kk + NW i, i < nt
+template <int ACT> __device__ __forceinline__ f32x4 act4(f32x4 x) {
+    f32x4 r;
+    r.x = actf<ACT>(x.x); r.y = actf<ACT>(x.y); r.z = actf<ACT>(x.z); r.w = actf<ACT>(x.w);
+    return r;
+}
+
+// ---- FWD entry (layer l): e_l = c_l (x_l - mu_l), energies, E_l -> LDS, Hebbian spills ------------------------------
+// mu_l = acc (from G, in LDS at out_lds) + bias for l >= 1; the constant mu_1 row for l == 0 (no GEMM).
+template <int CTT, int NW, int NTW, int ACT>
+__device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
+                                          int slot, int rec_idx, const int* prog_g, int need, int* err, int& dead) {
+    if (nt <= 0) return 0.f;                  // (a layer with fewer tiles than waves: nothing to load, nothing to wait for)
+    const KLayer& Ly = P.layer[ph.layer];
+    const int l = ph.layer;
+    const bool has_gemm = (ph.flags & PHF_WS_GEMM) && ph.nkb > 0;
+    const uint32_t npad4 = 4u * (uint32_t)Ly.npad;
+    uint32_t rowb[CTT], lrowb[CTT], orowb[CTT];
+#pragma unroll
+    for (int ct = 0; ct < CTT; ++ct) {
+        rowb[ct] = mul24(L.chain[ct], npad4) + 16u * L.q;
+        lrowb[ct] = mul24(L.lrow[ct], 4u * (uint32_t)Ly.ld) + 16u * L.q;
+        orowb[ct] = mul24(L.lrow[ct], 4u * (uint32_t)ph.out_ld) + 16u * L.q;
+    }
+    f32x4 xv[NTW][CTT], bv[NTW][CTT];
+    const float* const bsrc = l == 0 ? P.mu1 : Ly.bias;                  // mu1: a row per chain; bias: one row
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));     // unused slots repeat slot 0
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) {
+            xv[i][ct] = gld4s(Ly.x, rowb[ct] + tb);
+            bv[i][ct] = gld4(bsrc, (l == 0 ? rowb[ct] : 16u * L.q) + tb);
+        }
+    }
+    f32x4 av[NTW][CTT];
+    if (has_gemm) {
+        ws_wait_one(prog_g, need, err, dead);
+        const char* const src = reinterpret_cast<const char*>(lds + ph.out_lds);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));
+#pragma unroll
+            for (int ct = 0; ct < CTT; ++ct) av[i][ct] = *reinterpret_cast<const f32x4*>(src + orowb[ct] + tb);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int ct = 0; ct < CTT; ++ct) av[i][ct] = splat(0.f);
+    }
+    const float ecoef = Ly.ecoef;
+    char* const e_lds = reinterpret_cast<char*>(lds + Ly.lds_e);
+    float* const spill_a = slot >= 0 ? Ly.spill_a + (size_t)slot * P.Bpad * Ly.npad : nullptr;
+    float* const spill_e = slot >= 0 ? (l > 0 ? Ly.spill_e + (size_t)slot * P.Bpad * Ly.npad : Ly.spill_e) : nullptr;
+    float* const rec = (rec_idx >= 0 && Ly.rec != nullptr) ? Ly.rec + (size_t)rec_idx * P.B * Ly.n : nullptr;
+    float esum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        if (i >= nt) continue;
+        const int tile = ph.tile0 + kk + NW * i;
+        const uint32_t tb = 64u * (uint32_t)tile;
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) {
+            const f32x4 x = xv[i][ct];
+            const f32x4 d = x - (av[i][ct] + bv[i][ct]);                  // x - mu
+            const f32x4 e = d * ecoef;
+            if (l > 0) *reinterpret_cast<f32x4*>(e_lds + lrowb[ct] + tb) = e;
+            if (slot >= 0) {
+                gst4s(spill_a, rowb[ct] + tb, act4<ACT>(x));
+                if (l > 0) gst4s(spill_e, rowb[ct] + tb, e);
+                else gst4s(spill_e, rowb[ct] + tb, gld4s(spill_e, rowb[ct] + tb) + e);   // Linear 0: only sum_t e_1 is needed
+            }
+            if (rec != nullptr) st_unpadded(rec, (int)L.chain[ct], Ly.n, 16 * tile + 4 * L.q, x);
+            const f32x4 dd = d * d;
+            esum += 0.5f * ecoef * (dd.x + dd.y + dd.z + dd.w);
+        }
+    }
+    return esum;
+}
+
+// ---- BWD entry (layer l): x_l <- x_l - lr (e_l + sign f'(x_l) back) [+ Philox kick], f(x_l new) -> FX_l ---------------
+// back = acc from G (GEMM over E_{l+1}, or the read-out back-projection handed over in registers); none for sign == 0.
+template <int CTT, int NW, int NTW, int ACT, bool NOISE>
+__device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
+                                         int t, const int* prog_g, int need, int* err, int& dead) {
+    if (nt <= 0) return;
+    const KLayer& Ly = P.layer[ph.layer];
+    const int l = ph.layer, n = Ly.n;
+    const bool from_g = ((ph.flags & PHF_WS_GEMM) && ph.nkb > 0) || (ph.flags & PHF_WS2_HANDOFF);
+    const uint32_t npad4 = 4u * (uint32_t)Ly.npad;
+    uint32_t rowb[CTT], lrowb[CTT], orowb[CTT];
+#pragma unroll
+    for (int ct = 0; ct < CTT; ++ct) {
+        rowb[ct] = mul24(L.chain[ct], npad4) + 16u * L.q;
+        lrowb[ct] = mul24(L.lrow[ct], 4u * (uint32_t)Ly.ld) + 16u * L.q;
+        orowb[ct] = mul24(L.lrow[ct], 4u * (uint32_t)ph.out_ld) + 16u * L.q;
+    }
+    const float ecoef = Ly.ecoef;
+    f32x4 xv[NTW][CTT], ev[NTW][CTT];
+    const char* const e_lds = reinterpret_cast<const char*>(lds + Ly.lds_e);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) {
+            xv[i][ct] = gld4s(Ly.x, rowb[ct] + tb);
+            if (l == 0) ev[i][ct] = (xv[i][ct] - gld4(P.mu1, rowb[ct] + tb)) * ecoef;       // e_1 = c_1 (x_1 - mu_1), mu_1 constant
+            else ev[i][ct] = *reinterpret_cast<const f32x4*>(e_lds + lrowb[ct] + tb);
+        }
+    }
+    f32x4 av[NTW][CTT];
+    if (from_g) {
+        ws_wait_one(prog_g, need, err, dead);
+        const char* const src = reinterpret_cast<const char*>(lds + ph.out_lds);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));
+#pragma unroll
+            for (int ct = 0; ct < CTT; ++ct) av[i][ct] = *reinterpret_cast<const f32x4*>(src + orowb[ct] + tb);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int ct = 0; ct < CTT; ++ct) av[i][ct] = splat(0.f);
+    }
+    const float sign = ph.sign, lr = P.lr, nscale = P.noise_scale;
+    const uint64_t seed = P.seed, step = P.step_base + (uint64_t)t, chain_base = P.chain_base;
+    char* const fx_lds = reinterpret_cast<char*>(lds + Ly.lds_a);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        if (i >= nt) continue;
+        const int tile = ph.tile0 + kk + NW * i;
+        const uint32_t tb = 64u * (uint32_t)tile;
+        const bool pad_tile = 16 * tile + 16 > n;                  // wave-uniform: only the last tile of a ragged layer
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) {
+            const f32x4 x = xv[i][ct], e = ev[i][ct], back = av[i][ct];
+            f32x4 g;
+            g.x = e.x + sign * actd<ACT>(x.x, actf<ACT>(x.x)) * back.x;
+            g.y = e.y + sign * actd<ACT>(x.y, actf<ACT>(x.y)) * back.y;
+            g.z = e.z + sign * actd<ACT>(x.z, actf<ACT>(x.z)) * back.z;
+            g.w = e.w + sign * actd<ACT>(x.w, actf<ACT>(x.w)) * back.w;
+            f32x4 xn = x - g * lr;
+            if constexpr (NOISE)
+                xn = xn + normals4(seed, step, (uint32_t)l, (uint32_t)(chain_base + (uint64_t)L.chain[ct]), (uint32_t)(4 * tile + L.q)) * nscale;
+            if (pad_tile) {       // padded units stay exactly zero (their gradient is zero; only the noise must be masked)
+                const int u0 = 16 * tile + 4 * L.q;
+                if (u0 + 0 >= n) xn.x = 0.f;
+                if (u0 + 1 >= n) xn.y = 0.f;
+                if (u0 + 2 >= n) xn.z = 0.f;
+                if (u0 + 3 >= n) xn.w = 0.f;
+            }
+            gst4s(Ly.x, rowb[ct] + tb, xn);
+            *reinterpret_cast<f32x4*>(fx_lds + lrowb[ct] + tb) = act4<ACT>(xn);      // the next step's GEMMs read f(x_new) from FX_l
+        }
+    }
+}
+
+// ---- HEADF entry (read-out chunk): out = acc + bias, e_o = dL/dout -> ring slot (LDS), loss, spills, output records -----
+template <int CTT, int NW, int NTW>
+__device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
+                                            int slot, int rec_idx, bool do_energy, const int* prog_g, int need, int* err, int& dead) {
+    if (nt <= 0) return 0.f;
+    const KHead& H = P.head;
+    const int kind = H.loss_kind, n = H.n, mask_start = H.mask_start;
+    const uint32_t npad4 = 4u * (uint32_t)H.npad;
+    uint32_t rowb[CTT], orowb[CTT];
+#pragma unroll
+    for (int ct = 0; ct < CTT; ++ct) {
+        rowb[ct] = mul24(L.chain[ct], npad4) + 16u * L.q;
+        orowb[ct] = mul24(L.lrow[ct], 4u * (uint32_t)ph.out_ld) + 16u * L.q;
+    }
+    f32x4 yv[NTW][CTT], bv[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));
+        bv[i] = gld4(H.bias, 16u * L.q + tb);
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) yv[i][ct] = kind != MCPC_LOSS_NONE ? gld4s(H.y, rowb[ct] + tb) : splat(0.f);
+    }
+    ws_wait_one(prog_g, need, err, dead);
+    char* const eo = reinterpret_cast<char*>(lds + ph.out_lds);
+    f32x4 av[NTW][CTT];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const uint32_t cb = 64u * (uint32_t)(kk + NW * (i < nt ? i : 0));               // column inside the chunk
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) av[i][ct] = *reinterpret_cast<const f32x4*>(eo + orowb[ct] + cb);
+    }
+    const float inv_var = H.inv_var;
+    float* const spill = slot >= 0 ? H.spill_e + (size_t)slot * P.Bpad * H.npad : nullptr;
+    float* const rec = (rec_idx >= 0 && H.rec_out != nullptr) ? H.rec_out + (size_t)rec_idx * P.B * H.n : nullptr;
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        if (i >= nt) continue;
+        const int tile = ph.tile0 + kk + NW * i;
+        const uint32_t tb = 64u * (uint32_t)tile, cb = 64u * (uint32_t)(kk + NW * i);
+        const bool inside = 16 * tile >= mask_start && 16 * tile + 16 <= n;        // wave-uniform: every unit of the tile counts
+#pragma unroll
+        for (int ct = 0; ct < CTT; ++ct) {
+            const f32x4 o = av[i][ct] + bv[i];
+            f32x4 e = splat(0.f);
+            if (kind != MCPC_LOSS_NONE) {
+                const f32x4 y = yv[i][ct];
+                const float ov[4] = {o.x, o.y, o.z, o.w}, yy[4] = {y.x, y.y, y.z, y.w};
+                float ev[4];
+                const int u0 = 16 * tile + 4 * L.q;
+                if (kind == MCPC_LOSS_GAUSSIAN) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool on = inside || ((u0 + r) >= mask_start && (u0 + r) < n);
+                        const float dlt = ov[r] - yy[r];
+                        ev[r] = on ? inv_var * dlt : 0.f;
+                        lsum += on ? 0.5f * inv_var * dlt * dlt : 0.f;
+                    }
+                } else if (do_energy) {
+                    if (inside) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float sg, bc;
+                            sigmoid_bce_f(ov[r], yy[r], sg, bc);
+                            ev[r] = sg - yy[r];
+                            lsum += bc;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool on = (u0 + r) >= mask_start && (u0 + r) < n;
+                            float sg, bc;
+                            sigmoid_bce_f(ov[r], yy[r], sg, bc);
+                            ev[r] = on ? sg - yy[r] : 0.f;
+                            lsum += on ? bc : 0.f;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool on = inside || ((u0 + r) >= mask_start && (u0 + r) < n);
+                        ev[r] = on ? sigmoid_f(ov[r]) - yy[r] : 0.f;
+                    }
+                }
+                e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
+            }
+            *reinterpret_cast<f32x4*>(eo + orowb[ct] + cb) = e;
+            if (slot >= 0) gst4s(spill, rowb[ct] + tb, e);
+            if (rec != nullptr) st_unpadded(rec, (int)L.chain[ct], H.n, 16 * tile + 4 * L.q, o);
+        }
+    }
+    return lsum;
+}
+
+}  // namespace mcpc
