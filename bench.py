@@ -39,6 +39,8 @@ N_OUT = 784
 S_MACS = 30 * 256 + 256 * 256 + 256 * 784          # 273 920 MACs per chain per GEMM sweep
 PEAK_FP32_TFLOPS = 157.3                           # MI355X_MICROARCH.md: fp32 MFMA = vector peak
 PEAK_HBM_GBS = 8000.0
+PEAK_L2_GBS = 34500.0                              # MI355X_MICROARCH.md, L2 (per XCD): ~34.5 TB/s aggregate
+FRAG_BYTES_PER_WG_STEP = 2 * 4 * (32 * 256 + 256 * 256 + 256 * 784)   # packed Wf + Wb of the three GEMM Linears (padded): 2.19 MB
 
 
 def make_problem(batch, seed, device):
@@ -191,7 +193,7 @@ def main():
         flops_heb = 2.0 * S_MACS * B     # + the Hebbian sums e^T f(x) on accumulating steps
         bytes_per_step = 7472.0 * B
 
-        def kernel_line(kernel, ms_n_steps, flops_per_step, note):
+        def kernel_line(kernel, ms_n_steps, flops_per_step, note, n_wg):
             ms, n, steps = ms_n_steps
             if not n or not steps:
                 return None
@@ -204,6 +206,10 @@ def main():
                     "flop_per_chain_step": 4 * S_MACS,
                     "hbm_side": {"achieved": bytes_per_step * spl / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "bytes_per_chain_step": 7472},
+                    # every workgroup streams the packed weights (Wf + Wb, 2.19 MB) out of its XCD's L2 once per step
+                    "l2_fragment_stream": {"achieved": n_wg * FRAG_BYTES_PER_WG_STEP * spl / avg_s / 1e9, "peak": PEAK_L2_GBS,
+                                           "unit": "GB/s", "frac": n_wg * FRAG_BYTES_PER_WG_STEP * spl / avg_s / 1e9 / PEAK_L2_GBS,
+                                           "workgroups": n_wg, "bytes_per_workgroup_step": FRAG_BYTES_PER_WG_STEP},
                     "note": note}
 
         # the dominant kernel of the timed call: the step kernel's launches of the plain schedule (in a learning call: the
@@ -213,11 +219,14 @@ def main():
         roof = kernel_line("mcpc::mcpc_steps_ws2_kernel<2, false>" if q["chains_per_wg"] == 32 else q["step_kernel"],
                            plain_l if primary_learning else plain_i, flops_inf,
                            "HIP events around every launch of the plain schedule during the timed "
-                           + ("learning calls (Hebbian stretches; the Hebbian GEMMs of the previous segment run beside it)" if primary_learning else "inference calls"))
+                           + ("learning calls (Hebbian stretches; the Hebbian GEMMs of the previous segment run beside it)" if primary_learning else "inference calls"),
+                           q["n_workgroups"])
         mixed_line = kernel_line("mcpc::mcpc_steps_ws2_kernel<2, true> + <1, true> (mixed 32-/16-chain schedule, two concurrent launches per segment)",
                                  mixed_i if mixed_i is not None else mixed_l, flops_inf,
                                  "HIP events around whole cycles of the mixed schedule during the timed "
-                                 + ("inference-only calls" if mixed_i is not None else "learning calls (mixing steps)"))
+                                 + ("inference-only calls" if mixed_i is not None else "learning calls (mixing steps)"),
+                                 # one workgroup per CU: nwg pairs as 32-chain workgroups minus the split ones, which count twice
+                                 256 if q["n_workgroups"] < 256 else q["n_workgroups"])
         if roof is None:
             roof = mixed_line
         value = world * K * T / dt

@@ -60,6 +60,10 @@ def merge(d, out):
                 if "SQ_INSTS_VALU_MFMA_F32" in c:
                     dv["mfma_f32_insts"] = c["SQ_INSTS_VALU_MFMA_F32"]
                     dv["mfma_ideal_cycles_32_per_inst"] = 32.0 * c["SQ_INSTS_VALU_MFMA_F32"]
+            if c.get("SQ_INSTS_MFMA") and "SQ_INSTS_VALU" in c:
+                dv["valu_insts_per_mfma"] = (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / c["SQ_INSTS_MFMA"]
+            if "SQ_VALU_MFMA_COEXEC_CYCLES" in c:
+                dv["valu_mfma_coexec_cycles"] = c["SQ_VALU_MFMA_COEXEC_CYCLES"]
             if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
                 dv["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
             if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "TCP_TCC_READ_REQ_sum" in c and c["TCP_TOTAL_CACHE_ACCESSES_sum"] > 0:
