@@ -765,10 +765,14 @@ int mcpc_store_adam_state(mcpc_engine* e, float* const* m, float* const* v, void
 namespace {
 
 // How the Hebbian sums of Linear j are computed for `rows` spilled rows: the LDS-tiled kernel (mcpc_hebbian.h) for wide
-// Linears, the register-streaming kernel for narrow ones (few output tiles: HBM-bound whatever the tiling).
+// Linears -- as one or two launches whose error-tile groups cover the output exactly (49 tiles = 17 + 16 + 16) -- the same
+// kernel with the operands swapped for a wide Linear with a narrow input (256 x 32: the narrow side takes the TE slot),
+// and the register-streaming kernel for whatever is left (few output tiles: HBM-bound whatever the tiling).
 struct HebPlan {
-    bool tiled = false;
-    int te = 0, ra = 0, n_mt = 1, n_nt = 1;       // tiled kernel: template choice and tile groups
+    bool tiled = false, swapped = false;
+    int ra = 0;                                    // activation tiles per wave (TA = 8 ra)
+    int te[2] = {0, 0}, n_mt[2] = {0, 0};          // up to two launches: error tiles per group, number of groups
+    int n_nt = 1;
     int wave_tiles = 0;                            // streaming kernel: 64 x 64 wave tiles
     int ksplit = 1, rps = 0;
     int ksplit_cap = 1;                            // upper bound of ksplit that never decreases with `rows`: sizes the slabs
@@ -777,12 +781,26 @@ struct HebPlan {
 HebPlan plan_hebbian(const mcpc_engine* e, int ne, int na, int rows) {
     HebPlan h;
     const int et = ne / 16, at = na / 16;
-    h.tiled = et >= 8 && at % 8 == 0 && (at <= 16 || at % 16 == 0);
-    if (h.tiled) {
-        h.te = et > 16 ? 17 : (et > 8 ? 16 : 8);
+    const bool wide = et >= 8 && at % 8 == 0 && (at <= 16 || at % 16 == 0);
+    const bool narrow_in = !wide && et == 16 && (at == 1 || at == 2 || at == 4);       // e.g. 256 x 32
+    h.tiled = wide || narrow_in;
+    h.swapped = narrow_in;
+    if (wide) {
         h.ra = at >= 16 ? 2 : 1;
-        h.n_mt = (et + h.te - 1) / h.te;
         h.n_nt = at / (8 * h.ra);
+        if (et <= 8) { h.te[0] = 8; h.n_mt[0] = 1; }
+        else if (et <= 16) { h.te[0] = 16; h.n_mt[0] = 1; }
+        else {
+            // et = 17 b + 16 a exactly when b = et mod 16 groups of 17 fit; otherwise groups of 17 with a ragged last one
+            const int b17 = et % 16, a16 = (et - 17 * b17) / 16;
+            if (et - 17 * b17 >= 0) { h.te[0] = 17; h.n_mt[0] = b17; h.te[1] = 16; h.n_mt[1] = a16; }
+            else { h.te[0] = 17; h.n_mt[0] = (et + 16) / 17; }
+            if (h.n_mt[0] == 0) { h.te[0] = h.te[1]; h.n_mt[0] = h.n_mt[1]; h.te[1] = 0; h.n_mt[1] = 0; }
+        }
+    } else if (narrow_in) {
+        h.ra = 2; h.n_nt = 1; h.te[0] = at; h.n_mt[0] = 1;          // E slot = activations (at tiles), A slot = errors (16 tiles)
+    }
+    if (h.tiled) {
         // ~48 stages of 32 rows per workgroup (0.3 ms at cfg-M): short enough that the step kernel's next segment never
         // waits long for CUs, long enough that the slab traffic stays at a few percent of the spill's
         int want = e->knobs.dw_ksplit > 0 ? e->knobs.dw_ksplit : std::max(1, rows / (48 * kHebKB));
@@ -790,7 +808,6 @@ HebPlan plan_hebbian(const mcpc_engine* e, int ne, int na, int rows) {
         h.ksplit_cap = want;
         h.rps = ((rows + want - 1) / want + kHebKB - 1) / kHebKB * kHebKB;
         h.ksplit = (rows + h.rps - 1) / h.rps;
-        // (a multiple of 8 workgroups lets the kernel pair the workgroups of a split on one XCD)
     } else {
         h.wave_tiles = ((ne + 63) / 64) * ((na + 63) / 64);
         int ksplit = std::max(1, std::min(4096 / h.wave_tiles, rows / 64));
@@ -801,18 +818,18 @@ HebPlan plan_hebbian(const mcpc_engine* e, int ne, int na, int rows) {
     return h;
 }
 
-template <int TE, int RA>
+template <int TE, int RA, bool SW = false>
 int launch_heb(const HebArgs& a, hipStream_t stream) {
     constexpr int lds_bytes = 2 * kHebKB * 16 * (TE + 8 * RA) * (int)sizeof(float);
     static bool attr_set[16] = {false};      // per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)mcpc_heb_kernel<TE, RA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)mcpc_heb_kernel<TE, RA, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
             return fail(MCPC_EHIP, "hipFuncSetAttribute failed for the Hebbian kernel");
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((mcpc_heb_kernel<TE, RA>), dim3(a.n_mt * a.n_nt * a.ksplit), dim3(kHebThreads), lds_bytes, stream, a);
+    hipLaunchKernelGGL((mcpc_heb_kernel<TE, RA, SW>), dim3(a.n_mt * a.n_nt * a.ksplit), dim3(kHebThreads), lds_bytes, stream, a);
     return 0;
 }
 
@@ -870,23 +887,37 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
         float* slab_b = slab + (size_t)h.ksplit * ne * na;
         if ((size_t)h.ksplit * ((size_t)ne * na + ne) > ln.slab_floats)
             return fail(MCPC_ESTATE, "internal: Hebbian slabs of Linear %d (%d splits) exceed their allocation", j, h.ksplit);
-        if (h.tiled) {
-            HebArgs a{E, A, slab, slab_b, rows, ne, na, h.rps, h.n_mt, h.n_nt, h.ksplit};
+        if (h.swapped) {
+            // transposed product: the activations take the E slot, the errors the A slot; slab = [split][na][ne]
+            HebArgs a{A, E, slab, slab_b, rows, na, ne, h.rps, 1, 1, h.ksplit, 0};
             int rc = 0;
-            if (h.te == 17 && h.ra == 2) rc = launch_heb<17, 2>(a, stream);
-            else if (h.te == 16 && h.ra == 2) rc = launch_heb<16, 2>(a, stream);
-            else if (h.te == 8 && h.ra == 2) rc = launch_heb<8, 2>(a, stream);
-            else if (h.te == 17) rc = launch_heb<17, 1>(a, stream);
-            else if (h.te == 16) rc = launch_heb<16, 1>(a, stream);
-            else rc = launch_heb<8, 1>(a, stream);
+            if (h.te[0] == 1) rc = launch_heb<1, 2, true>(a, stream);
+            else if (h.te[0] == 2) rc = launch_heb<2, 2, true>(a, stream);
+            else rc = launch_heb<4, 2, true>(a, stream);
             if (rc) return rc;
+        } else if (h.tiled) {
+            int col = 0;
+            for (int part = 0; part < 2; ++part) {
+                if (h.n_mt[part] == 0) continue;
+                HebArgs a{E, A, slab, slab_b, rows, ne, na, h.rps, h.n_mt[part], h.n_nt, h.ksplit, col};
+                int rc = 0;
+                const int te = h.te[part];
+                if (te == 17 && h.ra == 2) rc = launch_heb<17, 2>(a, stream);
+                else if (te == 16 && h.ra == 2) rc = launch_heb<16, 2>(a, stream);
+                else if (te == 8 && h.ra == 2) rc = launch_heb<8, 2>(a, stream);
+                else if (te == 17) rc = launch_heb<17, 1>(a, stream);
+                else if (te == 16) rc = launch_heb<16, 1>(a, stream);
+                else rc = launch_heb<8, 1>(a, stream);
+                if (rc) return rc;
+                col += h.n_mt[part] * te * 16;
+            }
         } else {
             hipLaunchKernelGGL(mcpc_dw_kernel, dim3((h.wave_tiles + 3) / 4, h.ksplit), dim3(256), 0, stream, E, A, slab, slab_b,
                                rows, ne, na, h.rps);
         }
         const float sign = j < e->L ? -1.0f : 1.0f;
-        jobs.job[jobs.n_jobs++] = ReduceJob{slab, ln.G, ne * na, h.ksplit, sign};
-        jobs.job[jobs.n_jobs++] = ReduceJob{slab_b, ln.Gb, ne, h.ksplit, sign};
+        jobs.job[jobs.n_jobs++] = ReduceJob{slab, ln.G, ne * na, h.ksplit, sign, h.swapped ? ne : 0, h.swapped ? na : 0};
+        jobs.job[jobs.n_jobs++] = ReduceJob{slab_b, ln.Gb, ne, h.ksplit, sign, 0, 0};
         max_blocks = std::max(max_blocks, (unsigned)std::min<size_t>(((size_t)ne * na + 255) / 256, 2048));
     }
     if (jobs.n_jobs > 0)

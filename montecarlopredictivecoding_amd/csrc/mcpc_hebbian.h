@@ -31,6 +31,7 @@ struct HebArgs {
     int rows, ne, na;                // rows % 32 == 0; ne, na multiples of 16
     int rows_per_split;              // multiple of 32
     int n_mt, n_nt, ksplit;          // error-tile groups, activation-tile groups, K splits: grid = n_mt * n_nt * ksplit workgroups
+    int e_col_base;                  // first E column of this launch (a Linear may be covered by launches of different TE)
 };
 
 __device__ __forceinline__ void heb_glds16(const float* gsrc, float* lds_dst) {
@@ -38,7 +39,10 @@ __device__ __forceinline__ void heb_glds16(const float* gsrc, float* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int TE, int RA>
+// SWAPPED: the launch computes the TRANSPOSED product for a Linear with a narrow input (the E slot holds its activations,
+// the A slot its errors), so that the narrow operand takes the TE slot; the bias sums (column sums of the errors) then
+// come from the A panel, and the reduction writes the slab back transposed.
+template <int TE, int RA, bool SWAPPED = false>
 __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs P) {
     constexpr int TA = 8 * RA;
     constexpr int LDE = 16 * TE, LDA = 16 * TA;               // panel row lengths (floats)
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
     const int per_split = P.n_mt * P.n_nt;
     const int split = id / per_split, rem = id - split * per_split;
     const int nt = rem / P.n_mt, mt = rem - nt * P.n_mt;
-    const int e_col0 = mt * LDE, a_col0 = nt * LDA;
+    const int e_col0 = P.e_col_base + mt * LDE, a_col0 = nt * LDA;
     const int r0 = split * P.rows_per_split;
     const int r1 = min(P.rows, r0 + P.rows_per_split);
     const int n_stage = (r1 - r0) / kHebKB;
@@ -101,8 +105,10 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
     for (int i = 0; i < TE; ++i)
 #pragma unroll
         for (int j = 0; j < RA; ++j) acc[i][j] = splat(0.f);
-    float bsum = 0.f;                                         // column sum of E for column e_col0 + tid (threads < LDE, nt == 0)
-    const bool does_bias = nt == 0 && tid < LDE;
+    // column sum of the errors: column e_col0 + tid of the E panel (threads < LDE, nt == 0) or, SWAPPED, column
+    // a_col0 + tid of the A panel (threads < LDA, mt == 0)
+    float bsum = 0.f;
+    const bool does_bias = SWAPPED ? (mt == 0 && tid < LDA) : (nt == 0 && tid < LDE);
 
     if (n_stage > 0) issue_stage(0, 0);
     __syncthreads();                                          // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
@@ -140,9 +146,9 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
 #undef HEB_LOAD
 #undef HEB_MFMA
         if (does_bias) {
-            const float* col = lds + buf * STAGE + tid;
+            const float* col = lds + buf * STAGE + (SWAPPED ? kHebKB * LDE : 0) + tid;
 #pragma unroll 8
-            for (int r = 0; r < kHebKB; ++r) bsum += col[r * LDE];
+            for (int r = 0; r < kHebKB; ++r) bsum += col[r * (SWAPPED ? LDA : LDE)];
         }
         __syncthreads();      // stage s+1 has landed (vmcnt(0) in front of the barrier); every wave is done with stage s
     }
@@ -161,7 +167,11 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
             for (int reg = 0; reg < 4; ++reg) out[(size_t)(u0 + reg) * P.na + a] = acc[i][j][reg];
         }
     }
-    if (does_bias && e_col0 + tid < P.ne) P.slab_b[(size_t)split * P.ne + e_col0 + tid] = bsum;
+    if constexpr (SWAPPED) {
+        if (does_bias && a_col0 + tid < P.na) P.slab_b[(size_t)split * P.na + a_col0 + tid] = bsum;
+    } else {
+        if (does_bias && e_col0 + tid < P.ne) P.slab_b[(size_t)split * P.ne + e_col0 + tid] = bsum;
+    }
 }
 
 // ---- fixed-order slab reduction for every Linear of a flush in ONE launch ---------------------------------------------
@@ -170,6 +180,8 @@ struct ReduceJob {
     float* dst;            // [n]
     int n, ksplit;
     float sign;
+    int tr_cols, tr_ld;    // tr_cols > 0: the slab holds the transposed matrix [n / tr_cols][tr_cols]; element idx goes to
+                           // dst[(idx % tr_cols) * tr_ld + idx / tr_cols]
 };
 constexpr int kMaxReduceJobs = 2 * (kMaxLatent + 1);
 struct ReduceJobs {
@@ -193,7 +205,10 @@ __global__ __launch_bounds__(256) void mcpc_reduce_jobs_kernel(const ReduceJobs 
                 for (int k = wv; k < jb.ksplit; k += 4) s += __builtin_nontemporal_load(jb.slab + (size_t)k * n + idx);
             part[wv][lane] = s;
             __syncthreads();
-            if (wv == 0 && idx < jb.n) jb.dst[idx] += jb.sign * ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+            if (wv == 0 && idx < jb.n) {
+                const int di = jb.tr_cols > 0 ? (idx % jb.tr_cols) * jb.tr_ld + idx / jb.tr_cols : idx;
+                jb.dst[di] += jb.sign * ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+            }
             __syncthreads();
         }
         return;
@@ -209,7 +224,8 @@ __global__ __launch_bounds__(256) void mcpc_reduce_jobs_kernel(const ReduceJobs 
             for (int j = 0; j < 8; ++j) s += v[j];
         }
         for (; k < jb.ksplit; ++k) s += __builtin_nontemporal_load(jb.slab + (size_t)k * n + idx);
-        jb.dst[idx] += jb.sign * s;
+        const size_t di = jb.tr_cols > 0 ? (idx % jb.tr_cols) * (size_t)jb.tr_ld + idx / jb.tr_cols : idx;
+        jb.dst[di] += jb.sign * s;
     }
 }
 

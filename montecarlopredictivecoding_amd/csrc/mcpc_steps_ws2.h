@@ -349,6 +349,12 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
     LL.c = c; LL.q = q;
 #pragma unroll
     for (int ct = 0; ct < CTT; ++ct) { LL.chain[ct] = (uint32_t)(chain0 + 16 * ct + c); LL.lrow[ct] = (uint32_t)(16 * ct + c); }
+    // sum_t e_1 of this launch in registers (lean path, top layer of at most one tile per wave, rot == 0 for FWD entries)
+    const bool e0_in_regs = lean && P.layer[0].ntiles <= NW;
+    bool e0_dirty = false;
+    f32x4 e0acc[CTT];
+#pragma unroll
+    for (int ct = 0; ct < CTT; ++ct) e0acc[ct] = splat(0.f);
     STAMP_DECL
     for (int s = 0; s < P.n_steps; ++s) {
         const int t = t_first + s;
@@ -410,9 +416,10 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
 #endif
                 if (ph.type == PH_FWD) {
                     float esum;
-                    if (act == MCPC_ACT_RELU) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_RELU>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead);
-                    else if (act == MCPC_ACT_TANH) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_TANH>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead);
-                    else esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_IDENTITY>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead);
+                    if (ph.layer == 0 && slot >= 0) e0_dirty = true;
+                    if (act == MCPC_ACT_RELU) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_RELU>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead, e0acc, e0_in_regs);
+                    else if (act == MCPC_ACT_TANH) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_TANH>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead, e0acc, e0_in_regs);
+                    else esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_IDENTITY>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead, e0acc, e0_in_regs);
                     if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[ph.layer * kMaxWaves + k] += esum; }
                 } else if (ph.type == PH_HEADF) {
                     float lsum = lean_headf<CTT, NW, NTW>(P, ph, lds, nt, kk, LL, slot, rec_idx, do_energy, pg, need, P.err, dead);
@@ -486,6 +493,7 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
 #endif
         }
     }
+    if (e0_in_regs && e0_dirty) lean_flush_e0<CTT>(P, k, LL, e0acc);      // (FWD entries have rot == 0: this wave's tile is k)
 #ifdef MCPC_STAMPS
     if (lane == 0 && P.dbg != nullptr)
         for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * 8 + wave8) * 16 + i] = st_sum[i];

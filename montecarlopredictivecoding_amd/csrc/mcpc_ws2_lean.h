@@ -31,6 +31,24 @@ __device__ __forceinline__ void gst4s(float* base, uint32_t boff, f32x4 v) {
 }
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 
+// Hebbian spill store: the data is read next by another kernel on other CUs, long after it has left this XCD's L2 --
+// written through with sc1 it does not stay in L2 (MI355X_MICROARCH.md, stores of each flavour), where 5.6 MB of spill
+// per step and XCD otherwise compete with the 2.2 MB of packed weights every workgroup re-reads.
+#ifndef MCPC_SPILL_AUX
+#define MCPC_SPILL_AUX 16          // 16 = sc1; 2 = nt; 17 = sc0 sc1; 0 = plain
+#endif
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void spill_st4(float* base, uint32_t image_bytes, uint32_t boff, f32x4 v) {
+#ifdef MCPC_EXP_NOSPILL        // timing experiment only (wrong Hebbian sums): the spill stores are not issued
+    (void)base; (void)image_bytes; (void)boff; (void)v;
+#elif MCPC_SPILL_AUX < 0
+    gst4s(base, boff, v);
+#else
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)image_bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)boff, 0, MCPC_SPILL_AUX);
+#endif
+}
+
 // per-lane constants of an E wave, fixed for the launch
 template <int CTT>
 struct LeanLane {
@@ -48,9 +66,13 @@ template <int ACT> __device__ __forceinline__ f32x4 act4(f32x4 x) {
 
 // ---- FWD entry (layer l): e_l = c_l (x_l - mu_l), energies, E_l -> LDS, Hebbian spills ------------------------------
 // mu_l = acc (from G, in LDS at out_lds) + bias for l >= 1; the constant mu_1 row for l == 0 (no GEMM).
+// e0acc: Linear 0 sees a constant input, so only sum_t e_1 is needed for its Hebbian sums; when the top layer has at most
+// one tile per wave (n_1 <= 64) the sum of a launch's accumulating steps is kept in registers and added to the global
+// running sum once, after the step loop (lean_flush_e0), instead of a global read-modify-write in every step.
 template <int CTT, int NW, int NTW, int ACT>
 __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
-                                          int slot, int rec_idx, const int* prog_g, int need, int* err, int& dead) {
+                                          int slot, int rec_idx, const int* prog_g, int need, int* err, int& dead,
+                                          f32x4 (&e0acc)[CTT], bool e0_in_regs) {
     if (nt <= 0) return 0.f;                  // (a layer with fewer tiles than waves: nothing to load, nothing to wait for)
     const KLayer& Ly = P.layer[ph.layer];
     const int l = ph.layer;
@@ -95,6 +117,7 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
     float* const spill_a = slot >= 0 ? Ly.spill_a + (size_t)slot * P.Bpad * Ly.npad : nullptr;
     float* const spill_e = slot >= 0 ? (l > 0 ? Ly.spill_e + (size_t)slot * P.Bpad * Ly.npad : Ly.spill_e) : nullptr;
     float* const rec = (rec_idx >= 0 && Ly.rec != nullptr) ? Ly.rec + (size_t)rec_idx * P.B * Ly.n : nullptr;
+    const uint32_t img_bytes = (uint32_t)P.Bpad * npad4;               // one [Bpad][npad] image (lean_ok: < 4 GiB)
     float esum = 0.f;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -108,8 +131,9 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
             const f32x4 e = d * ecoef;
             if (l > 0) *reinterpret_cast<f32x4*>(e_lds + lrowb[ct] + tb) = e;
             if (slot >= 0) {
-                gst4s(spill_a, rowb[ct] + tb, act4<ACT>(x));
-                if (l > 0) gst4s(spill_e, rowb[ct] + tb, e);
+                spill_st4(spill_a, img_bytes, rowb[ct] + tb, act4<ACT>(x));
+                if (l > 0) spill_st4(spill_e, img_bytes, rowb[ct] + tb, e);
+                else if (e0_in_regs) e0acc[ct] = e0acc[ct] + e;                          // (one tile per wave: i == 0 only)
                 else gst4s(spill_e, rowb[ct] + tb, gld4s(spill_e, rowb[ct] + tb) + e);   // Linear 0: only sum_t e_1 is needed
             }
             if (rec != nullptr) st_unpadded(rec, (int)L.chain[ct], Ly.n, 16 * tile + 4 * L.q, x);
@@ -118,6 +142,19 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
         }
     }
     return esum;
+}
+
+// after the step loop: e0sum[chain][unit] += the launch's register sums (wave kk owns tile kk of the top layer)
+template <int CTT>
+__device__ __forceinline__ void lean_flush_e0(const KParams& P, int kk, const LeanLane<CTT>& L, const f32x4 (&e0acc)[CTT]) {
+    const KLayer& Ly = P.layer[0];
+    if (kk >= Ly.ntiles) return;
+    const uint32_t npad4 = 4u * (uint32_t)Ly.npad;
+#pragma unroll
+    for (int ct = 0; ct < CTT; ++ct) {
+        const uint32_t off = mul24(L.chain[ct], npad4) + 16u * L.q + 64u * (uint32_t)kk;
+        gst4s(Ly.spill_e, off, gld4s(Ly.spill_e, off) + e0acc[ct]);
+    }
 }
 
 // ---- BWD entry (layer l): x_l <- x_l - lr (e_l + sign f'(x_l) back) [+ Philox kick], f(x_l new) -> FX_l ---------------
@@ -286,7 +323,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                 e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
             }
             *reinterpret_cast<f32x4*>(eo + orowb[ct] + cb) = e;
-            if (slot >= 0) gst4s(spill, rowb[ct] + tb, e);
+            if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, rowb[ct] + tb, e);
             if (rec != nullptr) st_unpadded(rec, (int)L.chain[ct], H.n, 16 * tile + 4 * L.q, o);
         }
     }
