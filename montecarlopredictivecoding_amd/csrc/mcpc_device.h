@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // same vector in the global address space: loads through it are global_load_* (counted on vmcnt only);
@@ -85,10 +86,23 @@ __device__ __forceinline__ void sigmoid_bce_f(float o, float y, float& sig, floa
     bce = fmaxf(o, 0.0f) - o * y + 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + e);
 }
 
+// Sum over the 64 lanes, returned wave-uniform.  DPP row shifts and row broadcasts (gfx9 family: row_shr:n, row_bcast:15,
+// row_bcast:31) instead of six dependent ds_bpermute round trips through the LDS (~1.1 k cycles of latency per sum on an
+// epilogue wave whose partner streams MFMAs; seven sums per step when energies are recorded): a fixed order, bitwise
+// reproducible, the total lands in lane 63.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    auto dpp_add = [](float x, auto ctrl, auto row_mask) {
+        const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, true);
+        return x + __builtin_bit_cast(float, moved);
+    };
+    using std::integral_constant;
+    v = dpp_add(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});      // row_shr:1
+    v = dpp_add(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});      // row_shr:2
+    v = dpp_add(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});      // row_shr:4
+    v = dpp_add(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});      // row_shr:8  -> lane 15 of a row: its sum
+    v = dpp_add(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});      // row_bcast:15 into rows 1 and 3
+    v = dpp_add(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});      // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
