@@ -68,6 +68,7 @@ struct Knobs {
     int ws_prio = 1;          // 1: epilogue waves at raised priority, 2: GEMM waves, 0: neither
     int stagger = 0;          // barrier kernel: start cycles of the second workgroup of a CU
     int no_lean = 0;          // 1: the in-place kernel's E waves use the generic epilogues everywhere (A/B, parity tests)
+    int no_ybits = 0;         // 1: 0/1 targets are read as fp32 like any other target (A/B, parity tests)
 };
 
 int parse_tuning(const char* str, Knobs& k) {
@@ -88,7 +89,7 @@ int parse_tuning(const char* str, Knobs& k) {
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
             {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"dw_ksplit", &k.dw_ksplit},
-            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}};
+            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}};
         bool found = false;
         for (auto& t : table)
             if (key == t.name) { *t.dst = val; found = true; }
@@ -122,6 +123,9 @@ struct mcpc_engine {
     float* e0sum = nullptr;
     float* mu1 = nullptr;
     float* ypad = nullptr;
+    uint32_t* ybits = nullptr;      // bit-packed copy of a 0/1 target (see mcpc_pack_target_bits_kernel)
+    int* y_binary = nullptr;        // device flag: the bound target is exactly 0/1 everywhere
+    int ywords = 0;
     bool target_bound = false;
     const float* inputs = nullptr;
     // Hebbian spill ring: two halves, the flush of one half runs on `aux` while the step kernel fills the other
@@ -175,7 +179,7 @@ namespace {
 int free_all(mcpc_engine* e) {
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int l = 0; l < kMaxLatent; ++l) { F(e->x[l]); F(e->m[l]); F(e->v[l]); F(e->spill_a[l]); F(e->spill_e[l]); }
-    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err);
+    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err);
     for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : e->events_mix) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -615,6 +619,9 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if (e->has_head) {
         if ((rc = dmalloc(e->ypad, (size_t)e->Bpad * e->out_pad))) return bail(rc);
         if (hipMemset(e->ypad, 0, (size_t)e->Bpad * e->out_pad * 4) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
+        e->ywords = (e->out_pad + 31) / 32;
+        if ((rc = dmalloc(e->ybits, (size_t)e->Bpad * e->ywords)) || (rc = dmalloc(e->y_binary, 2))) return bail(rc);
+        if (hipMemset(e->y_binary, 0, 2 * sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));   // [1] stays 0
     }
     // Linear descriptors + gradient sums
     const int nlin = e->L + (e->has_head ? 1 : 0);
@@ -714,6 +721,10 @@ int mcpc_bind_target(mcpc_engine* e, const float* target, void* stream_) {
     const size_t total = (size_t)e->Bpad * e->out_pad;
     hipLaunchKernelGGL(mcpc_pad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, target, e->ypad,
                        e->d.batch, e->d.n_out, e->Bpad, e->out_pad);
+    // a 0/1 target (the Bernoulli read-out's usual one) is also kept bit-packed; the flag tells the step kernel which to read
+    HIP_TRY(hipMemsetAsync(e->y_binary, 0xff, sizeof(int), (hipStream_t)stream_));
+    hipLaunchKernelGGL(mcpc_pack_target_bits_kernel, dim3(grid_for((size_t)e->Bpad * e->ywords)), dim3(256), 0, (hipStream_t)stream_,
+                       e->ypad, e->ybits, e->y_binary, e->Bpad, e->out_pad, e->ywords);
     HIP_TRY(hipGetLastError());
     e->target_bound = true;
     return MCPC_OK;
@@ -1053,6 +1064,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         KHead& H = P.head;
         const Lin& ln = e->lin[e->L];
         H.Wf = (const f32x4*)ln.Wf; H.Wb = (const f32x4*)ln.Wb; H.bias = ln.bias_pad;
+        H.ybits = e->ybits; H.y_binary = e->knobs.no_ybits ? e->y_binary + 1 : e->y_binary; H.ywords = e->ywords;
         H.y = e->ypad; H.rec_out = r->rec_count > 0 ? r->rec_out : nullptr; H.spill_e = e->spill_eo;
         H.n = e->d.n_out; H.npad = e->out_pad; H.ntiles = e->out_pad / 16;
         H.loss_kind = r->loss_kind;

@@ -47,6 +47,9 @@ struct KHead {
     const f32x4* Wb;       // [ntiles(L-1)][ntiles][64]
     const float* bias;     // [npad]
     const float* y;        // padded target [Bpad][npad]
+    const uint32_t* ybits; // the same bit-packed, [Bpad][ywords] (bit u & 31 of word u >> 5 = y[chain][u]); valid iff *y_binary
+    const int* y_binary;   // device flag set by mcpc_bind_target: every target value is exactly 0.0f or 1.0f
+    int ywords;            // words per chain = ceil(npad / 32)
     float* rec_out;        // [rec_count][B][n] or null
     float* spill_e;        // [slots][Bpad][npad]
     int n, npad, ntiles;
@@ -794,6 +797,28 @@ __global__ void mcpc_pack_kernel(const float* __restrict__ W, const float* __res
     }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < out_tiles * 16) bias_pad[gid] = (bias != nullptr && gid < n_out) ? bias[gid] : 0.f;
+}
+
+// Bit-pack a padded target image [Bpad][npad] whose values are all exactly 0.0f / 1.0f (binarised MNIST, the Bernoulli
+// read-out's usual target): 98 B per chain instead of 3 136 B re-read from HBM in every step.  *flag is cleared by the first
+// value that is neither; the step kernel then reads the fp32 image as before.  One thread per 32-unit word.
+__global__ void mcpc_pack_target_bits_kernel(const float* __restrict__ ypad, uint32_t* __restrict__ bits, int* __restrict__ flag,
+                                             int Bpad, int npad, int ywords) {
+    const size_t total = (size_t)Bpad * ywords;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = idx / ywords, w = idx % ywords;
+        uint32_t word = 0;
+        bool ok = true;
+        for (int j = 0; j < 32; ++j) {
+            const int u = 32 * w + j;
+            if (u >= npad) break;
+            const uint32_t pat = __float_as_uint(ypad[(size_t)row * npad + u]);
+            if (pat == 0x3F800000u) word |= 1u << j;
+            else if (pat != 0u) ok = false;
+        }
+        bits[idx] = word;
+        if (!ok) *flag = 0;
+    }
 }
 
 // dst[Bpad][npad] <- src[B][n] (zero padded)      /     dst[B][n] <- src[Bpad][npad]

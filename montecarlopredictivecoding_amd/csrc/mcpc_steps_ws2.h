@@ -349,6 +349,8 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
     LL.c = c; LL.q = q;
 #pragma unroll
     for (int ct = 0; ct < CTT; ++ct) { LL.chain[ct] = (uint32_t)(chain0 + 16 * ct + c); LL.lrow[ct] = (uint32_t)(16 * ct + c); }
+    // 0/1 targets are read bit-packed (a wave-uniform flag the library set when the target was bound)
+    const bool ybin = lean && P.has_head && *P.head.y_binary != 0;
     // sum_t e_1 of this launch in registers (lean path, top layer of at most one tile per wave, rot == 0 for FWD entries)
     const bool e0_in_regs = lean && P.layer[0].ntiles <= NW;
     bool e0_dirty = false;
@@ -367,8 +369,11 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
             const int kk = (t - P.rec_begin) / P.rec_stride;
             if (kk < P.rec_count && P.rec_begin + kk * P.rec_stride == t) rec_idx = kk;
         }
+        // energies of this step: lane c of every E wave carries the wave's partial sum of column c (layers 0..5, loss) in a
+        // register; the LDS scratch is written once per step, at the ENERGY entry (an LDS read-modify-write behind every
+        // epilogue cost the E waves seven LDS round trips per step)
         float* red = lds + P.lds_red + (s & 1) * (kMaxLatent + 1) * kMaxWaves;
-        if (do_energy && lane <= kMaxLatent) red[lane * kMaxWaves + k] = 0.f;
+        float en_acc = 0.f;
 #pragma unroll 1
         for (int p = 0; p < n_ent; ++p) {
             const KPhase ph = load_phase(P.phases, p);
@@ -377,9 +382,11 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
             unsigned long long ewait = 0;
 #endif
             if (ph.type == PH_ENERGY) {
+                if (do_energy && lane <= kMaxLatent) red[lane * kMaxWaves + k] = en_acc;
+                if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
                 if (do_energy && k == 0) {
-                    // every E wave has finished the entries of this step that add to red[]
-                    ws2_wait_all(sync->prog_e + 0, base + p, P.err, dead);    // own counter equals base + p already
+                    // every E wave has written its partial sums of this step
+                    ws2_wait_all(sync->prog_e + 0, base + p + 1, P.err, dead);
                     if (lane <= kMaxLatent) {
                         double v = 0.0;
                         const bool used = (lane < L) || (lane == kMaxLatent && P.has_head);
@@ -396,7 +403,6 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                         if (CTT == 2) ep[kMaxLatent + 1] = 0.0;
                     }
                 }
-                if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
                 continue;
             }
             if (!(ph.flags & PHF_WS_EPI)) {
@@ -420,10 +426,10 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                     if (act == MCPC_ACT_RELU) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_RELU>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead, e0acc, e0_in_regs);
                     else if (act == MCPC_ACT_TANH) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_TANH>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead, e0acc, e0_in_regs);
                     else esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_IDENTITY>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead, e0acc, e0_in_regs);
-                    if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[ph.layer * kMaxWaves + k] += esum; }
+                    if (do_energy) { esum = wave_sum(esum); if (lane == ph.layer) en_acc += esum; }
                 } else if (ph.type == PH_HEADF) {
-                    float lsum = lean_headf<CTT, NW, NTW>(P, ph, lds, nt, kk, LL, slot, rec_idx, do_energy, pg, need, P.err, dead);
-                    if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[kMaxLatent * kMaxWaves + k] += lsum; }
+                    float lsum = lean_headf<CTT, NW, NTW>(P, ph, lds, nt, kk, LL, slot, rec_idx, do_energy, pg, need, P.err, dead, ybin);
+                    if (do_energy) { lsum = wave_sum(lsum); if (lane == kMaxLatent) en_acc += lsum; }
                 } else if (ph.type == PH_BWD) {
                     if (upd_mode == 2) {
                         if (act == MCPC_ACT_RELU) lean_bwd<CTT, NW, NTW, MCPC_ACT_RELU, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
@@ -476,10 +482,10 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                 if (Ly.act == MCPC_ACT_RELU) esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_RELU, false>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx);
                 else if (Ly.act == MCPC_ACT_TANH) esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_TANH, false>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx);
                 else esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_IDENTITY, false>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx);
-                if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[ph.layer * kMaxWaves + k] += esum; }
+                if (do_energy) { esum = wave_sum(esum); if (lane == ph.layer) en_acc += esum; }
             } else if (ph.type == PH_HEADF) {
                 float lsum = ws2_headf_epilogue<CTT, NW, NTW>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx, do_energy);
-                if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[kMaxLatent * kMaxWaves + k] += lsum; }
+                if (do_energy) { lsum = wave_sum(lsum); if (lane == kMaxLatent) en_acc += lsum; }
             } else if (ph.type == PH_BWD) {
                 if (Ly.act == MCPC_ACT_RELU) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_RELU, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s_tab, t, upd_mode, lds);
                 else if (Ly.act == MCPC_ACT_TANH) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_TANH, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s_tab, t, upd_mode, lds);

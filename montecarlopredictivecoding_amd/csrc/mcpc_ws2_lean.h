@@ -31,11 +31,12 @@ __device__ __forceinline__ void gst4s(float* base, uint32_t boff, f32x4 v) {
 }
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 
-// Hebbian spill store: the data is read next by another kernel on other CUs, long after it has left this XCD's L2 --
-// written through with sc1 it does not stay in L2 (MI355X_MICROARCH.md, stores of each flavour), where 5.6 MB of spill
-// per step and XCD otherwise compete with the 2.2 MB of packed weights every workgroup re-reads.
+// Hebbian spill store through a buffer descriptor (wave-uniform base, 32-bit lane offset, selectable cache policy).  The
+// data is read next by another kernel on other CUs, so write-through / no-allocate policies were tried to keep the 5.6 MB
+// of spill per step and XCD out of the L2 that holds the 2.2 MB of packed weights: they measured 0.4 us per step SLOWER than
+// plain write-back stores (a wave's loads wait for its older stores in vmcnt order, and write-back stores retire sooner).
 #ifndef MCPC_SPILL_AUX
-#define MCPC_SPILL_AUX 16          // 16 = sc1; 2 = nt; 17 = sc0 sc1; 0 = plain
+#define MCPC_SPILL_AUX 0           // 0 = plain (write-back); 2 = nt; 16 = sc1; 17 = sc0 sc1: within 0.5 us per step of each other, plain fastest
 #endif
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void spill_st4(float* base, uint32_t image_bytes, uint32_t boff, f32x4 v) {
@@ -92,7 +93,11 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
         const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));     // unused slots repeat slot 0
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
+#ifdef MCPC_EXP_NOX       // timing experiment only (wrong results): the state is neither loaded nor stored
+            xv[i][ct] = splat(0.5f);
+#else
             xv[i][ct] = gld4s(Ly.x, rowb[ct] + tb);
+#endif
             bv[i][ct] = gld4(bsrc, (l == 0 ? rowb[ct] : 16u * L.q) + tb);
         }
     }
@@ -182,7 +187,11 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
         const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
+#ifdef MCPC_EXP_NOX
+            xv[i][ct] = splat(0.5f);
+#else
             xv[i][ct] = gld4s(Ly.x, rowb[ct] + tb);
+#endif
             if (l == 0) ev[i][ct] = (xv[i][ct] - gld4(P.mu1, rowb[ct] + tb)) * ecoef;       // e_1 = c_1 (x_1 - mu_1), mu_1 constant
             else ev[i][ct] = *reinterpret_cast<const f32x4*>(e_lds + lrowb[ct] + tb);
         }
@@ -230,7 +239,9 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
                 if (u0 + 2 >= n) xn.z = 0.f;
                 if (u0 + 3 >= n) xn.w = 0.f;
             }
+#ifndef MCPC_EXP_NOX
             gst4s(Ly.x, rowb[ct] + tb, xn);
+#endif
             *reinterpret_cast<f32x4*>(fx_lds + lrowb[ct] + tb) = act4<ACT>(xn);      // the next step's GEMMs read f(x_new) from FX_l
         }
     }
@@ -239,7 +250,8 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
 // ---- HEADF entry (read-out chunk): out = acc + bias, e_o = dL/dout -> ring slot (LDS), loss, spills, output records -----
 template <int CTT, int NW, int NTW>
 __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
-                                            int slot, int rec_idx, bool do_energy, const int* prog_g, int need, int* err, int& dead) {
+                                            int slot, int rec_idx, bool do_energy, const int* prog_g, int need, int* err, int& dead,
+                                            bool ybin) {
     if (nt <= 0) return 0.f;
     const KHead& H = P.head;
     const int kind = H.loss_kind, n = H.n, mask_start = H.mask_start;
@@ -251,12 +263,27 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
         orowb[ct] = mul24(L.lrow[ct], 4u * (uint32_t)ph.out_ld) + 16u * L.q;
     }
     f32x4 yv[NTW][CTT], bv[NTW];
+    uint32_t yw[NTW][CTT];                                   // ybin: the word of the bit-packed target that holds this lane's four units
+    const uint32_t wrow4 = 4u * (uint32_t)H.ywords;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));
+        const int tile = ph.tile0 + kk + NW * (i < nt ? i : 0);
+        const uint32_t tb = 64u * (uint32_t)tile;
         bv[i] = gld4(H.bias, 16u * L.q + tb);
 #pragma unroll
-        for (int ct = 0; ct < CTT; ++ct) yv[i][ct] = kind != MCPC_LOSS_NONE ? gld4s(H.y, rowb[ct] + tb) : splat(0.f);
+        for (int ct = 0; ct < CTT; ++ct) {
+            // Branch-free on purpose (a load under an `if` makes hipcc join the paths behind `s_waitcnt vmcnt(0)`, which here
+            // would also wait for every spill store still in flight): both loads are always issued; the one that is not
+            // needed reads a harmless hot address (the bias row again / the word array, which always exists).
+#ifdef MCPC_EXP_NOY        // (timing experiment only, wrong results: targets are not loaded)
+            yv[i][ct] = splat(0.f); yw[i][ct] = 0u;
+#else
+            const bool fp32_y = kind != MCPC_LOSS_NONE && !ybin;
+            yv[i][ct] = gld4s(fp32_y ? H.y : H.bias, fp32_y ? rowb[ct] + tb : 16u * L.q + tb);
+            yw[i][ct] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(
+                (gbytes_t)H.ybits + mul24(L.chain[ct], wrow4) + 4u * (uint32_t)(tile >> 1));
+#endif
+        }
     }
     ws_wait_one(prog_g, need, err, dead);
     char* const eo = reinterpret_cast<char*>(lds + ph.out_lds);
@@ -282,7 +309,11 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
             const f32x4 o = av[i][ct] + bv[i];
             f32x4 e = splat(0.f);
             if (kind != MCPC_LOSS_NONE) {
-                const f32x4 y = yv[i][ct];
+                f32x4 y = yv[i][ct];
+                if (ybin) {                                     // units 16 tile + 4 q .. + 3: a nibble of the word
+                    const uint32_t nib = yw[i][ct] >> (16u * (uint32_t)(tile & 1) + 4u * (uint32_t)L.q);
+                    y.x = (float)(nib & 1u); y.y = (float)((nib >> 1) & 1u); y.z = (float)((nib >> 2) & 1u); y.w = (float)((nib >> 3) & 1u);
+                }
                 const float ov[4] = {o.x, o.y, o.z, o.w}, yy[4] = {y.x, y.y, y.z, y.w};
                 float ev[4];
                 const int u0 = 16 * tile + 4 * L.q;

@@ -280,6 +280,29 @@ def test_mixed_schedule_with_per_step_tables(mode, monkeypatch):
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-6)
 
 
+def test_lean_epilogues_and_bitpacked_targets_change_nothing():
+    """The E waves' lean epilogues (32-bit lane offsets, uniform fast paths) and the bit-packed copy of a 0/1 target are
+    different code for the same arithmetic: states, records, energies and Hebbian sums are BITWISE those of the generic
+    epilogues reading the fp32 target -- except dF/db of Linear 0, whose sum over the steps of a launch the lean path keeps in
+    registers (one association more than adding every step to the running sum in memory: last-bit differences)."""
+    W, b, y, xs = _problem()
+    outs = []
+    for tuning in (None, "no_ybits=1", "no_lean=1"):
+        eng = _engine(B, W, b, y, tuning=tuning)
+        res, out = _run(eng, xs, 90, acc_begin=20, acc_end=90, rec_begin=0, rec_stride=30, rec_count=3, rec_x=True)
+        outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x],
+                     eng.read_param_grads_flat().cpu().numpy()))
+        eng.close()
+    for k in (1, 2):
+        assert np.array_equal(outs[0][0], outs[k][0])
+        for a, c in zip(outs[0][1] + outs[0][2], outs[k][1] + outs[k][2]):
+            assert np.array_equal(a, c)
+        n_w0, n_b0 = 30 * 30, 30
+        assert np.array_equal(outs[0][3][:n_w0], outs[k][3][:n_w0]) and np.array_equal(outs[0][3][n_w0 + n_b0:], outs[k][3][n_w0 + n_b0:])
+        np.testing.assert_allclose(outs[0][3][n_w0:n_w0 + n_b0], outs[k][3][n_w0:n_w0 + n_b0], rtol=1e-6)
+    assert np.array_equal(outs[0][3], outs[1][3])            # bit-packed vs fp32 target: everything identical
+
+
 def test_pc_path_is_bitwise_reproducible_and_descends():
     """cfg-PC: noise = 0.  Two runs are bit-identical (energies included: fixed-order reductions, no float atomics),
     and F = loss + energy never increases under plain gradient descent with a small step."""
