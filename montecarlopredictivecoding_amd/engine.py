@@ -146,8 +146,12 @@ class Engine:
             ext_noise: Optional[Sequence[torch.Tensor]] = None,
             acc_begin=0, acc_end=0, acc_reset=True,
             energy_mode=L.ENERGY_NONE, energies_out: Optional[torch.Tensor] = None,
-            rec_begin=0, rec_stride=1, rec_count=0, rec_x=False, rec_out=False) -> RunResult:
-        """``rec_x``: bool, or one bool per latent layer (record only those layers)."""
+            rec_begin=0, rec_stride=1, rec_count=0, rec_x=False, rec_out=False,
+            rec_x_bufs: Optional[Sequence[Optional[torch.Tensor]]] = None,
+            rec_out_buf: Optional[torch.Tensor] = None) -> RunResult:
+        """``rec_x``: bool, or one bool per latent layer (record only those layers).  ``rec_x_bufs`` / ``rec_out_buf``:
+        caller-owned record buffers ``[>= rec_count][batch][n]`` to write into (a ring that is drained to host memory while
+        the next slice of the call runs) instead of fresh allocations."""
         n_steps = T - t_begin if n_steps is None else n_steps
         r = L.RunDesc()
         r.T, r.t_begin, r.n_steps = T, t_begin, n_steps
@@ -183,13 +187,21 @@ class Engine:
             want = [bool(rec_x)] * self.L if isinstance(rec_x, bool) else [bool(v) for v in rec_x]
             for l in range(self.L):
                 if want[l]:
-                    t = torch.empty(rec_count, self.batch, self.sizes[l], dtype=torch.float32, device=self.device)
+                    if rec_x_bufs is not None and rec_x_bufs[l] is not None:
+                        t = rec_x_bufs[l][:rec_count]
+                        _check_tensor(t, (rec_count, self.batch, self.sizes[l]), self.device, f"rec_x_bufs[{l}]")
+                    else:
+                        t = torch.empty(rec_count, self.batch, self.sizes[l], dtype=torch.float32, device=self.device)
                     res.rec_x.append(t)
                     r.rec_x[l] = t.data_ptr()
                 else:
                     res.rec_x.append(None)
             if rec_out and self.n_out > 0:
-                res.rec_out = torch.empty(rec_count, self.batch, self.n_out, dtype=torch.float32, device=self.device)
+                if rec_out_buf is not None:
+                    res.rec_out = rec_out_buf[:rec_count]
+                    _check_tensor(res.rec_out, (rec_count, self.batch, self.n_out), self.device, "rec_out_buf")
+                else:
+                    res.rec_out = torch.empty(rec_count, self.batch, self.n_out, dtype=torch.float32, device=self.device)
                 r.rec_out = res.rec_out.data_ptr()
         if not update_x:
             for l in range(self.L):

@@ -158,6 +158,11 @@ class PCTrainer(object):
         self.mcpc_sharded = False
         self.mcpc_materialize_unused_grads = False   # reference quirk: autograd fills .grad even if never used
         self.last_call_mode = None            # 'fused' | 'stepwise' (for tests / diagnostics)
+        # trajectories larger than this (bytes of host-bound records per call) are recorded slice by slice into a
+        # two-buffer device ring that is drained to pinned host memory while the next slice runs (figure_5 pulls
+        # 10 000 steps x all latents to the host, pc_trainer.py:440-445,772-774)
+        self.mcpc_record_chunk_bytes = 1 << 30
+        self.last_record_slices = 0
 
     # ---- getters & setters (reference :268-461) -------------------------------------------------------
     def get_T(self) -> int:
@@ -593,16 +598,22 @@ class PCTrainer(object):
         if is_return_outputs and net.n_out == 0:
             rec_layers[-1] = True
         any_rec = any(rec_layers) or (is_return_outputs and net.n_out > 0)
-        res = eng.run(
-            T, loss_kind=loss.kind, loss_var=loss.var, mask_start=loss.mask_start,
+        run_kw = dict(
+            loss_kind=loss.kind, loss_var=loss.var, mask_start=loss.mask_start,
             xopt=xopt.kind, lr=xopt.lr, betas=xopt.betas, eps=xopt.eps,
             noise_mode=L.NOISE_PHILOX if plan["noise_var"] is not None else L.NOISE_NONE,
             noise_var=0.0 if plan["noise_var"] is None else plan["noise_var"],
             seed=self.mcpc_seed, step_base=_take_philox_steps(T), chain_base=self.mcpc_chain_base,
-            acc_begin=acc_begin, acc_end=acc_end, acc_reset=acc_reset,
-            energy_mode=L.ENERGY_ALL if is_return_results_every_t else L.ENERGY_LAST,
-            rec_begin=rec_begin, rec_stride=1, rec_count=n_rec if any_rec else 0,
-            rec_x=rec_layers, rec_out=is_return_outputs and net.n_out > 0)
+            acc_begin=acc_begin, acc_end=acc_end,
+            energy_mode=L.ENERGY_ALL if is_return_results_every_t else L.ENERGY_LAST)
+        host_step_bytes = 4 * plan["B"] * sum(n for n, on in zip(net.sizes, rec_layers) if on)
+        self.last_record_slices = 0
+        if any(rec_layers) and n_rec == T and T * host_step_bytes > self.mcpc_record_chunk_bytes:
+            res = self._run_fused_sliced(eng, net, plan, T, run_kw, acc_reset, rec_layers, host_step_bytes,
+                                         is_return_outputs and net.n_out > 0)
+        else:
+            res = eng.run(T, acc_reset=acc_reset, rec_begin=rec_begin, rec_stride=1, rec_count=n_rec if any_rec else 0,
+                          rec_x=rec_layers, rec_out=is_return_outputs and net.n_out > 0, **run_kw)
         eng.store_state([x.data for x in xs])
         if xopt.kind == L.XOPT_ADAM and isinstance(self._optimizer_x, optim.Adam):
             # the reference's optimizer_x object outlives the call (pc_trainer.py:742-752 recreates it only behind a flag):
@@ -625,6 +636,47 @@ class PCTrainer(object):
                                      accumulate=start is None)
         return self._collect_results(plan, res, T, is_return_results_every_t, is_return_outputs,
                                      is_return_representations, is_return_xs, loss_fn)
+
+    def _run_fused_sliced(self, eng, net, plan, T, run_kw, acc_reset, rec_layers, host_step_bytes, rec_out):
+        """A call whose every-step trajectory would not fit the record budget on the device: the same T steps as slices of
+        one `mcpc_run` each (slicing does not change a bit of the trajectories, tests/test_gpu_fullsize.py), the latent
+        records of a slice go to one half of a two-buffer device ring and are copied to pinned host memory on a side stream
+        while the next slice computes.  Outputs stay on the device, as in the reference (live tensors, pc_trainer.py:733,770)."""
+        from ..engine import RunResult
+        dev, B = plan["device"], plan["B"]
+        S = max(1, min(T, self.mcpc_record_chunk_bytes // max(2 * host_step_bytes, 1)))
+        host = [torch.empty(T, B, n, dtype=torch.float32, pin_memory=True) if on else None for n, on in zip(net.sizes, rec_layers)]
+        ring = [[torch.empty(S, B, n, dtype=torch.float32, device=dev) if on else None for n, on in zip(net.sizes, rec_layers)]
+                for _ in range(2)]
+        out_full = torch.empty(T, B, net.n_out, dtype=torch.float32, device=dev) if rec_out else None
+        energies = torch.zeros(T, L.ENERGY_COLS, dtype=torch.float64, device=dev)
+        main, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+        drained = [None, None]                              # event: the copy out of this half of the ring has finished
+        acc_b = run_kw["acc_begin"]
+        run_kw = dict(run_kw, energy_mode=L.ENERGY_ALL)
+        n_slices = 0
+        for t0 in range(0, T, S):
+            n = min(S, T - t0)
+            half = n_slices & 1
+            if drained[half] is not None:
+                main.wait_event(drained[half])
+            eng.run(T, t_begin=t0, n_steps=n, adam_step0=t0, energies_out=energies,
+                    acc_reset=acc_reset and (t0 <= acc_b < t0 + n),
+                    rec_begin=t0, rec_stride=1, rec_count=n, rec_x=rec_layers, rec_x_bufs=ring[half],
+                    rec_out=rec_out, rec_out_buf=None if out_full is None else out_full[t0:t0 + n], **run_kw)
+            filled = torch.cuda.Event()
+            filled.record(main)
+            side.wait_event(filled)
+            with torch.cuda.stream(side):
+                for h, d in zip(host, ring[half]):
+                    if h is not None:
+                        h[t0:t0 + n].copy_(d[:n], non_blocking=True)
+                drained[half] = torch.cuda.Event()
+                drained[half].record(side)
+            n_slices += 1
+        side.synchronize()
+        self.last_record_slices = n_slices
+        return RunResult(energies=energies, rec_x=host, rec_out=out_full)
 
     # ---- step-wise path -------------------------------------------------------------------------------------
     def _run_stepwise(self, plan, inputs, loss_fn, is_sample_x_at_batch_start, is_reset_optimizer_x_at_batch_start,

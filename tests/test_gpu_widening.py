@@ -209,3 +209,48 @@ def test_shipped_checkpoint_map_energies_match_reference():
     np.testing.assert_allclose(res["overall"], z["overall"], rtol=3e-5)
     for l, x in enumerate(tr.get_model_xs()):
         np.testing.assert_allclose(x.detach().cpu().numpy(), z[f"x_final_l{l}"], rtol=0, atol=3e-4)
+
+
+def test_long_trajectories_are_recorded_in_slices_through_a_device_ring():
+    """figure_2 / figure_5 pull every step of all latents to the host (pc_trainer.py:440-445,772-774).
+    Above `mcpc_record_chunk_bytes` the fused call runs as slices whose records go through a two-buffer device ring to pinned
+    host memory on a side stream; energies, every recorded state, outputs and the final state must be bitwise those of the
+    one-launch call, the Hebbian sums equal up to the grouping of their fp32 partial sums."""
+    um, cfg, model, loader, pc_tr, _ = _setup()
+    from montecarlopredictivecoding_amd.utils.training_evaluation import get_mcpc_trainer
+    cfg = dict(cfg, mixing=20, sampling=37)
+    data = (torch.rand(16, 64, generator=torch.Generator().manual_seed(1)) < 0.3).float().to(DEV)
+    inputs = torch.zeros(16, 8, device=DEV)
+    x0 = [torch.rand(16, n, generator=torch.Generator().manual_seed(70 + i)).to(DEV) for i, n in enumerate((8, 32, 32))]
+    import montecarlopredictivecoding_amd.predictive_coding.pc_trainer as pt
+    outs = []
+    for chunk in (1 << 30, 16 * (8 + 32 + 32) * 4 * 10):          # one launch / slices of 5 steps (ring halves of 5)
+        for layer, x in zip([m for m in model if hasattr(m, "get_x")], x0):
+            layer._sample_x_fn = lambda inp, _x=x: _x.clone()
+        tr = get_mcpc_trainer(model, cfg, training=False)
+        tr.mcpc_materialize_unused_grads = True
+        tr.mcpc_record_chunk_bytes = chunk
+        base = pt._PHILOX_STEPS[0]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = tr.train_on_batch(inputs=inputs, loss_fn=um.bernoulli_fn, loss_fn_kwargs={"_target": data, "_var": None},
+                                  callback_after_t=um.random_step, callback_after_t_kwargs={"_pc_trainer": tr},
+                                  is_log_progress=False, is_return_results_every_t=True, is_return_xs=True, is_return_outputs=True)
+        pt._PHILOX_STEPS[0] = base                                   # the second run replays the same noise
+        outs.append((r, [x.detach().clone() for x in tr.get_model_xs()], tr.last_record_slices,
+                     [m.weight.grad.clone() for m in model if isinstance(m, torch.nn.Linear)]))
+        for m in model:
+            if isinstance(m, torch.nn.Linear):
+                m.weight.grad = None; m.bias.grad = None
+    (ra, xa, sa, ga), (rb, xb, sb, gb) = outs
+    assert sa == 0 and sb == 12                                      # 57 steps in slices of 5
+    assert ra["overall"] == rb["overall"] and ra["loss"] == rb["loss"]
+    assert len(rb["xs"]) == 57 and all(not t.is_cuda for t in rb["xs"][3])
+    for t in range(57):
+        for p, q in zip(ra["xs"][t], rb["xs"][t]):
+            assert torch.equal(p, q)
+        assert torch.equal(ra["outputs"][t], rb["outputs"][t])
+    for p, q in zip(xa, xb):
+        assert torch.equal(p, q)
+    for p, q in zip(ga, gb):                                          # Hebbian sums: one flush per slice regroups the fp32 sums
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-5 * float(p.abs().max()))
