@@ -65,6 +65,14 @@ __device__ __forceinline__ float act_d(int a, float x, float fx) {
     return a == 1 ? (x > 0.0f ? 1.0f : 0.0f) : (a == 2 ? 1.0f - fx * fx : 1.0f);
 }
 
+// Adam's x update, x - step_size * m / (sqrt(v) / sqrt(bias2) + eps) (torch.optim.Adam: addcdiv_), with v_sqrt_f32 and
+// v_rcp_f32 (1 ulp each) instead of the IEEE-refined sqrtf and division: those cost ~27 VALU instructions per element, 16 us of
+// a 109 us MAP step at cfg-M (fp32 MFMA and VALU share one pipe).  The denominator is >= eps, far inside the normal range;
+// a denormal v (|g| < 1e-19) is below eps by 11 orders of magnitude either way.
+__device__ __forceinline__ float adam_x(float x, float m, float v, float step_size, float inv_bc2, float eps) {
+    return x - step_size * (m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * inv_bc2 + eps));
+}
+
 __device__ __forceinline__ float sigmoid_f(float o) {
     // same arithmetic as sigmoid_bce_f below, so that recording the loss never changes a trajectory
     const float e = __builtin_amdgcn_exp2f(-fabsf(o) * 1.4426950408889634f);  // exp(-|o|)

@@ -593,17 +593,17 @@ __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph,
                 if (P.xopt == MCPC_XOPT_SGD) {
                     xn = x - g * lr;
                 } else {
-                    // torch.optim.Adam single-tensor path: lerp_, mul_/addcmul_, sqrt/bias2 + eps, addcdiv_
+                    // torch.optim.Adam single-tensor path: lerp_, mul_/addcmul_, sqrt/bias2 + eps, addcdiv_ (adam_x, mcpc_device.h)
                     f32x4 m = ld4s(Ly.m + row), v = ld4s(Ly.v + row);
                     m = m + (g - m) * P.omb1;
                     v = v * P.beta2 + (g * g) * P.omb2;
                     st4s(Ly.m + row, m);
                     st4s(Ly.v + row, v);
                     const float step_size = P.adam_coef[2 * s], inv_bc2 = P.adam_coef[2 * s + 1], eps = P.eps;
-                    xn.x = x.x - step_size * (m.x / (__builtin_sqrtf(v.x) * inv_bc2 + eps));
-                    xn.y = x.y - step_size * (m.y / (__builtin_sqrtf(v.y) * inv_bc2 + eps));
-                    xn.z = x.z - step_size * (m.z / (__builtin_sqrtf(v.z) * inv_bc2 + eps));
-                    xn.w = x.w - step_size * (m.w / (__builtin_sqrtf(v.w) * inv_bc2 + eps));
+                    xn.x = adam_x(x.x, m.x, v.x, step_size, inv_bc2, eps);
+                    xn.y = adam_x(x.y, m.y, v.y, step_size, inv_bc2, eps);
+                    xn.z = adam_x(x.z, m.z, v.z, step_size, inv_bc2, eps);
+                    xn.w = adam_x(x.w, m.w, v.w, step_size, inv_bc2, eps);
                 }
                 if (P.noise_mode == MCPC_NOISE_PHILOX) {
                     xn = xn + normals4(seed, step, (uint32_t)l, (uint32_t)(chain_base + (uint64_t)chain), (uint32_t)(u0 >> 2)) * nscale;

@@ -343,8 +343,10 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
     if (P.ws_prio == 1) __builtin_amdgcn_s_setprio(2);
     const int upd_mode = (P.update_x && P.xopt == MCPC_XOPT_SGD)
                              ? (P.noise_mode == MCPC_NOISE_PHILOX ? 2 : (P.noise_mode == MCPC_NOISE_NONE ? 1 : 0)) : 0;
-    // lean epilogues (mcpc_ws2_lean.h): fused SGD update, every chain of the workgroup inside the batch, 32-bit offsets fit
-    const bool lean = upd_mode != 0 && chain0 + 16 * CTT <= P.B && P.lean_ok;
+    // lean epilogues (mcpc_ws2_lean.h): fused SGD update (or Adam without noise: the MAP warm-up), every chain of the
+    // workgroup inside the batch, 32-bit offsets fit
+    const bool lean_adam = P.update_x && P.xopt == MCPC_XOPT_ADAM && P.noise_mode == MCPC_NOISE_NONE;
+    const bool lean = (upd_mode != 0 || lean_adam) && chain0 + 16 * CTT <= P.B && P.lean_ok;
     LeanLane<CTT> LL;
     LL.c = c; LL.q = q;
 #pragma unroll
@@ -431,7 +433,11 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                     float lsum = lean_headf<CTT, NW, NTW>(P, ph, lds, nt, kk, LL, slot, rec_idx, do_energy, pg, need, P.err, dead, ybin);
                     if (do_energy) { lsum = wave_sum(lsum); if (lane == kMaxLatent) en_acc += lsum; }
                 } else if (ph.type == PH_BWD) {
-                    if (upd_mode == 2) {
+                    if (lean_adam) {
+                        if (act == MCPC_ACT_RELU) lean_bwd<CTT, NW, NTW, MCPC_ACT_RELU, false, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead, s_tab);
+                        else if (act == MCPC_ACT_TANH) lean_bwd<CTT, NW, NTW, MCPC_ACT_TANH, false, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead, s_tab);
+                        else lean_bwd<CTT, NW, NTW, MCPC_ACT_IDENTITY, false, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead, s_tab);
+                    } else if (upd_mode == 2) {
                         if (act == MCPC_ACT_RELU) lean_bwd<CTT, NW, NTW, MCPC_ACT_RELU, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
                         else if (act == MCPC_ACT_TANH) lean_bwd<CTT, NW, NTW, MCPC_ACT_TANH, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
                         else lean_bwd<CTT, NW, NTW, MCPC_ACT_IDENTITY, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);

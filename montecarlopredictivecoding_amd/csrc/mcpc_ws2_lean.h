@@ -164,9 +164,14 @@ __device__ __forceinline__ void lean_flush_e0(const KParams& P, int kk, const Le
 
 // ---- BWD entry (layer l): x_l <- x_l - lr (e_l + sign f'(x_l) back) [+ Philox kick], f(x_l new) -> FX_l ---------------
 // back = acc from G (GEMM over E_{l+1}, or the read-out back-projection handed over in registers); none for sign == 0.
-template <int CTT, int NW, int NTW, int ACT, bool NOISE>
+// ADAM (the MAP warm-up, torch.optim.Adam on x without noise): the moments m, v of the wave's tiles are requested with x,
+// in front of the wait for the partner's block -- the generic epilogue loads them behind it, one L2/HBM round trip exposed
+// per x update -- and the arithmetic is the generic epilogue's, operation for operation (s_tab: row of the bias-correction
+// table).
+template <int CTT, int NW, int NTW, int ACT, bool NOISE, bool ADAM = false>
 __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
-                                         int t, const int* prog_g, int need, int* err, int& dead) {
+                                         int t, const int* prog_g, int need, int* err, int& dead, int s_tab = 0) {
+    static_assert(!(NOISE && ADAM), "Adam with the fused kick takes the generic epilogue");
     if (nt <= 0) return;
     const KLayer& Ly = P.layer[ph.layer];
     const int l = ph.layer, n = Ly.n;
@@ -181,6 +186,7 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
     }
     const float ecoef = Ly.ecoef;
     f32x4 xv[NTW][CTT], ev[NTW][CTT];
+    f32x4 mv[ADAM ? NTW : 1][CTT], vv[ADAM ? NTW : 1][CTT];
     const char* const e_lds = reinterpret_cast<const char*>(lds + Ly.lds_e);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -192,8 +198,12 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
 #else
             xv[i][ct] = gld4s(Ly.x, rowb[ct] + tb);
 #endif
+            if constexpr (ADAM) {
+                mv[i][ct] = gld4s(Ly.m, rowb[ct] + tb);
+                vv[i][ct] = gld4s(Ly.v, rowb[ct] + tb);
+            }
             if (l == 0) ev[i][ct] = (xv[i][ct] - gld4(P.mu1, rowb[ct] + tb)) * ecoef;       // e_1 = c_1 (x_1 - mu_1), mu_1 constant
-            else ev[i][ct] = *reinterpret_cast<const f32x4*>(e_lds + lrowb[ct] + tb);
+            else if constexpr (!ADAM) ev[i][ct] = *reinterpret_cast<const f32x4*>(e_lds + lrowb[ct] + tb);
         }
     }
     f32x4 av[NTW][CTT];
@@ -223,13 +233,35 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
         const bool pad_tile = 16 * tile + 16 > n;                  // wave-uniform: only the last tile of a ragged layer
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
-            const f32x4 x = xv[i][ct], e = ev[i][ct], back = av[i][ct];
+            const f32x4 x = xv[i][ct], back = av[i][ct];
+            f32x4 e;
+            if constexpr (ADAM) {         // (the error rows are read here, not held across the wait: registers go to m and v)
+                if (l == 0) e = ev[i][ct];
+                else e = *reinterpret_cast<const f32x4*>(e_lds + lrowb[ct] + tb);
+            } else {
+                e = ev[i][ct];
+            }
             f32x4 g;
             g.x = e.x + sign * actd<ACT>(x.x, actf<ACT>(x.x)) * back.x;
             g.y = e.y + sign * actd<ACT>(x.y, actf<ACT>(x.y)) * back.y;
             g.z = e.z + sign * actd<ACT>(x.z, actf<ACT>(x.z)) * back.z;
             g.w = e.w + sign * actd<ACT>(x.w, actf<ACT>(x.w)) * back.w;
-            f32x4 xn = x - g * lr;
+            f32x4 xn;
+            if constexpr (ADAM) {
+                // torch.optim.Adam single-tensor path: lerp_, mul_/addcmul_, sqrt/bias2 + eps, addcdiv_ (adam_x, mcpc_device.h)
+                f32x4 m = mv[i][ct], v = vv[i][ct];
+                m = m + (g - m) * P.omb1;
+                v = v * P.beta2 + (g * g) * P.omb2;
+                gst4s(Ly.m, rowb[ct] + tb, m);
+                gst4s(Ly.v, rowb[ct] + tb, v);
+                const float step_size = P.adam_coef[2 * s_tab], inv_bc2 = P.adam_coef[2 * s_tab + 1], eps = P.eps;
+                xn.x = adam_x(x.x, m.x, v.x, step_size, inv_bc2, eps);
+                xn.y = adam_x(x.y, m.y, v.y, step_size, inv_bc2, eps);
+                xn.z = adam_x(x.z, m.z, v.z, step_size, inv_bc2, eps);
+                xn.w = adam_x(x.w, m.w, v.w, step_size, inv_bc2, eps);
+            } else {
+                xn = x - g * lr;
+            }
             if constexpr (NOISE)
                 xn = xn + normals4(seed, step, (uint32_t)l, (uint32_t)(chain_base + (uint64_t)L.chain[ct]), (uint32_t)(4 * tile + L.q)) * nscale;
             if (pad_tile) {       // padded units stay exactly zero (their gradient is zero; only the noise must be masked)

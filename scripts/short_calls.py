@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Short calls at cfg-M's size: ms per call and us per step for T in a few lengths, mixed schedule on / off, Adam (MAP) / SGD + noise.
+Developer measurement: where the mixed schedule starts to pay."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import make_problem  # noqa: E402
+from montecarlopredictivecoding_amd import _lib as L  # noqa: E402
+from montecarlopredictivecoding_amd.engine import Engine  # noqa: E402
+
+DEV = "cuda:0"
+B = 6000
+W, b, y, xs = make_problem(B, 30, DEV)
+xs = [x * 0.1 for x in xs]
+for tuning in (None, "no_mix=1"):
+    eng = Engine([30, 256, 256], [L.ACT_RELU] * 3, 30, 784, B, device=DEV, tuning=tuning)
+    eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
+    for name, kw in (("adam", dict(noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.1)),
+                     ("sgd+noise", dict(noise_mode=L.NOISE_PHILOX, lr=0.03, seed=3, step_base=0))):
+        for T in (50, 150, 250, 400, 1000):
+            def call():
+                eng.load_state(xs)
+                eng.run(T, loss_kind=L.LOSS_BERNOULLI, energy_mode=L.ENERGY_LAST, **kw)
+                eng.sync_check()
+            call(); call()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                call()
+            dt = (time.perf_counter() - t0) / 5
+            print(f"{'mixed' if tuning is None else 'plain':5s} {name:9s} T={T:5d}: {dt*1e3:7.2f} ms per call, {dt/T*1e6:6.1f} us per step", flush=True)
+    eng.close()

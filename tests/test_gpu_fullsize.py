@@ -303,6 +303,29 @@ def test_lean_epilogues_and_bitpacked_targets_change_nothing():
     assert np.array_equal(outs[0][3], outs[1][3])            # bit-packed vs fp32 target: everything identical
 
 
+def test_lean_adam_epilogue_matches_generic_epilogue():
+    """The MAP warm-up (Adam on x, no noise) takes the lean x update, which requests the moments in front of the wait for the
+    partner's block: states, energies and the moments themselves are bitwise those of the generic epilogue, on the mixed
+    schedule (200 steps = one short cycle + 25 plain steps) and on the plain one."""
+    from montecarlopredictivecoding_amd import _lib as L
+    W, b, y, xs = _problem()
+    xs_small = [x * 0.1 for x in xs]
+    for base in ("", "no_mix=1,"):
+        outs = []
+        for tuning in (base.rstrip(",") or None, base + "no_lean=1"):
+            eng = _engine(B, W, b, y, tuning=tuning)
+            res, out = _run(eng, xs_small, 200 if not base else 40, noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.05)
+            m = [torch.empty_like(x) for x in xs]; v = [torch.empty_like(x) for x in xs]
+            eng.store_adam_state(m, v)
+            eng.sync_check()
+            outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out + m + v]))
+            eng.close()
+        assert np.array_equal(outs[0][0], outs[1][0])
+        for a, c in zip(outs[0][1], outs[1][1]):
+            assert np.array_equal(a, c)
+        assert np.isfinite(outs[0][0]).all() and outs[0][0][-1, -1] < outs[0][0][0, -1]
+
+
 def test_pc_path_is_bitwise_reproducible_and_descends():
     """cfg-PC: noise = 0.  Two runs are bit-identical (energies included: fixed-order reductions, no float atomics),
     and F = loss + energy never increases under plain gradient descent with a small step."""
