@@ -167,6 +167,22 @@ int mcpc_read_param_grads(mcpc_engine* e, int j, float* dW, float* db, float sca
 int mcpc_read_param_grads_flat(mcpc_engine* e, float* flat, int64_t n_floats, float scale, void* stream);
 int64_t mcpc_param_count(const mcpc_engine* e);
 
+/* ---- multi-GPU (the reference is single-device, `use_cuda = torch.cuda.is_available()`
+ * figure_2.py:150): one process per GPU, the chains sharded, the weights replicated.  The ONLY collective of a learning
+ * call is one sum of the gradient bucket over the shards, before the division by len(accumulate_p_at) * B_global
+ * (pc_trainer.py:905-909 divides by len(inputs) = the whole batch).  For a host that is not on torch.distributed the
+ * library drives RCCL itself (librccl.so.1 is loaded on first use; ncclAllReduce(sum, fp32) over xGMI):
+ *   rank 0:   mcpc_comm_unique_id(id)         and ships the MCPC_COMM_ID_BYTES to the other ranks out of band
+ *   all:      mcpc_comm_init(e, n_ranks, rank, id)            (collective: every rank must call it)
+ *   per call: mcpc_read_param_grads_flat(e, flat, n, 1/(n_acc*B_global), stream); mcpc_allreduce_grads(e, flat, n, stream)
+ * mcpc_allreduce_grads is asynchronous on `stream` and in place; with a communicator of one rank it is the identity.
+ * mcpc_destroy releases the communicator. */
+#define MCPC_COMM_ID_BYTES 128
+int mcpc_comm_unique_id(void* id_out);
+int mcpc_comm_init(mcpc_engine* e, int n_ranks, int rank, const void* id);
+int mcpc_allreduce_grads(mcpc_engine* e, float* flat, int64_t n_floats, void* stream);
+int mcpc_comm_destroy(mcpc_engine* e);
+
 /* Fill out[batch][n_units] with the engine's Philox normals for (seed, step, layer): the device
  * generator exposed for bit-exactness tests against oracle/philox.py. raw != 0 writes the u32 stream. */
 int mcpc_philox_normals(int device, uint64_t seed, uint64_t step, int layer, uint64_t chain_base,

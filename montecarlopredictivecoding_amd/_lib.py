@@ -8,6 +8,7 @@ import ctypes as C
 import os
 
 MAX_LATENT = 6
+COMM_ID_BYTES = 128
 ENERGY_COLS = MAX_LATENT + 2
 ABI_VERSION = 2
 
@@ -87,6 +88,10 @@ SYMBOLS = {
     "mcpc_read_param_grads": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]),
     "mcpc_read_param_grads_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "mcpc_param_count": (C.c_int64, [C.c_void_p]),
+    "mcpc_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mcpc_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mcpc_allreduce_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mcpc_comm_destroy": (C.c_int, [C.c_void_p]),
     "mcpc_philox_normals": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                       C.c_void_p, C.c_int, C.c_void_p]),
     "mcpc_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),

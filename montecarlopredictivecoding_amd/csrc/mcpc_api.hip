@@ -1,6 +1,8 @@
 // Host side of libmcpc.so: the C ABI declared in include/mcpc.h.
 // Allocation, weight packing, launch orchestration (step segments + Hebbian flushes); no torch.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library is loaded with dlopen on first use (no link dependency)
 
 #include <algorithm>
 #include <cmath>
@@ -108,6 +110,8 @@ int parse_tuning(const char* str, Knobs& k) {
 struct mcpc_engine {
     mcpc_net_desc d{};
     Knobs knobs;
+    ncclComm_t comm = nullptr;      // mcpc_comm_init: the shards' communicator (RCCL), one rank per engine
+    int comm_ranks = 0;
     int L = 0, Bpad = 0, nwg = 0, has_head = 0;
     int ct = kCT;                   // chains per workgroup: 16 (two workgroups per CU) or 32
     int nw = kWaves;                // waves per workgroup: 4, or 8 with 32 chains (two waves per SIMD, one workgroup per CU)
@@ -176,7 +180,40 @@ struct mcpc_engine {
 
 namespace {
 
+// RCCL, bound at first use: a host that never shards the chains never loads it; inside a torch process dlopen returns the copy
+// torch already mapped (same soname), so both share one HIP runtime.
+struct Rccl {
+    void* so = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+    if (g_rccl.so) return MCPC_OK;
+    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!so) return fail(MCPC_EHIP, "librccl.so.1 could not be loaded: %s", dlerror());
+    Rccl r;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(so, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(so, "ncclCommInitRank");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(so, "ncclAllReduce");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(so, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(so, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.GetErrorString) {
+        dlclose(so);
+        return fail(MCPC_EHIP, "librccl.so.1 lacks an entry point this library needs");
+    }
+    r.so = so;
+    g_rccl = r;
+    return MCPC_OK;
+}
+
 int free_all(mcpc_engine* e) {
+    if (e->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(e->comm); e->comm = nullptr; e->comm_ranks = 0; }
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int l = 0; l < kMaxLatent; ++l) { F(e->x[l]); F(e->m[l]); F(e->v[l]); F(e->spill_a[l]); F(e->spill_e[l]); }
     F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err);
@@ -1313,6 +1350,53 @@ int mcpc_read_param_grads(mcpc_engine* e, int j, float* dW, float* db, float sca
         hipLaunchKernelGGL(mcpc_export_grad_kernel, dim3(grid_for((size_t)ln.n_out)), dim3(256), 0, stream, ln.Gb, db,
                            ln.n_out, 1, 1, scale, accumulate);
     HIP_TRY(hipGetLastError());
+    return MCPC_OK;
+}
+
+// ---- multi-GPU: the one collective of a learning call ---------------------------------------------
+int mcpc_comm_unique_id(void* id_out) {
+    static_assert(sizeof(ncclUniqueId) == MCPC_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    if (!id_out) return fail(MCPC_EINVAL, "null id buffer");
+    if (const int rc = rccl_load()) return rc;
+    ncclUniqueId id;
+    const ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(MCPC_EHIP, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r));
+    std::memcpy(id_out, &id, sizeof(id));
+    return MCPC_OK;
+}
+
+int mcpc_comm_init(mcpc_engine* e, int n_ranks, int rank, const void* id_in) {
+    if (!e || !id_in) return fail(MCPC_EINVAL, "null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(MCPC_EINVAL, "rank %d of %d", rank, n_ranks);
+    if (e->comm) return fail(MCPC_ESTATE, "the engine already has a communicator (mcpc_comm_destroy first)");
+    if (const int rc = rccl_load()) return rc;
+    HIP_TRY(hipSetDevice(e->d.device));
+    ncclUniqueId id;
+    std::memcpy(&id, id_in, sizeof(id));
+    const ncclResult_t r = g_rccl.CommInitRank(&e->comm, n_ranks, id, rank);
+    if (r != ncclSuccess) { e->comm = nullptr; return fail(MCPC_EHIP, "ncclCommInitRank(%d of %d): %s", rank, n_ranks, g_rccl.GetErrorString(r)); }
+    e->comm_ranks = n_ranks;
+    return MCPC_OK;
+}
+
+int mcpc_allreduce_grads(mcpc_engine* e, float* flat, int64_t n_floats, void* stream_) {
+    if (!e || !flat) return fail(MCPC_EINVAL, "null argument");
+    if (!e->comm) return fail(MCPC_ESTATE, "mcpc_allreduce_grads before mcpc_comm_init");
+    if (n_floats != mcpc_param_count(e)) return fail(MCPC_EINVAL, "bucket of %lld floats, the engine's parameters have %lld", (long long)n_floats, (long long)mcpc_param_count(e));
+    HIP_TRY(hipSetDevice(e->d.device));
+    const ncclResult_t r = g_rccl.AllReduce(flat, flat, (size_t)n_floats, ncclFloat, ncclSum, e->comm, (hipStream_t)stream_);
+    if (r != ncclSuccess) return fail(MCPC_EHIP, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
+    return MCPC_OK;
+}
+
+int mcpc_comm_destroy(mcpc_engine* e) {
+    if (!e) return fail(MCPC_EINVAL, "null engine");
+    if (e->comm) {
+        (void)hipSetDevice(e->d.device);
+        const ncclResult_t r = g_rccl.CommDestroy(e->comm);
+        e->comm = nullptr; e->comm_ranks = 0;
+        if (r != ncclSuccess) return fail(MCPC_EHIP, "ncclCommDestroy: %s", g_rccl.GetErrorString(r));
+    }
     return MCPC_OK;
 }
 

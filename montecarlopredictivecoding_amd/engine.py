@@ -230,6 +230,29 @@ class Engine:
         L.check(self._lib.mcpc_read_param_grads_flat(self._h, _ptr(flat), flat.numel(), scale, self._stream()))
         return flat
 
+    # ---- the library's own collective (hosts that are not on torch.distributed; include/mcpc.h "multi-GPU") ------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: the RCCL unique id (128 bytes) every rank passes to comm_init."""
+        buf = C.create_string_buffer(L.COMM_ID_BYTES)
+        L.check(L.load().mcpc_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, n_ranks: int, rank: int, unique_id: bytes):
+        if len(unique_id) != L.COMM_ID_BYTES:
+            raise ValueError(f"unique id of {len(unique_id)} bytes, expected {L.COMM_ID_BYTES}")
+        L.check(self._lib.mcpc_comm_init(self._h, n_ranks, rank, C.create_string_buffer(unique_id, L.COMM_ID_BYTES)))
+
+    def allreduce_grads(self, flat: torch.Tensor):
+        """In-place sum of the gradient bucket over the shards (ncclAllReduce on the caller's stream)."""
+        if flat.dtype != torch.float32 or not flat.is_contiguous() or flat.device != self.device:
+            raise ValueError("the bucket must be a contiguous float32 tensor on the engine's device")
+        L.check(self._lib.mcpc_allreduce_grads(self._h, _ptr(flat), flat.numel(), self._stream()))
+        return flat
+
+    def comm_destroy(self):
+        L.check(self._lib.mcpc_comm_destroy(self._h))
+
     def sync_check(self):
         """Synchronise the stream and raise MCPCError if a kernel reported a device-side fault."""
         L.check(self._lib.mcpc_sync_check(self._h, self._stream()))

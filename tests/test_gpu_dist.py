@@ -65,3 +65,39 @@ def test_one_rank_rccl_group_matches_unsharded_run(world_batch):
     for a, c in zip(plain_w, shard_w):
         assert torch.equal(a, c)
     assert any(float(g.abs().max()) > 0 for g in plain_g)
+
+
+def test_native_rccl_allreduce_of_the_gradient_bucket_one_rank():
+    """include/mcpc.h "multi-GPU": the library's own RCCL path (mcpc_comm_unique_id / mcpc_comm_init / mcpc_allreduce_grads) for
+    hosts that are not on torch.distributed.  With a communicator of one rank the sum over the shards is the identity: the
+    bucket read from the engine must come back bit for bit, on the caller's stream, and the error paths must be clean."""
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    g = torch.Generator().manual_seed(5)
+    sizes, n_in, n_out, B = [8, 32, 32], 8, 64, 48
+    dims = [n_in] + sizes + [n_out]
+    W = [((torch.rand(dims[j + 1], dims[j], generator=g) - 0.5) * 0.4).to(DEV) for j in range(4)]
+    b = [((torch.rand(dims[j + 1], generator=g) - 0.5) * 0.4).to(DEV) for j in range(4)]
+    eng = Engine(sizes, [L.ACT_RELU] * 3, n_in, n_out, B, device=DEV)
+    eng.bind_params(W, b); eng.bind_inputs(None)
+    eng.bind_target((torch.rand(B, n_out, generator=g) < 0.3).float().to(DEV))
+    eng.load_state([torch.rand(B, n, generator=g).to(DEV) for n in sizes])
+    eng.run(12, loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=1, step_base=0, acc_begin=2, acc_end=12)
+    flat = eng.read_param_grads_flat(scale=1.0 / (10 * B))
+    want = flat.clone()
+    with pytest.raises(L.MCPCError, match="before mcpc_comm_init"):
+        eng.allreduce_grads(flat)
+    uid = Engine.comm_unique_id()
+    assert len(uid) == L.COMM_ID_BYTES and any(uid)
+    eng.comm_init(1, 0, uid)
+    with pytest.raises(L.MCPCError, match="already has a communicator"):
+        eng.comm_init(1, 0, uid)
+    with pytest.raises(L.MCPCError, match="bucket of"):
+        eng.allreduce_grads(flat[:-1].contiguous())
+    eng.allreduce_grads(flat)
+    eng.sync_check()
+    assert torch.equal(flat, want) and float(want.abs().max()) > 0
+    eng.comm_destroy()
+    eng.comm_destroy()                     # idempotent
+    eng.close()
