@@ -93,12 +93,16 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
         const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));     // unused slots repeat slot 0
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
-#ifdef MCPC_EXP_NOX       // timing experiment only (wrong results): the state is neither loaded nor stored
+#if defined(MCPC_EXP_NOX) || defined(MCPC_EXP_NOELOAD)       // timing experiment only (wrong results): the state is neither loaded nor stored
             xv[i][ct] = splat(0.5f);
 #else
             xv[i][ct] = gld4s(Ly.x, rowb[ct] + tb);
 #endif
+#ifdef MCPC_EXP_NOELOAD   // timing experiment only (wrong results): no operand loads at all in the E waves
+            bv[i][ct] = splat(0.25f); (void)bsrc;
+#else
             bv[i][ct] = gld4(bsrc, (l == 0 ? rowb[ct] : 16u * L.q) + tb);
+#endif
         }
     }
     f32x4 av[NTW][CTT];
@@ -193,7 +197,7 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
         const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
-#ifdef MCPC_EXP_NOX
+#if defined(MCPC_EXP_NOX) || defined(MCPC_EXP_NOELOAD)
             xv[i][ct] = splat(0.5f);
 #else
             xv[i][ct] = gld4s(Ly.x, rowb[ct] + tb);
@@ -202,7 +206,11 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
                 mv[i][ct] = gld4s(Ly.m, rowb[ct] + tb);
                 vv[i][ct] = gld4s(Ly.v, rowb[ct] + tb);
             }
+#ifdef MCPC_EXP_NOELOAD
+            if (l == 0) ev[i][ct] = (xv[i][ct] - splat(0.25f)) * ecoef;
+#else
             if (l == 0) ev[i][ct] = (xv[i][ct] - gld4(P.mu1, rowb[ct] + tb)) * ecoef;       // e_1 = c_1 (x_1 - mu_1), mu_1 constant
+#endif
             else if constexpr (!ADAM) ev[i][ct] = *reinterpret_cast<const f32x4*>(e_lds + lrowb[ct] + tb);
         }
     }
@@ -301,13 +309,17 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
     for (int i = 0; i < NTW; ++i) {
         const int tile = ph.tile0 + kk + NW * (i < nt ? i : 0);
         const uint32_t tb = 64u * (uint32_t)tile;
+#ifdef MCPC_EXP_NOELOAD
+        bv[i] = splat(0.25f);
+#else
         bv[i] = gld4(H.bias, 16u * L.q + tb);
+#endif
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
             // Branch-free on purpose (a load under an `if` makes hipcc join the paths behind `s_waitcnt vmcnt(0)`, which here
             // would also wait for every spill store still in flight): both loads are always issued; the one that is not
             // needed reads a harmless hot address (the bias row again / the word array, which always exists).
-#ifdef MCPC_EXP_NOY        // (timing experiment only, wrong results: targets are not loaded)
+#if defined(MCPC_EXP_NOY) || defined(MCPC_EXP_NOELOAD)        // (timing experiment only, wrong results: targets are not loaded)
             yv[i][ct] = splat(0.f); yw[i][ct] = 0u;
 #else
             const bool fp32_y = kind != MCPC_LOSS_NONE && !ybin;
