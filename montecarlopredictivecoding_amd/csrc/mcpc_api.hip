@@ -516,8 +516,18 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
     // MCPC_MIX_SLACK CUs are left free (default 0): with every CU taken, a workgroup that finds its CU still draining has
     // to wait for another workgroup of its XCD to finish, which doubles that segment
     const int slack = e->knobs.mix_slack;
-    const int ns = std::min(n_cu - slack - npairs, npairs);     // npairs + ns workgroups (np pairs + 2 ns singles) <= CUs
-    if (ns < 1) return 0;
+    int ns = std::min(n_cu - slack - npairs, npairs);           // npairs + ns workgroups (np pairs + 2 ns singles) <= CUs
+    // ... and <= the CUs of every XCD: the workgroups of a launch go round-robin over the 8 XCDs starting at XCD 0, so XCD 0
+    // receives ceil(np / 8) of the pairs AND ceil(2 ns / 8) of the singles.  One workgroup too many on an XCD waits for a
+    // whole segment and doubles it (measured at 7500 chains: 214 + 42 workgroups, 27 + 6 on XCD 0: 173 us per step instead
+    // of 88; 6000 chains happen to give 15 + 17 on every XCD).
+    constexpr int kXcd = 8;
+    if (n_cu % kXcd == 0)
+        while (ns >= 1 && (npairs - ns + kXcd - 1) / kXcd + (2 * ns + kXcd - 1) / kXcd > n_cu / kXcd) --ns;
+    // A split pair advances 34 steps where a paired one advances 20: the schedule does 1 + 0.7 ns / npairs times the plain
+    // schedule's work per unit of time, minus what its short launches cost.  Below 4 % expected it does not pay (8000 chains:
+    // 4 of 250 pairs split, +1.1 % expected, -5 % measured).
+    if (ns < 1 || 0.7 * ns < 0.04 * npairs) return 0;
     // second plan: swap the primary one out, plan for 16 chains, swap back
     mcpc_engine::Alt keep;
     std::copy(e->lds_a, e->lds_a + kMaxLatent, keep.lds_a); std::copy(e->lds_e, e->lds_e + kMaxLatent, keep.lds_e);

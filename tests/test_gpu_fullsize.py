@@ -189,6 +189,31 @@ def test_mixed_schedule_all_segment_sizes_match_plain_schedule(monkeypatch):
     assert np.all(np.isfinite(outs[0][0]))
 
 
+@pytest.mark.parametrize("batch,T,cycles,steps", [(7500, 700, 2, 498 + 149), (5000, 700, 1, 663), (4200, 420, 2, 322), (8000, 300, 0, 0)])
+def test_mixed_schedule_other_shard_sizes(batch, T, cycles, steps, monkeypatch):
+    """The split count of the mixed schedule is bounded by the CUs of every XCD (the workgroups of both launches go round-robin
+    over the XCDs from XCD 0), which makes the pair / single counts and the rotation length depend on the shard size:
+    7500 chains = 215 pairs + 40 singles, rotation of 47 segments; 5000 chains = 61 + 192, rotation of 157 (157 pairs: prime);
+    4200 chains = 8 + 248; 8000 chains would split 4 pairs of 250, which does not pay: plain schedule.  Trajectories and
+    records must be BITWISE those of the plain schedule for every one of them."""
+    W, b, y, xs = _problem(batch)
+    outs = []
+    for no_mix in (False, True):
+        if no_mix:
+            monkeypatch.setenv("MCPC_TUNING", "no_mix=1")
+        eng = _engine(batch, W, b, y)
+        eng.set_profiling(True)
+        res, out = _run(eng, xs, T, rec_begin=0, rec_stride=97, rec_count=(T + 96) // 97, rec_x=True)
+        ms, n_cycles, n_steps = eng.last_mixed_cycles_ms()
+        assert (n_cycles, n_steps) == ((0, 0) if no_mix else (cycles, steps))
+        outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x]))
+        eng.close()
+    for a, c in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
+        assert np.array_equal(a, c)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-6)
+    assert np.all(np.isfinite(outs[0][0]))
+
+
 def test_hebbian_ring_wraps_full_size():
     """B = 6000, Hebbian sums over 400 steps (pc_trainer.py:853-862: autograd adds dF/dtheta of every accumulating step).
     The default ring (128 slots, halves of 64, overlapped flush) wraps three times.  Checked against
