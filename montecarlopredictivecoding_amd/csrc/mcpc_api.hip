@@ -1217,18 +1217,20 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         if (in_acc) n = std::min(std::min(end, acc_e) - t, e->half_slots);
         else n = (t < acc_b ? std::min(end, acc_b) : end) - t;
         if (!in_acc && mix_ok) {
-            // as many whole cycles as fit, long segments first; what is left runs on the plain schedule below
-            static const int kSeg[3][2] = {{20, 34}, {10, 17}, {3, 5}};   // (paired, split) steps per segment: ~ the 1 : 1.7 rate ratio
-            for (const auto& sg : kSeg) {
-                const int cyc = e->mix_a * sg[1] + (e->mix_lc - e->mix_a) * sg[0];
-                while (n >= cyc) {
-                    // (events around a whole cycle only: one between the two concurrent launches of a segment serialises them)
-                    { const int rc = prof_begin(true); if (rc) return rc; }
-                    const int rc = run_mixed_cycle(t, sg[0], sg[1]);
-                    if (rc) return rc;
-                    { const int rc2 = prof_end((double)cyc, true); if (rc2) return rc2; }
-                    t += cyc; n -= cyc;
-                }
+            // As many whole cycles as fit, longest segments first; what is left runs on the plain schedule below.  A cycle with p
+            // steps per segment for the paired units and s(p) = round(1.7 p) for the split ones (the 1 : 1.7 rate ratio of the two
+            // workgroup forms: 20 / 34, 10 / 17, 3 / 5) advances every unit by a s + (lc - a) p steps; segments shorter than 3
+            // steps do not pay for their launches.
+            for (int p = 20; p >= 3;) {
+                const int sp = (17 * p + 5) / 10;
+                const int cyc = e->mix_a * sp + (e->mix_lc - e->mix_a) * p;
+                if (cyc > n) { --p; continue; }
+                // (events around a whole cycle only: one between the two concurrent launches of a segment serialises them)
+                { const int rc = prof_begin(true); if (rc) return rc; }
+                const int rc = run_mixed_cycle(t, p, sp);
+                if (rc) return rc;
+                { const int rc2 = prof_end((double)cyc, true); if (rc2) return rc2; }
+                t += cyc; n -= cyc;
             }
             if (n == 0) continue;
         }

@@ -140,12 +140,35 @@ def test_sharding_and_launch_slicing_do_not_change_trajectories():
     np.testing.assert_allclose(flat_sum, flat_whole, rtol=1e-4, atol=1e-6 * np.abs(flat_whole).max())
 
 
+def _mixed_plan(batch, T, n_cu=256):
+    """Mirror of setup_mixed_schedule / mcpc_run (mcpc_api.hip): (cycles, steps on the mixed schedule, segment sizes used) of an
+    inference stretch of T steps of a shard of `batch` chains on a GPU of n_cu CUs in 8 XCDs."""
+    from math import gcd
+    npairs = (batch + 31) // 32
+    ns = min(n_cu - npairs, npairs)
+    while ns >= 1 and (npairs - ns + 7) // 8 + (2 * ns + 7) // 8 > n_cu // 8:
+        ns -= 1
+    if ns < 1 or 0.7 * ns < 0.04 * npairs:
+        return 0, 0, []
+    lc = npairs // gcd(npairs, ns)
+    a = ns * lc // npairs
+    cycles, steps, used, n, p = 0, 0, [], T, 20
+    while p >= 3:
+        sp = (17 * p + 5) // 10
+        cyc = a * sp + (lc - a) * p
+        if cyc > n:
+            p -= 1
+            continue
+        cycles += 1; steps += cyc; n -= cyc; used.append(p)
+    return cycles, steps, used
+
+
 def test_mixed_schedule_matches_plain_schedule(monkeypatch):
     """Inference stretches of a shard that leaves CUs idle run on the mixed schedule (most chain-tile pairs as 32-chain
     workgroups, a rotating subset split into 16-chain workgroups on the spare CUs).  Per chain the arithmetic is the same, so
     trajectories and records must be BITWISE those of the plain schedule; energies regroup fp32 partial sums."""
     W, b, y, xs = _problem()
-    T = 420                                    # two short cycles (175 steps each) + 70 plain steps; mixing then Hebbian steps
+    T = 420                                    # 400 inference steps (one cycle of (6, 10) steps per segment: 350, then plain), then 20 Hebbian steps
     outs = []
     for no_mix in (False, True):
         if no_mix:
@@ -165,11 +188,14 @@ def test_mixed_schedule_matches_plain_schedule(monkeypatch):
 
 
 def test_mixed_schedule_all_segment_sizes_match_plain_schedule(monkeypatch):
-    """A T = 5000 call runs whole cycles of the mixed schedule with (20, 34), then (10, 17), then (3, 5) steps per segment
-    (1178 + 589 + 175 steps at B = 6000) before the plain schedule takes what is left.  T = 1960 runs one cycle of each
-    size and 18 plain steps: final state and every record must be BITWISE those of the plain schedule."""
+    """A call runs whole cycles of the mixed schedule, longest segments first: (20, 34) steps per segment (1178 steps per cycle at
+    B = 6000), then the longest that still fits, down to (3, 5) (175 steps), before the plain schedule takes what is left.
+    T = 2073 runs one cycle with (20, 34) steps per segment, one with (15, 26) (892 steps) and 3 plain steps; the shortest form, (3, 5),
+    is what test_mixed_schedule_with_per_step_tables runs, (6, 10) what test_mixed_schedule_matches_plain_schedule runs: final state and
+    every record must be BITWISE those of the plain schedule."""
     W, b, y, xs = _problem()
-    T = 1178 + 589 + 175 + 18
+    T = 1178 + 892 + 3
+    assert _mixed_plan(B, T) == (2, 1178 + 892, [20, 15])
     outs = []
     for no_mix in (False, True):
         if no_mix:
@@ -178,7 +204,7 @@ def test_mixed_schedule_all_segment_sizes_match_plain_schedule(monkeypatch):
         eng.set_profiling(True)
         res, out = _run(eng, xs, T, rec_begin=0, rec_stride=89, rec_count=23, rec_x=True)
         ms, n_cycles, n_steps = eng.last_mixed_cycles_ms()
-        assert (n_cycles, n_steps) == ((0, 0) if no_mix else (3, 1178 + 589 + 175))
+        assert (n_cycles, n_steps) == ((0, 0) if no_mix else (2, 1178 + 892))
         outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x]))
         eng.close()
     for a, c in zip(outs[0][1], outs[1][1]):
@@ -189,14 +215,16 @@ def test_mixed_schedule_all_segment_sizes_match_plain_schedule(monkeypatch):
     assert np.all(np.isfinite(outs[0][0]))
 
 
-@pytest.mark.parametrize("batch,T,cycles,steps", [(7500, 700, 2, 498 + 149), (5000, 700, 1, 663), (4200, 420, 2, 322), (8000, 300, 0, 0)])
-def test_mixed_schedule_other_shard_sizes(batch, T, cycles, steps, monkeypatch):
+@pytest.mark.parametrize("batch,T", [(7500, 700), (5000, 700), (4200, 420), (8000, 300)])
+def test_mixed_schedule_other_shard_sizes(batch, T, monkeypatch):
     """The split count of the mixed schedule is bounded by the CUs of every XCD (the workgroups of both launches go round-robin
     over the XCDs from XCD 0), which makes the pair / single counts and the rotation length depend on the shard size:
     7500 chains = 215 pairs + 40 singles, rotation of 47 segments; 5000 chains = 61 + 192, rotation of 157 (157 pairs: prime);
     4200 chains = 8 + 248; 8000 chains would split 4 pairs of 250, which does not pay: plain schedule.  Trajectories and
     records must be BITWISE those of the plain schedule for every one of them."""
     W, b, y, xs = _problem(batch)
+    cycles, steps, used = _mixed_plan(batch, T)
+    assert (cycles > 0) == (batch != 8000) and steps <= T
     outs = []
     for no_mix in (False, True):
         if no_mix:
@@ -286,7 +314,7 @@ def test_mixed_schedule_with_per_step_tables(mode, monkeypatch):
     from montecarlopredictivecoding_amd import _lib as L
     W, b, y, xs = _problem()
     xs_small = [x * 0.1 for x in xs]
-    T = 200                                    # one short cycle (175 steps) + 25 plain steps
+    T = 200                                    # one short cycle ((3, 5) steps per segment: 175 steps) + 25 plain steps
     kw = dict(noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.05)
     if mode == "external_noise":
         g = torch.Generator().manual_seed(3)
