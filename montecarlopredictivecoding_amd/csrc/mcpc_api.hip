@@ -66,6 +66,7 @@ struct Knobs {
     int slot_cap = 128;       // upper bound on spill-ring slots
     int spill_gb = 0;         // > 0: spill budget in GiB (overrides mcpc_net_desc::spill_budget_bytes)
     int mix_slack = 0;        // CUs the mixed schedule leaves free
+    int mix_ratio = 17;       // steps of a split unit per 10 steps of a paired one (the rate ratio of the two workgroup forms)
     int dw_ksplit = 0;        // > 0: K-splits per workgroup tile of the Hebbian GEMM (0: one wave of workgroups over the chip)
     int ws_prio = 1;          // 1: epilogue waves at raised priority, 2: GEMM waves, 0: neither
     int stagger = 0;          // barrier kernel: start cycles of the second workgroup of a CU
@@ -90,7 +91,7 @@ int parse_tuning(const char* str, Knobs& k) {
         const int val = eq == std::string::npos ? 1 : atoi(item.c_str() + eq + 1);
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
-            {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"dw_ksplit", &k.dw_ksplit},
+            {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"dw_ksplit", &k.dw_ksplit},
             {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}};
         bool found = false;
         for (auto& t : table)
@@ -102,6 +103,7 @@ int parse_tuning(const char* str, Knobs& k) {
     if (k.nw != 0 && k.nw != 4 && k.nw != 8) return fail(MCPC_EINVAL, "tuning nw=%d: 4 or 8", k.nw);
     if (k.slot_cap < 2) k.slot_cap = 2;
     if (k.mix_slack < 0) k.mix_slack = 0;
+    if (k.mix_ratio < 10 || k.mix_ratio > 30) return fail(MCPC_EINVAL, "tuning mix_ratio=%d: 10..30 (tenths)", k.mix_ratio);
     return 0;
 }
 
@@ -527,7 +529,7 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
     // A split pair advances 34 steps where a paired one advances 20: the schedule does 1 + 0.7 ns / npairs times the plain
     // schedule's work per unit of time, minus what its short launches cost.  Below 4 % expected it does not pay (8000 chains:
     // 4 of 250 pairs split, +1.1 % expected, -5 % measured).
-    if (ns < 1 || 0.7 * ns < 0.04 * npairs) return 0;
+    if (ns < 1 || (0.1 * e->knobs.mix_ratio - 1.0) * ns < 0.04 * npairs) return 0;
     // second plan: swap the primary one out, plan for 16 chains, swap back
     mcpc_engine::Alt keep;
     std::copy(e->lds_a, e->lds_a + kMaxLatent, keep.lds_a); std::copy(e->lds_e, e->lds_e + kMaxLatent, keep.lds_e);
@@ -1222,7 +1224,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             // workgroup forms: 20 / 34, 10 / 17, 3 / 5) advances every unit by a s + (lc - a) p steps; segments shorter than 3
             // steps do not pay for their launches.
             for (int p = 20; p >= 3;) {
-                const int sp = (17 * p + 5) / 10;
+                const int sp = (e->knobs.mix_ratio * p + 5) / 10;
                 const int cyc = e->mix_a * sp + (e->mix_lc - e->mix_a) * p;
                 if (cyc > n) { --p; continue; }
                 // (events around a whole cycle only: one between the two concurrent launches of a segment serialises them)
