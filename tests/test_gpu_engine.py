@@ -197,3 +197,58 @@ def test_philox_statistics():
     assert abs((z ** 3).mean()) < 5.0 * np.sqrt(15.0 / n)
     assert abs((z ** 4).mean() - 3.0) < 5.0 * np.sqrt(96.0 / n)
     assert np.abs(z).max() < 6.5
+
+
+def test_two_engines_on_two_streams_run_concurrently():
+    """include/mcpc.h threading rule: one engine per (device, stream), launches asynchronous.  Two engines of different shapes
+    driven from two torch streams at the same time (their kernels overlap on the GPU: each leaves most CUs idle) must give
+    exactly what each gives alone."""
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    dev = _dev()
+    specs = [([12, 40, 24], 8 + 4, 60, 200), ([6, 20], 6, 0, 90)]      # (sizes, n_in, n_out, batch)
+    gen = torch.Generator().manual_seed(11)
+
+    def make(sizes, n_in, n_out, batch):
+        dims = [n_in] + sizes + ([n_out] if n_out else [])
+        W = [((torch.rand(dims[j + 1], dims[j], generator=gen) - 0.5) * 0.6).to(dev) for j in range(len(dims) - 1)]
+        b = [((torch.rand(dims[j + 1], generator=gen) - 0.5) * 0.2).to(dev) for j in range(len(dims) - 1)]
+        y = (torch.rand(batch, n_out, generator=gen) < 0.3).float().to(dev) if n_out else None
+        xs = [torch.rand(batch, n, generator=gen).to(dev) for n in sizes]
+        return W, b, y, xs
+
+    probs = [make(*s) for s in specs]
+
+    def launch(i, stream):
+        sizes, n_in, n_out, batch = specs[i]
+        W, b, y, xs = probs[i]
+        with torch.cuda.stream(stream):
+            eng = Engine(sizes, [L.ACT_TANH] * len(sizes), n_in, n_out, batch, device=dev)
+            eng.bind_params(W, b); eng.bind_inputs(None)
+            if y is not None:
+                eng.bind_target(y)
+            eng.load_state(xs)
+            res = eng.run(300, loss_kind=L.LOSS_BERNOULLI if n_out else L.LOSS_NONE, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=5 + i,
+                          step_base=0, acc_begin=100, acc_end=300, energy_mode=L.ENERGY_ALL)
+            out = [torch.empty_like(x) for x in xs]
+            eng.store_state(out)
+            flat = eng.read_param_grads_flat()
+        return eng, res, out, flat
+
+    torch.cuda.synchronize()
+    alone = []
+    for i in range(2):
+        eng, res, out, flat = launch(i, torch.cuda.current_stream())
+        eng.sync_check()
+        alone.append((res.energies.clone(), [o.clone() for o in out], flat.clone()))
+        eng.close()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    live = [launch(i, streams[i]) for i in range(2)]          # both in flight before either is waited for
+    for i, (eng, res, out, flat) in enumerate(live):
+        with torch.cuda.stream(streams[i]):
+            eng.sync_check()
+        assert torch.equal(res.energies, alone[i][0])
+        for a, c in zip(out, alone[i][1]):
+            assert torch.equal(a, c)
+        assert torch.equal(flat, alone[i][2])
+        eng.close()
