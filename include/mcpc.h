@@ -80,7 +80,8 @@ typedef struct mcpc_net_desc {
     int32_t n_out;                       /* width of the read-out Linear; 0 = model ends with a PCLayer */
     int32_t batch;                       /* chains held by this engine (local shard) */
     int32_t device;                      /* HIP device ordinal */
-    int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default (6 GiB, at most 128 steps) */
+    int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default: room for 128 steps (5.7 GB at 6000 chains of
+                                          * cfg-M's net), at least 6 GiB, at most a quarter of the device's memory */
     const char* tuning;                  /* NULL, or developer overrides of the schedule heuristics as "key=value,key=value"
                                           * (parsed once by mcpc_create, not kept): ws=0|2 step kernel (barrier / in-place),
                                           * ct=16|32 chains per workgroup, nw=4|8, no_mix=1, no_overlap=1, slot_cap=N,

@@ -694,9 +694,15 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     for (int l = 0; l < e->L; ++l) per_slot += (size_t)e->Bpad * e->npad[l] * (l >= 1 ? 2 : 1);
     per_slot += (size_t)e->Bpad * e->out_pad;
     per_slot *= sizeof(float);
-    // defaults sized for 288 GB of HBM per GPU: a 6 GiB ring (128 steps of cfg-M) gives Hebbian segments of 64 steps; a
-    // 2 GiB ring (segments of 24) cost 1.4 % more per step
-    int64_t budget = d->spill_budget_bytes > 0 ? d->spill_budget_bytes : (int64_t)6 << 30;
+    // defaults sized for 288 GB of HBM per GPU: room for `slot_cap` steps (128: Hebbian segments of 64 steps; 5.7 GB at cfg-M,
+    // 45 GB for a shard of 48 000 chains), at least 6 GiB, at most a quarter of the device's memory.  A 2 GiB ring (segments of 24)
+    // cost 1.4 % more per step at cfg-M; 6 GiB instead of 24 cost 13 % at 24 000 chains (segments of 17 steps).
+    int64_t budget = d->spill_budget_bytes;
+    if (budget <= 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
+        budget = std::max<int64_t>((int64_t)6 << 30, std::min<int64_t>((int64_t)kn.slot_cap * (int64_t)per_slot, (int64_t)(total_b / 4)));
+    }
     if (kn.spill_gb > 0) budget = (int64_t)kn.spill_gb << 30;
     e->slots = (int)std::max<int64_t>(1, std::min<int64_t>(kn.slot_cap, budget / (int64_t)per_slot));
     if (e->slots >= 2) { e->slots &= ~1; e->half_slots = e->slots / 2; } else { e->half_slots = 1; }
