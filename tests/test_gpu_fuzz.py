@@ -1,0 +1,84 @@
+"""Seeded sweep of random network shapes and run modes against the NumPy oracle: ragged widths (not multiples of 16), 1-5
+latent layers, batches that are not multiples of the chain tile, every activation / loss / x optimizer / noise mode, non-zero
+pseudo-inputs, bias-free Linears, masked losses, ragged accumulation windows -- on the kernel form the engine picks by default
+(in-place, 16 chains per workgroup), on the 32-chain in-place form large shards get, and on the barrier kernel.  Complements the golden fixtures (fixed shapes, pinned by the reference itself)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mcpc_oracle as mo
+from oracle import philox
+from oracle.cases import make_case_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N_CASES = 24
+
+
+def _random_case(i):
+    r = np.random.RandomState(1000 + i)
+    L_ = int(r.randint(1, 6))
+    sizes = [int(r.randint(1, 70)) for _ in range(L_)]
+    if i % 5 == 0:
+        sizes[-1] = int(r.randint(100, 200))              # a wider last layer now and then (several tiles per wave)
+    n_out = 0 if i % 6 == 5 else int(r.randint(1, 120))
+    loss = "none" if n_out == 0 else ["bernoulli", "gaussian", "bernoulli_mask", "gaussian_mask", "zero"][i % 5]
+    act = ["relu", "tanh", "identity"][i % 3]
+    B = int(r.choice([1, 2, 7, 15, 16, 17, 31, 33, 48, 65, 100]))
+    T = int(r.randint(3, 12))
+    case = dict(sizes=sizes, acts=[act] * L_, ecoef=[float(np.float32(0.5 + r.rand())) for _ in range(L_)], n_in=int(r.randint(1, 20)),
+                n_out=n_out, loss=loss, var=float(np.float32(0.3 + r.rand())), perc=float(r.choice([0.25, 0.5, 0.75])), B=B, seed=500 + i,
+                x0_range=1.5, inputs_zero=bool(i % 4), no_bias=[0] if i % 7 == 3 else [], calls=[dict(T=T)])
+    mode = dict(adam=(i % 4 == 1), noise=(i % 4 != 1) and (i % 3 != 2), acc_begin=int(r.randint(0, T)), lr=float(r.choice([0.01, 0.03, 0.1])))
+    return case, mode
+
+
+@pytest.mark.parametrize("kernel", ["default", "inplace32", "barrier"])
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_random_shape_matches_oracle(i, kernel):
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    case, mode = _random_case(i)
+    sizes, n_out, B, T = case["sizes"], case["n_out"], case["B"], case["calls"][0]["T"]
+    W, b, X0, inputs, target = make_case_inputs(case)
+    act_o = {"relu": mo.ACT_RELU, "tanh": mo.ACT_TANH, "identity": mo.ACT_IDENTITY}[case["acts"][0]]
+    act_l = {"relu": L.ACT_RELU, "tanh": L.ACT_TANH, "identity": L.ACT_IDENTITY}[case["acts"][0]]
+    loss = case["loss"]
+    kind_o, kind_l, mask = mo.LOSS_NONE, L.LOSS_NONE, 0
+    if loss.startswith("bernoulli"):
+        kind_o, kind_l = mo.LOSS_BERNOULLI, L.LOSS_BERNOULLI
+    elif loss.startswith("gaussian"):
+        kind_o, kind_l = mo.LOSS_GAUSSIAN, L.LOSS_GAUSSIAN
+    if loss.endswith("_mask"):
+        mask = mo.mask_start_from_perc(n_out, case["perc"])
+    net = mo.NetSpec(sizes=sizes, acts=[act_o] * len(sizes), W=W, b=b, ecoef=case["ecoef"], has_head=bool(n_out))
+    lspec = mo.LossSpec(kind_o, target, case["var"], mask) if kind_o != mo.LOSS_NONE else mo.LossSpec()
+    xopt = mo.XOpt(mo.OPT_ADAM if mode["adam"] else mo.OPT_SGD, mode["lr"])
+    seed = 40 + i
+    noise = (lambda t, l: philox.layer_normals(seed, 7 + t, l, 3, B, sizes[l])) if mode["noise"] else None
+    ref = mo.run(net, inputs, X0, lspec, xopt, T, noise=noise, noise_var=1.5, accumulate_p_at=list(range(mode["acc_begin"], T)))
+
+    eng = Engine(sizes, [act_l] * len(sizes), case["n_in"], n_out, B, device=DEV, ecoef=case["ecoef"],
+                 tuning={"barrier": "ws=0", "inplace32": "ws=2", "default": None}[kernel])
+    eng.bind_params([torch.from_numpy(w).to(DEV) for w in W], [None if x is None else torch.from_numpy(x).to(DEV) for x in b])
+    eng.bind_inputs(None if case["inputs_zero"] else torch.from_numpy(inputs).to(DEV))
+    if target is not None:
+        eng.bind_target(torch.from_numpy(target).to(DEV))
+    xs = [torch.from_numpy(x).to(DEV) for x in X0]
+    eng.load_state(xs)
+    res = eng.run(T, loss_kind=kind_l, loss_var=case["var"], mask_start=mask, xopt=L.XOPT_ADAM if mode["adam"] else L.XOPT_SGD, lr=mode["lr"],
+                  noise_mode=L.NOISE_PHILOX if mode["noise"] else L.NOISE_NONE, noise_var=1.5, seed=seed, step_base=7, chain_base=3,
+                  acc_begin=mode["acc_begin"], acc_end=T, energy_mode=L.ENERGY_ALL)
+    eng.store_state(xs)
+    eng.sync_check()
+    en = res.energies.cpu().numpy()
+    scale = max(1.0, float(np.abs(ref.overall).max()))
+    np.testing.assert_allclose(en[:, -1], ref.overall, rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(en[:, 0], ref.loss, rtol=1e-4, atol=1e-5 * scale)
+    for l in range(len(sizes)):
+        np.testing.assert_allclose(xs[l].cpu().numpy(), ref.xs[l], rtol=0, atol=5e-4 * max(1.0, float(np.abs(ref.xs[l]).max())))
+    flat = eng.read_param_grads_flat().cpu().numpy()
+    want = np.concatenate([np.concatenate([gw.reshape(-1)] + ([] if bb is None else [gb.reshape(-1)])) for gw, gb, bb in zip(ref.gW, ref.gb, b)])
+    assert flat.shape == want.shape
+    np.testing.assert_allclose(flat, want, rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(want).max())))
+    eng.close()
