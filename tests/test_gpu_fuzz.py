@@ -82,3 +82,43 @@ def test_random_shape_matches_oracle(i, kernel):
     assert flat.shape == want.shape
     np.testing.assert_allclose(flat, want, rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(want).max())))
     eng.close()
+
+
+@pytest.mark.parametrize("sizes,n_out", [([40, 384, 200], 784), ([64, 512, 256], 300), ([100, 600, 96], 64), ([256, 256, 256, 256], 1000),
+                                         ([16, 500], 0)])
+def test_wide_networks_against_oracle(sizes, n_out):
+    """Widths near the limits of the LDS plans: the 32-chain in-place plan stops fitting, the engine falls back to
+    its 16-chain forms; results must not depend on which form ran."""
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    B, T, lr, seed = 40, 5, 0.02, 9
+    case = dict(sizes=sizes, acts=["relu"] * len(sizes), ecoef=[1.0] * len(sizes), n_in=sizes[0], n_out=n_out, loss="bernoulli" if n_out else "none",
+                var=1.0, perc=0.5, B=B, seed=77, x0_range=1.0, calls=[dict(T=T)])
+    W, b, X0, inputs, target = make_case_inputs(case)
+    net = mo.NetSpec(sizes=sizes, acts=[mo.ACT_RELU] * len(sizes), W=W, b=b, ecoef=case["ecoef"], has_head=bool(n_out))
+    lspec = mo.LossSpec(mo.LOSS_BERNOULLI, target) if n_out else mo.LossSpec()
+    ref = mo.run(net, inputs, X0, lspec, mo.XOpt(mo.OPT_SGD, lr), T, noise=lambda t, l: philox.layer_normals(seed, t, l, 0, B, sizes[l]),
+                 accumulate_p_at=list(range(1, T)))
+    seen = set()
+    for tuning in (None, "ws=2", "ws=0"):
+        eng = Engine(sizes, [L.ACT_RELU] * len(sizes), sizes[0], n_out, B, device=DEV, tuning=tuning)
+        q = eng.query()
+        seen.add((q["step_kernel"], q["chains_per_wg"]))
+        eng.bind_params([torch.from_numpy(w).to(DEV) for w in W], [torch.from_numpy(x).to(DEV) for x in b])
+        eng.bind_inputs(None)
+        if n_out:
+            eng.bind_target(torch.from_numpy(target).to(DEV))
+        xs = [torch.from_numpy(x).to(DEV) for x in X0]
+        eng.load_state(xs)
+        res = eng.run(T, loss_kind=L.LOSS_BERNOULLI if n_out else L.LOSS_NONE, lr=lr, noise_mode=L.NOISE_PHILOX, seed=seed, step_base=0,
+                      acc_begin=1, acc_end=T, energy_mode=L.ENERGY_ALL)
+        eng.store_state(xs)
+        eng.sync_check()
+        np.testing.assert_allclose(res.energies.cpu().numpy()[:, -1], ref.overall, rtol=1e-4)
+        for l in range(len(sizes)):
+            np.testing.assert_allclose(xs[l].cpu().numpy(), ref.xs[l], rtol=0, atol=5e-4 * max(1.0, float(np.abs(ref.xs[l]).max())))
+        flat = eng.read_param_grads_flat().cpu().numpy()
+        want = np.concatenate([np.concatenate([gw.reshape(-1), gb.reshape(-1)]) for gw, gb in zip(ref.gW, ref.gb)])
+        np.testing.assert_allclose(flat, want, rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(want).max())))
+        eng.close()
+    assert len(seen) >= 2
