@@ -204,8 +204,9 @@ def main():
                     "frac": tf / PEAK_FP32_TFLOPS, "traffic": None, "brackets": n, "steps_per_bracket": spl,
                     "avg_bracket_ms": avg_s * 1e3, "us_per_step": avg_s / spl * 1e6,
                     "flop_per_chain_step": 4 * S_MACS,
+                    # the same launches against the HBM roofline (north_star asks for both): algorithmic streaming bytes, SURVEY 8(d)
                     "hbm_side": {"achieved": bytes_per_step * spl / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "bytes_per_chain_step": 7472},
+                                 "frac": bytes_per_step * spl / avg_s / 1e9 / PEAK_HBM_GBS, "bytes_per_chain_step": 7472},
                     # every workgroup streams the packed weights (Wf + Wb, 2.19 MB) out of its XCD's L2 once per step
                     "l2_fragment_stream": {"achieved": n_wg * FRAG_BYTES_PER_WG_STEP * spl / avg_s / 1e9, "peak": PEAK_L2_GBS,
                                            "unit": "GB/s", "frac": n_wg * FRAG_BYTES_PER_WG_STEP * spl / avg_s / 1e9 / PEAK_L2_GBS,
