@@ -292,7 +292,7 @@ int plan_lds_ws2(mcpc_engine* e) {
     if (e->has_head) {
         // fewest chunks of at most 16 tiles whose ring of two still fits; chunks equalised; ring of three if that fits too
         const int ht = std::max(e->out_pad / 16, 1);
-        const int span = kWs2Pairs * kWs2NT;
+        const int span = kWs2Pairs * (CT == 16 ? ws2_nt<1>() : ws2_nt<2>());     // tiles a table entry hands out
         auto fits = [&](int hc, int nb) { return (off + std::max(nb * CT * (hc * 16 + kLdPad), e_sum)) * (int)sizeof(float) <= 160 * 1024; };
         int hc_fit = 0;
         for (int hc = std::min(span, ht); hc >= 1; --hc)
@@ -326,7 +326,7 @@ int plan_lds_ws2(mcpc_engine* e) {
 // after the FWD_{l+1} epilogues, which follow FWD_{l+1}'s GEMM over FX_l).
 int build_phases_ws2(mcpc_engine* e) {
     const int L = e->L;
-    const int span = kWs2Pairs * kWs2NT;     // 16
+    const int span = kWs2Pairs * (e->ct == 16 ? ws2_nt<1>() : ws2_nt<2>());     // tiles per table entry: 16 (32-chain workgroups) or 32 (16-chain)
     auto tiles = [&](int l) { return e->npad[l] / 16; };
     auto blank = [&]() { KPhase k{}; k.dep_e = -1; k.dep_g = -1; k.dep_se = -1; return k; };
     enum { REF_LAST_BWD = -1000, REF_LAST_FWD = -2000, REF_LAST_HB = -3000, REF_LAST_BWD_GEMM = -4000, REF_LAST_BWD_ANY = -5000 };   // symbolic deps
@@ -646,12 +646,24 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     e->nwg = e->Bpad / e->ct;
     for (int l = 0; l < e->L; ++l) e->npad[l] = pad16(d->sizes[l]);
     e->out_pad = pad16(d->n_out);
-    if (e->has_head && e->npad[e->L - 1] / 16 > kNT * kWaves) {
+    // The back-projection of the read-out error is accumulated in registers over the whole read-out: 16 tiles per workgroup
+    // (a last latent layer of up to 256 units) for 32-chain workgroups and for the barrier kernel, 32 tiles (512 units) for
+    // the 16-chain in-place kernel, which a wider last layer therefore selects whatever the shard size.
+    const int last_tiles = e->has_head ? e->npad[e->L - 1] / 16 : 0;
+    const int cap32 = kWs2Pairs * ws2_nt<2>(), cap16 = kWs2Pairs * ws2_nt<1>();
+    if (last_tiles > std::max(cap16, kNT * kWaves) || (last_tiles > kNT * kWaves && e->ws != 2)) {
         delete e;
-        return fail(MCPC_ENOMEM, "last latent layer wider than %d units is not supported by the fused read-out (its back-projection is held in 16 register tiles per workgroup)", kNT * kWaves * 16);
+        return fail(MCPC_ENOMEM, "last latent layer wider than %d units is not supported by the fused read-out (its back-projection is held in register tiles)", std::max(cap16, kNT * kWaves) * 16);
     }
+    if (e->ws == 2 && e->ct == 32 && last_tiles > cap32) { e->ct = 16; e->nwg = e->Bpad / e->ct; }
     int rc = e->ws == 2 ? plan_lds_ws2(e) : plan_lds(e);
-    if (rc && e->ws) {                       // the wave-specialised plan does not fit: classic 16-chain schedule
+    if (rc && e->ws == 2 && e->ct == 32) {   // the 32-chain in-place plan does not fit the LDS: the 16-chain one may
+        g_err.clear();
+        e->ct = 16; e->nwg = e->Bpad / e->ct;
+        rc = plan_lds_ws2(e);
+    }
+    if (rc && e->ws && last_tiles <= kNT * kWaves) {   // no in-place plan fits: classic 16-chain barrier schedule
+        g_err.clear();
         e->ws = 0; e->ct = 16; e->nw = 4; e->nwg = e->Bpad / e->ct;
         rc = plan_lds(e);
     }

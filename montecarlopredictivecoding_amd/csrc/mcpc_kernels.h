@@ -339,22 +339,22 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4*
 }
 
 // nt (wave-uniform, 1..NTT) selects a straight-line instantiation: no per-tile branches in the loop
+template <int N, int NTT, int CTT, int NW>
+__device__ __forceinline__ void gemm_dispatch(f32x4 (&acc)[NTT][CTT], const gf32x4* __restrict__ A, const int (&aoff)[NTT], int nt, int nkb,
+                                              const float* B, int ldb, int lane, const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT]) {
+    if constexpr (N >= NTT) {
+        gemm_fixed<NTT, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1);
+    } else {
+        if (nt == N) gemm_fixed<N, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1);
+        else gemm_dispatch<N + 1, NTT, CTT, NW>(acc, A, aoff, nt, nkb, B, ldb, lane, pre0, pre1);
+    }
+}
 template <int NTT, int CTT, int NW>
 __device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const gf32x4* __restrict__ A,
                                            const int (&aoff)[NTT], int nt, int nkb,
                                            const float* B, int ldb, int lane,
                                            const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT]) {
-    if constexpr (NTT >= 4) {
-        switch (nt) {
-            case 1: gemm_fixed<1, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1); break;
-            case 2: gemm_fixed<2, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1); break;
-            case 3: gemm_fixed<3, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1); break;
-            default: gemm_fixed<4, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1); break;
-        }
-    } else {
-        if (nt == 1) gemm_fixed<1, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1);
-        else gemm_fixed<2, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1);
-    }
+    gemm_dispatch<1, NTT, CTT, NW>(acc, A, aoff, nt, nkb, B, ldb, lane, pre0, pre1);
 }
 
 // request the fragments of k-blocks 0 and 1 of a phase's GEMM (issued one phase early: weights do not

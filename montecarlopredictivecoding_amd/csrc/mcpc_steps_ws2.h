@@ -40,6 +40,15 @@ constexpr int kWs2Pairs = MCPC_WS2_PAIRS;          // (G, E) pairs per workgroup
 #define MCPC_WS2_WAVES_PER_EU 2
 #endif
 constexpr int kWs2NT = MCPC_WS2_SPAN / kWs2Pairs;   // unit tiles per pair per table entry: an entry hands out 16 tiles
+// Tiles per pair and entry of a 16-CHAIN workgroup (build-time knob): with one chain tile the same accumulator registers would
+// hold 8 unit tiles, i.e. half as many table entries and hand-overs per step.  Measured (round 2): 6 (the most that compiles
+// without spilling: three fragment sets of NT registers each) and 5 against 4 -- 50.7 / 50.0 / 51.4 us per step at 4096 chains,
+// 76.7 / 76.4 / 76.2 on the mixed schedule at 6000: within the noise, so the hand-over count is not what the 16-chain form
+// pays for, and the default stays 4 (one table layout, 140 KB less code).
+#ifndef MCPC_WS2_NT16
+#define MCPC_WS2_NT16 kWs2NT
+#endif
+template <int CTT> constexpr int ws2_nt() { return CTT == 1 ? MCPC_WS2_NT16 : kWs2NT; }
 constexpr int kWs2Threads = 2 * kWs2Pairs * 64;
 static_assert(kWs2Pairs == 4 || kWs2Pairs == 8, "4 or 8 pairs");
 
@@ -92,18 +101,19 @@ __device__ __forceinline__ int ws2_need(int base, int n_ent, int p, int dep) {
 // Branch-free: all four tile slots always issue both loads; unused slots repeat slot 0 (L1 hits) and entries without
 // a GEMM read `dummy` (any 2 KiB of valid global memory).  With the loads under `if (i < nt)` hipcc joined every
 // branch behind `s_waitcnt vmcnt(0)`: four serial L2 round trips (~1 k cycles) per table entry.
-__device__ __forceinline__ void ws2_prefetch(const KPhase& ph, int k, int lane, const void* dummy, int& nt_out, int (&aoff)[kWs2NT],
-                                             f32x4 (&pre0)[kWs2NT], f32x4 (&pre1)[kWs2NT]) {
+template <int NT>
+__device__ __forceinline__ void ws2_prefetch(const KPhase& ph, int k, int lane, const void* dummy, int& nt_out, int (&aoff)[NT],
+                                             f32x4 (&pre0)[NT], f32x4 (&pre1)[NT]) {
     const int kk = (k + ph.rot) & (kWs2Pairs - 1);
     int nt = (ph.ntiles - kk + kWs2Pairs - 1) / kWs2Pairs;
-    nt = nt < 0 ? 0 : (nt > kWs2NT ? kWs2NT : nt);
+    nt = nt < 0 ? 0 : (nt > NT ? NT : nt);
     if (!(ph.flags & PHF_WS_GEMM) || ph.nkb <= 0) nt = 0;
     nt_out = nt;
     const bool valid = nt > 0;
     const gf32x4* const A = valid ? (const gf32x4*)ph.A : (const gf32x4*)dummy;
     const int second = (valid && ph.nkb > 1) ? 64 : 0;
 #pragma unroll
-    for (int i = 0; i < kWs2NT; ++i) {
+    for (int i = 0; i < NT; ++i) {
         const int ii = i < nt ? i : 0;
         const int off = valid ? (ph.tile0 + kk + kWs2Pairs * ii) * ph.a_tile_stride + ph.a_off0 : 0;
         aoff[i] = off;
@@ -201,7 +211,7 @@ __device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPha
 template <int CTT, bool MIX = false>
 __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps_ws2_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NW = kWs2Pairs, NTW = kWs2NT;
+    constexpr int NW = kWs2Pairs, NTW = ws2_nt<CTT>();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -235,10 +245,10 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
         // variables -- with separate "next" copies hipcc put `s_waitcnt vmcnt(0)` + 16 v_mov at the loop latch, i.e.
         // every entry waited out the L2 round trip of the prefetch it had just issued.
         KPhase ph_next = load_phase(P.phases, 0);
-        int nt_next, aoff[kWs2NT];
-        f32x4 pre0[kWs2NT], pre1[kWs2NT];
+        int nt_next, aoff[NTW];
+        f32x4 pre0[NTW], pre1[NTW];
 #pragma unroll
-        for (int i = 0; i < kWs2NT; ++i) { pre0[i] = splat(0.f); pre1[i] = splat(0.f); aoff[i] = 0; }
+        for (int i = 0; i < NTW; ++i) { pre0[i] = splat(0.f); pre1[i] = splat(0.f); aoff[i] = 0; }
         ws2_prefetch(ph_next, k, lane, P.mu1, nt_next, aoff, pre0, pre1);
         STAMP_DECL
 #ifdef MCPC_STAMPS
@@ -246,9 +256,9 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
 #endif
         for (int s = 0; s < P.n_steps; ++s) {
             const int base = s * n_ent;
-            f32x4 accb[kWs2NT][CTT];                       // back-projection of the read-out error: 16 tiles over the pairs
+            f32x4 accb[NTW][CTT];                       // back-projection of the read-out error: 16 tiles over the pairs
 #pragma unroll
-            for (int i = 0; i < kWs2NT; ++i)
+            for (int i = 0; i < NTW; ++i)
 #pragma unroll
                 for (int ct = 0; ct < CTT; ++ct) accb[i][ct] = splat(0.f);
 #pragma unroll 1
@@ -261,9 +271,9 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                 const bool is_headb = ph.type == PH_HEADB;
                 const bool works = (ph.flags & PHF_WS_GEMM) || handoff;
                 const bool stores = works && !is_headb;
-                f32x4 acc[kWs2NT][CTT];
+                f32x4 acc[NTW][CTT];
 #pragma unroll
-                for (int i = 0; i < kWs2NT; ++i)
+                for (int i = 0; i < NTW; ++i)
 #pragma unroll
                     for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = splat(0.f);
                 STAMP(0);
@@ -278,17 +288,17 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
 #endif
                     STAMP(1);
                     if (is_headb) {
-                        if (nt > 0 MCPC_EXP_GEMM_GATE) gemm_tiles<kWs2NT, CTT, NW>(accb, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
+                        if (nt > 0 MCPC_EXP_GEMM_GATE) gemm_tiles<NTW, CTT, NW>(accb, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
                         STAMP(2);
                     } else {
                         if (handoff) {
 #pragma unroll
-                            for (int i = 0; i < kWs2NT; ++i)
+                            for (int i = 0; i < NTW; ++i)
 #pragma unroll
                                 for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = accb[i][ct];     // one entry covers all of accb
                         }
                         if (nt > 0 && ph.nkb > 0 MCPC_EXP_GEMM_GATE)
-                            gemm_tiles<kWs2NT, CTT, NW>(acc, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
+                            gemm_tiles<NTW, CTT, NW>(acc, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
                         STAMP(3);
                     }
                 }
@@ -309,11 +319,11 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                     // the block goes where its consumer reads it; E_k finishes it in place
                     const int kk = (k + ph.rot) & (NW - 1);
                     int ntw = (ph.ntiles - kk + NW - 1) / NW;
-                    ntw = ntw < 0 ? 0 : (ntw > kWs2NT ? kWs2NT : ntw);
+                    ntw = ntw < 0 ? 0 : (ntw > NTW ? NTW : ntw);
                     float* const out = lds + ph.out_lds;
                     const int col0 = (ph.type == PH_HEADF) ? 0 : 16 * ph.tile0;
 #pragma unroll
-                    for (int i = 0; i < kWs2NT; ++i) {
+                    for (int i = 0; i < NTW; ++i) {
                         if (i >= ntw) continue;
                         const int col = col0 + 16 * (kk + NW * i) + 4 * q;
 #pragma unroll
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
             }
             const int kk = (k + ph.rot) & (NW - 1);
             int nt = (ph.ntiles - kk + NW - 1) / NW;
-            nt = nt < 0 ? 0 : (nt > kWs2NT ? kWs2NT : nt);
+            nt = nt < 0 ? 0 : (nt > NTW ? NTW : nt);
 #ifndef MCPC_EXP_NOLEAN
             if (lean) {
                 const int act = P.layer[ph.layer].act;
@@ -451,9 +461,9 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                 continue;
             }
 #endif
-            f32x4 acc[kWs2NT][CTT], pa[kWs2NT][CTT], pb[kWs2NT][CTT];
+            f32x4 acc[NTW][CTT], pa[NTW][CTT], pb[NTW][CTT];
 #pragma unroll
-            for (int i = 0; i < kWs2NT; ++i)
+            for (int i = 0; i < NTW; ++i)
 #pragma unroll
                 for (int ct = 0; ct < CTT; ++ct) { acc[i][ct] = splat(0.f); pa[i][ct] = splat(0.f); pb[i][ct] = splat(0.f); }
             const KLayer& Ly = P.layer[ph.layer];
@@ -474,7 +484,7 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
                 const float* const src = lds + ph.out_lds;
                 const int col0 = (ph.type == PH_HEADF) ? 0 : 16 * ph.tile0;
 #pragma unroll
-                for (int i = 0; i < kWs2NT; ++i) {
+                for (int i = 0; i < NTW; ++i) {
                     const int col = col0 + 16 * (kk + NW * (i < nt ? i : 0)) + 4 * q;     // unused slots re-read slot 0
 #pragma unroll
                     for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = ld4(src + (16 * ct + c) * ph.out_ld + col);
