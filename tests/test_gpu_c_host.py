@@ -36,6 +36,8 @@ def write_case(path, case, W, b, X0, target, T, acc_begin, loss_kind, act, lr, n
 @pytest.mark.gpu
 @pytest.mark.parametrize("loss,sizes,n_out,batch", [("bernoulli", [12, 48, 40], 100, 50), ("gaussian", [7, 33], 21, 19)])
 def test_plain_c_host_matches_oracle(tmp_path, loss, sizes, n_out, batch):
+    if not os.path.exists(HOST):          # normally built by __graft_entry__.build(); the box has the same gcc
+        subprocess.run(["make", "-C", os.path.dirname(HOST)], check=True, capture_output=True)
     assert os.path.exists(HOST), f"{HOST} missing: python -c 'import __graft_entry__ as g; g.build()'"
     T, acc_begin, lr, noise_var, var, seed = 14, 4, 0.03, 2.0, 0.6, 77
     case = dict(sizes=sizes, acts=["relu"] * len(sizes), ecoef=[1.0] * len(sizes), n_in=sizes[0], n_out=n_out, loss=loss, var=var,
