@@ -122,3 +122,46 @@ def test_wide_networks_against_oracle(sizes, n_out):
         np.testing.assert_allclose(flat, want, rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(want).max())))
         eng.close()
     assert len(seen) >= 2
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_slicing_of_a_call_is_invisible(seed):
+    """mcpc_run executes a slice [t_begin, t_begin + n_steps) of a call: any cut of a call into slices -- through the accumulation
+    window, with Adam's step count carried (adam_step0) or the Philox counter indexed by the step of the CALL -- must leave states and
+    energies bitwise those of the single run, and the Hebbian sums equal up to the order of the partial sums of the slices."""
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    r = np.random.RandomState(70 + seed)
+    sizes = [int(r.randint(3, 40)) for _ in range(int(r.randint(1, 4)))]
+    n_out, B, T = int(r.randint(5, 60)), int(r.choice([9, 16, 40, 70])), int(r.randint(12, 40))
+    adam = seed % 2 == 1
+    case = dict(sizes=sizes, acts=["tanh"] * len(sizes), ecoef=[1.0] * len(sizes), n_in=sizes[0], n_out=n_out, loss="bernoulli", var=1.0, perc=0.5,
+                B=B, seed=900 + seed, x0_range=1.0, calls=[dict(T=T)])
+    W, b, X0, inputs, target = make_case_inputs(case)
+    acc_begin = int(r.randint(0, T - 2))
+    cuts = sorted(set([0, T] + [int(v) for v in r.randint(1, T, size=int(r.randint(1, 5)))]))
+    kw = dict(loss_kind=L.LOSS_BERNOULLI, xopt=L.XOPT_ADAM if adam else L.XOPT_SGD, lr=0.05, noise_mode=L.NOISE_NONE if adam else L.NOISE_PHILOX,
+              seed=3, step_base=11, acc_begin=acc_begin, acc_end=T, energy_mode=L.ENERGY_ALL)
+    outs = []
+    for sliced in (False, True):
+        eng = Engine(sizes, [L.ACT_TANH] * len(sizes), sizes[0], n_out, B, device=DEV)
+        eng.bind_params([torch.from_numpy(w).to(DEV) for w in W], [torch.from_numpy(x).to(DEV) for x in b])
+        eng.bind_inputs(None); eng.bind_target(torch.from_numpy(target).to(DEV))
+        xs = [torch.from_numpy(x).to(DEV) for x in X0]
+        eng.load_state(xs)
+        en = torch.zeros(T, L.ENERGY_COLS, dtype=torch.float64, device=DEV)
+        if not sliced:
+            eng.run(T, energies_out=en, **kw)
+        else:
+            for t0, t1 in zip(cuts[:-1], cuts[1:]):
+                eng.run(T, t_begin=t0, n_steps=t1 - t0, adam_step0=t0, energies_out=en, acc_reset=(t0 <= acc_begin < t1), **kw)
+        eng.store_state(xs)
+        flat = eng.read_param_grads_flat()
+        eng.sync_check()
+        outs.append((en.cpu().numpy(), [x.cpu().numpy() for x in xs], flat.cpu().numpy()))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for a, c in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, c)
+    np.testing.assert_allclose(outs[1][2], outs[0][2], rtol=2e-5, atol=2e-6 * max(1.0, float(np.abs(outs[0][2]).max())))
+    assert np.isfinite(outs[0][0]).all()
