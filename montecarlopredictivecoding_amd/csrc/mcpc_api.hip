@@ -638,6 +638,13 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess || n_cu <= 0) n_cu = 256;
     int want_ws = (!kn.ct && !kn.nw) ? 2 : 0;
     bool ct16 = (d->batch + 15) / 16 <= n_cu;
+    if (!ct16) {
+        // Shards of more than one round of workgroups: a round of 16-chain workgroups takes 1 / 1.65 of a round of 32-chain ones
+        // (54 against 88.5 us per step at cfg-M with every CU taken), so the form with the cheaper sum of rounds wins -- 12 000
+        // chains: 3 x 54 against 2 x 88.5 us.  (One round of 32-chain workgroups with CUs to spare is the mixed schedule's case.)
+        const int r32 = ((d->batch + 31) / 32 + n_cu - 1) / n_cu, r16 = ((d->batch + 15) / 16 + n_cu - 1) / n_cu;
+        if (r32 >= 2 && r16 < 1.65 * r32 - 0.05) ct16 = true;
+    }
     if (kn.ws != -1) {
         want_ws = kn.ws;
         ct16 = kn.ct == 16;

@@ -465,3 +465,25 @@ def test_oversized_networks_are_rejected_not_miscomputed():
         Engine([32, 384], [1, 1], 32, 100, 32, device=DEV)
     with pytest.raises(ValueError):
         Engine([4] * 7, [0] * 7, 4, 0, 8, device=DEV)
+
+
+def test_shards_of_several_rounds_pick_the_cheaper_workgroup_form():
+    """More chains than one round of 32-chain workgroups covers: 9000 chains are 2 rounds of 32-chain workgroups or 3 of 16-chain
+    ones, which are 1.65x shorter -- the engine picks the 16-chain form; 16 384 chains (2 rounds against 4) keep the 32-chain form.
+    Per chain the two forms compute the same thing: states bitwise equal to the forced other form."""
+    from montecarlopredictivecoding_amd import _lib as L
+    W, b, y, xs = _problem(9000)
+    outs = []
+    for tuning, want in ((None, 16), ("ws=2,ct=32", 32)):
+        eng = _engine(9000, W, b, y, tuning=tuning)
+        assert eng.query()["chains_per_wg"] == want
+        res, out = _run(eng, xs, 12, acc_begin=4, acc_end=12)
+        outs.append(([o.cpu().numpy() for o in out], res.energies.cpu().numpy()))
+        eng.close()
+    for a, c in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, c)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=2e-6)
+    from montecarlopredictivecoding_amd.engine import Engine
+    eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, 16384, device=DEV)
+    assert eng.query()["chains_per_wg"] == 32
+    eng.close()
