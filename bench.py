@@ -99,7 +99,16 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the inference-only calls (clean PMC passes of the learning call)")
     ap.add_argument("--only-inference", action="store_true", help="time inference-only calls only (clean PMC passes of the mixed schedule)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="developer check: take the multi-rank code path (RCCL group, barriers, all-reduces) with whatever world size the "
+                         "environment gives, 1 included -- the 1-GPU rehearsal of what the driver launches with torch.distributed.run")
     args = ap.parse_args()
+
+    # stdout carries ONE JSON line and nothing else: libraries that chat on fd 1 (RCCL prints a version banner there when a
+    # communicator is created) are pointed at stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -108,9 +117,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -272,7 +284,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, args.cpu_budget)
             out["config"]["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     eng.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -576,7 +576,15 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
     if ((rc = dmalloc(e->mix_tab, tab.size()))) return rc;
     if (hipMemcpy(e->mix_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
         return fail(MCPC_EHIP, "hipMemcpy of the mixed-schedule tables failed");
-    if (hipStreamCreateWithFlags(&e->aux2, hipStreamNonBlocking) != hipSuccess) return fail(MCPC_EHIP, "hipStreamCreateWithFlags failed");
+    // The split half of a segment runs on a stream of its own, which must map to a hardware queue of its own: the HIP runtime
+    // spreads normal-priority streams over GPU_MAX_HW_QUEUES = 4 queues, and in a process that also holds an RCCL communicator
+    // (torch.distributed: its streams take queues too) this stream came to share the caller's queue -- the two launches of
+    // every segment ran one after the other, 145 us per step instead of 76.  High-priority streams have their own queues.
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // hi = most urgent (numerically lowest)
+        if (hipStreamCreateWithPriority(&e->aux2, hipStreamNonBlocking, hi) != hipSuccess) return fail(MCPC_EHIP, "hipStreamCreateWithPriority failed");
+    }
     for (int i = 0; i < 2; ++i)
         if (hipEventCreateWithFlags(&e->ev_mix[i], hipEventDisableTiming) != hipSuccess) return fail(MCPC_EHIP, "hipEventCreate failed");
     e->mix_ns = ns; e->mix_np = np; e->mix_lc = lc; e->mix_a = cnt_a[0];

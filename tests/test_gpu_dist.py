@@ -101,3 +101,25 @@ def test_native_rccl_allreduce_of_the_gradient_bucket_one_rank():
     eng.comm_destroy()
     eng.comm_destroy()                     # idempotent
     eng.close()
+
+
+def test_bench_multi_rank_code_path_with_one_rank():
+    """bench.py's N > 1 path (RCCL group, barrier + synchronize brackets, all-reduce of the gradient bucket, MAX over ranks of the
+    wall time) launched the way the driver launches it (torch.distributed.run), with the one rank this box has: one JSON line on
+    stdout, learning and inference-only calls timed, the collective named in the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--T", "400",
+           "--force-dist", "--no-cpu-baseline"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, run.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["config"]["T"] == 400 and out["config"]["finite"]
+    assert out["value"] > 1000 and out["config"]["inference_only"]["steps_per_s"] > out["value"]
+    assert out["roofline"]["bound"] == "mfma" and 0.2 < out["roofline"]["frac"] < 1.0
