@@ -196,8 +196,8 @@ Rccl g_rccl;
 
 int rccl_load() {
     if (g_rccl.so) return MCPC_OK;
-    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    void* so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!so) return fail(MCPC_EHIP, "librccl.so.1 could not be loaded: %s", dlerror());
     Rccl r;
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(so, "ncclGetUniqueId");
