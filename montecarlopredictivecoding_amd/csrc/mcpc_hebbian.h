@@ -34,9 +34,14 @@ struct HebArgs {
     int e_col_base;                  // first E column of this launch (a Linear may be covered by launches of different TE)
 };
 
+#ifndef MCPC_HEB_LD_AUX
+#define MCPC_HEB_LD_AUX 0          // cache policy of the spill reads (0 plain, 1 sc0, 2 nt, 16 sc1, 18 nt sc1): the learning call runs
+                                   // within 0.2 us per step of itself with any of them (scripts/lib_ab.sh), so the reads are not what
+                                   // costs the step kernel beside it its L2 hits (0.82 against 0.95-0.99 without a flush)
+#endif
 __device__ __forceinline__ void heb_glds16(const float* gsrc, float* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, MCPC_HEB_LD_AUX);
 }
 
 // SWAPPED: the launch computes the TRANSPOSED product for a Linear with a narrow input (the E slot holds its activations,
