@@ -80,12 +80,12 @@ typedef struct mcpc_net_desc {
     int32_t n_out;                       /* width of the read-out Linear; 0 = model ends with a PCLayer */
     int32_t batch;                       /* chains held by this engine (local shard) */
     int32_t device;                      /* HIP device ordinal */
-    int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default: room for 128 steps (5.7 GB at 6000 chains of
-                                          * cfg-M's net), at least 6 GiB, at most a quarter of the device's memory */
+    int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default: room for 192 steps in three parts (8.5 GB at 6000
+                                          * chains of cfg-M's net), at least 6 GiB, at most a quarter of the device's memory */
     const char* tuning;                  /* NULL, or developer overrides of the schedule heuristics as "key=value,key=value"
                                           * (parsed once by mcpc_create, not kept): ws=0|2 step kernel (barrier / in-place),
                                           * ct=16|32 chains per workgroup, nw=4|8, no_mix=1, no_overlap=1, slot_cap=N,
-                                          * spill_gb=N, mix_slack=N, mix_ratio=N, dw_ksplit=N, ws_prio=0|1|2, stagger=N, no_lean=1, no_ybits=1.  Unknown keys are
+                                          * spill_gb=N, ring_parts=N, flush_tail=N, mix_slack=N, mix_ratio=N, dw_ksplit=N, ws_prio=0|1|2, stagger=N, no_lean=1, no_ybits=1.  Unknown keys are
                                           * an error.  Used by A/B runs and by the tests that pin every kernel variant. */
 } mcpc_net_desc;
 

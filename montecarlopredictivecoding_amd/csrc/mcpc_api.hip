@@ -57,15 +57,20 @@ struct Lin {
 
 // Developer overrides of the schedule heuristics, parsed ONCE from mcpc_net_desc::tuning at mcpc_create
 // ("key=value,key=value"; see include/mcpc.h).  The library itself reads no environment variables.
+constexpr int kMaxRingParts = 8;
 struct Knobs {
     int ws = -1;              // -1: automatic; 0: barrier kernel; 2: in-place wave-specialised kernel
     int ct = 0;               // 0: automatic; 16 / 32 chains per workgroup
     int nw = 0;               // 0: automatic; 4 / 8 waves per workgroup of the barrier kernel
     int no_mix = 0;           // 1: never use the mixed 32-/16-chain schedule
     int no_overlap = 0;       // 1: Hebbian flushes run serially on the caller's stream (one ring segment = the whole ring)
-    int slot_cap = 128;       // upper bound on spill-ring slots
+    int slot_cap = 192;       // spill-ring slots at most (3 parts of 64 steps)
     int spill_gb = 0;         // > 0: spill budget in GiB (overrides mcpc_net_desc::spill_budget_bytes)
     int mix_slack = 0;        // CUs the mixed schedule leaves free
+    int flush_tail = 0;       // > 0: the last accumulating segment of a stretch is cut to this many steps (its flush is the one nothing overlaps)
+    int ring_parts = 3;       // parts of the spill ring: one is filled by the step kernel, one is being flushed, one is slack -- with two
+                              // halves the step kernel waited at every boundary for a flush that takes as long as its own segment
+                              // (96.8 -> 95.2 us per step of the learning call; parts of 64 steps beat 48, 96 and 128)
     int mix_ratio = 17;       // steps of a split unit per 10 steps of a paired one (the rate ratio of the two workgroup forms)
     int dw_ksplit = 0;        // > 0: K-splits per workgroup tile of the Hebbian GEMM (0: one wave of workgroups over the chip)
     int ws_prio = 1;          // 1: epilogue waves at raised priority, 2: GEMM waves, 0: neither
@@ -91,7 +96,7 @@ int parse_tuning(const char* str, Knobs& k) {
         const int val = eq == std::string::npos ? 1 : atoi(item.c_str() + eq + 1);
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
-            {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"dw_ksplit", &k.dw_ksplit},
+            {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"dw_ksplit", &k.dw_ksplit},
             {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}};
         bool found = false;
         for (auto& t : table)
@@ -103,6 +108,7 @@ int parse_tuning(const char* str, Knobs& k) {
     if (k.nw != 0 && k.nw != 4 && k.nw != 8) return fail(MCPC_EINVAL, "tuning nw=%d: 4 or 8", k.nw);
     if (k.slot_cap < 2) k.slot_cap = 2;
     if (k.mix_slack < 0) k.mix_slack = 0;
+    if (k.ring_parts < 2 || k.ring_parts > kMaxRingParts) return fail(MCPC_EINVAL, "tuning ring_parts=%d: 2..%d", k.ring_parts, kMaxRingParts);
     if (k.mix_ratio < 10 || k.mix_ratio > 30) return fail(MCPC_EINVAL, "tuning mix_ratio=%d: 10..30 (tenths)", k.mix_ratio);
     return 0;
 }
@@ -137,8 +143,8 @@ struct mcpc_engine {
     // Hebbian spill ring: two halves, the flush of one half runs on `aux` while the step kernel fills the other
     int slots = 0, half_slots = 0;
     hipStream_t aux = nullptr;
-    hipEvent_t ev_steps[2] = {nullptr, nullptr}, ev_flush[2] = {nullptr, nullptr};
-    bool flush_pending[2] = {false, false};
+    hipEvent_t ev_steps[kMaxRingParts] = {}, ev_flush[kMaxRingParts] = {};
+    bool flush_pending[kMaxRingParts] = {};
     float* spill_a[kMaxLatent]{};
     float* spill_e[kMaxLatent]{};
     float* spill_eo = nullptr;
@@ -223,7 +229,7 @@ int free_all(mcpc_engine* e) {
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : e->events_mix) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     e->events_mix.clear();
-    for (int h = 0; h < 2; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
+    for (int h = 0; h < kMaxRingParts; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
     if (e->aux) { (void)hipStreamDestroy(e->aux); e->aux = nullptr; }
     if (e->aux2) { (void)hipStreamDestroy(e->aux2); e->aux2 = nullptr; }
     for (int h = 0; h < 2; ++h) if (e->ev_mix[h]) { (void)hipEventDestroy(e->ev_mix[h]); e->ev_mix[h] = nullptr; }
@@ -732,8 +738,10 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     }
     if (kn.spill_gb > 0) budget = (int64_t)kn.spill_gb << 30;
     e->slots = (int)std::max<int64_t>(1, std::min<int64_t>(kn.slot_cap, budget / (int64_t)per_slot));
-    if (e->slots >= 2) { e->slots &= ~1; e->half_slots = e->slots / 2; } else { e->half_slots = 1; }
-    if (kn.no_overlap) e->half_slots = e->slots;             // serial flushes on the caller's stream
+    // `half_slots` = slots of one PART of the ring = steps of one Hebbian segment
+    if (kn.no_overlap || e->slots < 2) e->half_slots = e->slots;          // serial flushes on the caller's stream: one part
+    else if (e->slots >= kn.ring_parts) { e->half_slots = e->slots / kn.ring_parts; e->slots = e->half_slots * kn.ring_parts; }
+    else { e->slots &= ~1; e->half_slots = e->slots / 2; }                   // fewer slots than parts: two halves
     // (the ring itself -- up to 6 GiB -- is allocated by the first run that accumulates Hebbian sums: ensure_spill)
 
     if ((rc = e->ws == 2 ? build_phases_ws2(e) : build_phases(e))) return bail(rc);
@@ -936,7 +944,7 @@ int ensure_spill(mcpc_engine* e) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least urgent
         if (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, lo) != hipSuccess) return fail(MCPC_EHIP, "hipStreamCreateWithPriority failed");
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < kMaxRingParts; ++h)
             if (hipEventCreateWithFlags(&e->ev_steps[h], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&e->ev_flush[h], hipEventDisableTiming) != hipSuccess)
                 return fail(MCPC_EHIP, "hipEventCreate failed");
@@ -1186,7 +1194,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     int t = r->t_begin;
     const int end = r->t_begin + r->n_steps;
     const bool overlap = e->aux != nullptr;
-    int half = 0;
+    int half = 0;                                         // part of the ring the next accumulating segment spills into
+    const int n_parts = std::max(1, e->slots / std::max(1, e->half_slots));
     // mixed schedule for stretches without Hebbian accumulation (fused x updates only: the gradients-only mode hands dF/dx to
     // the caller after every single step)
     bool mix_ok = e->mix && r->update_x;
@@ -1249,7 +1258,13 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     while (t < end) {
         const bool in_acc = t >= acc_b && t < acc_e;
         int n;
-        if (in_acc) n = std::min(std::min(end, acc_e) - t, e->half_slots);
+        if (in_acc) {
+            const int rem = std::min(end, acc_e) - t;
+            n = std::min(rem, e->half_slots);
+            // the flush of a stretch's LAST segment has no step kernel to hide behind: keep that segment short
+            const int tail = e->knobs.flush_tail;
+            if (overlap && tail > 0 && rem <= e->half_slots && rem >= 2 * tail && std::min(end, acc_e) == acc_e) n = rem - tail;
+        }
         else n = (t < acc_b ? std::min(end, acc_b) : end) - t;
         if (!in_acc && mix_ok) {
             // As many whole cycles as fit, longest segments first; what is left runs on the plain schedule below.  A cycle with p
@@ -1353,7 +1368,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
                 if (rc) return rc;
                 HIP_TRY(hipEventRecord(e->ev_flush[half], e->aux));
                 e->flush_pending[half] = true;
-                half ^= 1;
+                half = (half + 1) % n_parts;
             } else {
                 int rc = flush_spill(e, n, 0, stream);
                 if (rc) return rc;
@@ -1362,7 +1377,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         t += n;
     }
     // everything that follows on the caller's stream (dw0, gradient read-out, the next run) sees finished sums
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < kMaxRingParts; ++h)
         if (overlap && e->flush_pending[h]) { HIP_TRY(hipStreamWaitEvent(stream, e->ev_flush[h], 0)); e->flush_pending[h] = false; }
     if (run_accumulates) {
         // Linear 0 sees a constant input: fold sum_t e_1 now, then clear the running sum

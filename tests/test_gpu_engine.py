@@ -151,17 +151,18 @@ def _per_slot_bytes(case):
 
 
 @pytest.mark.parametrize("overlap", [True, False])
-@pytest.mark.parametrize("slots", [2, 4, 8])
+@pytest.mark.parametrize("slots,parts", [(2, 3), (3, 3), (6, 3), (4, 2), (8, 2), (8, 4)])
 @pytest.mark.parametrize("name", ["g2_cfgM_b64", "g8_ragged", "g6_nonzero_inputs"])
-def test_hebbian_ring_reuse_matches_reference_golden(name, slots, overlap):
+def test_hebbian_ring_reuse_matches_reference_golden(name, slots, parts, overlap):
     """The learning call at T = 5000 re-uses each half of the Hebbian spill ring dozens of times, with the flush of one half
     overlapped with the steps that fill the other (pc_trainer.py:853-862,904-914 is what the sums must equal).  Here the ring
-    is shrunk through mcpc_net_desc::spill_budget_bytes to 2, 4 and 8 slots, so the 80 / 15 / 8 accumulating steps of the
-    fixtures wrap it up to 40 times -- with the overlapped flush (two halves, low-priority stream, ev_flush waits) and with the
-    serial one -- and dW / db must still be the reference's.  g2_cfgM_b64 runs the LDS-tiled Hebbian kernel (784 x 256 and
+    is shrunk through mcpc_net_desc::spill_budget_bytes to 2 ... 8 slots in 2, 3 (the default) or 4 parts, so the 80 / 15 / 8
+    accumulating steps of the fixtures wrap it up to 40 times -- with the overlapped flush (parts flushed one by one on the
+    low-priority stream behind ev_flush waits; 2 slots: two halves of one) and with the serial one -- and dW / db must still be the
+    reference's.  g2_cfgM_b64 runs the LDS-tiled Hebbian kernel (784 x 256 and
     256 x 256) plus the streaming one (256 x 32); the small nets the streaming kernel only."""
     g = Golden(name)
-    eng = make_engine(g, spill_budget_bytes=slots * _per_slot_bytes(g.case), tuning=None if overlap else "no_overlap=1")
+    eng = make_engine(g, spill_budget_bytes=slots * _per_slot_bytes(g.case), tuning=f"ring_parts={parts}" + ("" if overlap else ",no_overlap=1"))
     assert eng.query()["spill_slots"] == slots
     bind(eng, g)
     dev = _dev()

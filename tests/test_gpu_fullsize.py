@@ -244,7 +244,7 @@ def test_mixed_schedule_other_shard_sizes(batch, T, monkeypatch):
 
 def test_hebbian_ring_wraps_full_size():
     """B = 6000, Hebbian sums over 400 steps (pc_trainer.py:853-862: autograd adds dF/dtheta of every accumulating step).
-    The default ring (128 slots, halves of 64, overlapped flush) wraps three times.  Checked against
+    The default ring (192 slots, three parts of 64, overlapped flush) wraps twice.  Checked against
       (1) the serial flush with the same segment length (no_overlap, 64 slots): BITWISE -- the overlap (second stream,
           ev_flush waits, ring halves) must not change a single bit of the bucket;
       (2) a ring that never wraps (448 slots, one flush of all 400 steps): equal up to summation order;
@@ -262,7 +262,7 @@ def test_hebbian_ring_wraps_full_size():
         if key == "overlap":
             kw.update(rec_begin=acc0, rec_stride=1, rec_count=n_acc, rec_x=True)
         res, out = _run(eng, xs, T, **kw)
-        assert eng.query()["spill_slots"] == {"overlap": 128, "serial": 64, "nowrap": 448}[key]
+        assert eng.query()["spill_slots"] == {"overlap": 192, "serial": 64, "nowrap": 448}[key]
         runs[key] = eng.read_param_grads_flat().cpu().numpy()
         if key == "overlap":
             rec = res.rec_x
