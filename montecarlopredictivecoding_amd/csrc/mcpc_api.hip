@@ -67,6 +67,7 @@ struct Knobs {
     int slot_cap = 192;       // spill-ring slots at most (3 parts of 64 steps)
     int spill_gb = 0;         // > 0: spill budget in GiB (overrides mcpc_net_desc::spill_budget_bytes)
     int mix_slack = 0;        // CUs the mixed schedule leaves free
+    int flush_streams = 2;    // low-priority streams the GEMMs of an overlapped flush are spread over (1 or 2)
     int flush_tail = 0;       // > 0: the last accumulating segment of a stretch is cut to this many steps (its flush is the one nothing overlaps)
     int ring_parts = 3;       // parts of the spill ring: one is filled by the step kernel, one is being flushed, one is slack -- with two
                               // halves the step kernel waited at every boundary for a flush that takes as long as its own segment
@@ -96,7 +97,7 @@ int parse_tuning(const char* str, Knobs& k) {
         const int val = eq == std::string::npos ? 1 : atoi(item.c_str() + eq + 1);
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
-            {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"dw_ksplit", &k.dw_ksplit},
+            {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
             {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}};
         bool found = false;
         for (auto& t : table)
@@ -144,6 +145,8 @@ struct mcpc_engine {
     int slots = 0, half_slots = 0;
     hipStream_t aux = nullptr;
     hipEvent_t ev_steps[kMaxRingParts] = {}, ev_flush[kMaxRingParts] = {};
+    hipStream_t aux3 = nullptr;     // second low-priority stream of the overlapped flush: the GEMMs of a flush alternate between the two,
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // so that the tail of one launch is filled by the next (same-stream kernels serialise)
     bool flush_pending[kMaxRingParts] = {};
     float* spill_a[kMaxLatent]{};
     float* spill_e[kMaxLatent]{};
@@ -231,6 +234,9 @@ int free_all(mcpc_engine* e) {
     e->events_mix.clear();
     for (int h = 0; h < kMaxRingParts; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
     if (e->aux) { (void)hipStreamDestroy(e->aux); e->aux = nullptr; }
+    if (e->aux3) { (void)hipStreamDestroy(e->aux3); e->aux3 = nullptr; }
+    if (e->ev_fork) { (void)hipEventDestroy(e->ev_fork); e->ev_fork = nullptr; }
+    if (e->ev_join) { (void)hipEventDestroy(e->ev_join); e->ev_join = nullptr; }
     if (e->aux2) { (void)hipStreamDestroy(e->aux2); e->aux2 = nullptr; }
     for (int h = 0; h < 2; ++h) if (e->ev_mix[h]) { (void)hipEventDestroy(e->ev_mix[h]); e->ev_mix[h] = nullptr; }
     F(e->mix_tab); F(e->alt16.phases);
@@ -944,6 +950,11 @@ int ensure_spill(mcpc_engine* e) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least urgent
         if (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, lo) != hipSuccess) return fail(MCPC_EHIP, "hipStreamCreateWithPriority failed");
+        if (e->knobs.flush_streams >= 2 &&
+            (hipStreamCreateWithPriority(&e->aux3, hipStreamNonBlocking, lo) != hipSuccess ||
+             hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess))
+            return fail(MCPC_EHIP, "second flush stream could not be created");
         for (int h = 0; h < kMaxRingParts; ++h)
             if (hipEventCreateWithFlags(&e->ev_steps[h], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&e->ev_flush[h], hipEventDisableTiming) != hipSuccess)
@@ -978,6 +989,17 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
     const int nlin = e->L + (e->has_head ? 1 : 0);
     ReduceJobs jobs{};
     unsigned max_blocks = 1;
+    // Overlapped flush: the launches alternate between two low-priority streams (kernels of one stream run one after the
+    // other, each leaving the idle CUs half empty while its last workgroups finish); the reduction joins them.
+    hipStream_t const main_stream = stream;
+    const bool two = e->aux3 != nullptr && stream == e->aux;
+    double load[2] = {0.0, 0.0};                            // work queued on each stream so far (output columns x rows)
+    if (two) { HIP_TRY(hipEventRecord(e->ev_fork, main_stream)); HIP_TRY(hipStreamWaitEvent(e->aux3, e->ev_fork, 0)); }
+    auto next_stream = [&](double cost) {                   // greedy: the launch goes to the stream with less work queued
+        const int k = (two && load[1] < load[0]) ? 1 : 0;
+        load[k] += cost;
+        return k ? e->aux3 : main_stream;
+    };
     for (int j = 1; j < nlin; ++j) {
         Lin& ln = e->lin[j];
         const int ne = ln.out_pad, na = ln.in_pad;
@@ -989,6 +1011,7 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
         if ((size_t)h.ksplit * ((size_t)ne * na + ne) > ln.slab_floats)
             return fail(MCPC_ESTATE, "internal: Hebbian slabs of Linear %d (%d splits) exceed their allocation", j, h.ksplit);
         if (h.swapped) {
+            stream = next_stream((double)ne * na);
             // transposed product: the activations take the E slot, the errors the A slot; slab = [split][na][ne]
             HebArgs a{A, E, slab, slab_b, rows, na, ne, h.rps, 1, 1, h.ksplit, 0};
             int rc = 0;
@@ -1001,6 +1024,7 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
             for (int part = 0; part < 2; ++part) {
                 if (h.n_mt[part] == 0) continue;
                 HebArgs a{E, A, slab, slab_b, rows, ne, na, h.rps, h.n_mt[part], h.n_nt, h.ksplit, col};
+                stream = next_stream((double)h.n_mt[part] * h.te[part] * 16 * na);
                 int rc = 0;
                 const int te = h.te[part];
                 if (te == 17 && h.ra == 2) rc = launch_heb<17, 2>(a, stream);
@@ -1013,6 +1037,7 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
                 col += h.n_mt[part] * te * 16;
             }
         } else {
+            stream = next_stream((double)ne * na);
             hipLaunchKernelGGL(mcpc_dw_kernel, dim3((h.wave_tiles + 3) / 4, h.ksplit), dim3(256), 0, stream, E, A, slab, slab_b,
                                rows, ne, na, h.rps);
         }
@@ -1021,6 +1046,8 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
         jobs.job[jobs.n_jobs++] = ReduceJob{slab_b, ln.Gb, ne, h.ksplit, sign, 0, 0};
         max_blocks = std::max(max_blocks, (unsigned)std::min<size_t>(((size_t)ne * na + 255) / 256, 2048));
     }
+    stream = main_stream;
+    if (two) { HIP_TRY(hipEventRecord(e->ev_join, e->aux3)); HIP_TRY(hipStreamWaitEvent(main_stream, e->ev_join, 0)); }
     if (jobs.n_jobs > 0)
         hipLaunchKernelGGL(mcpc_reduce_jobs_kernel, dim3(max_blocks, jobs.n_jobs), dim3(256), 0, stream, jobs);
     HIP_TRY(hipGetLastError());
