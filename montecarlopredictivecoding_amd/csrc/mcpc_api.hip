@@ -72,6 +72,8 @@ struct Knobs {
     int ring_parts = 3;       // parts of the spill ring: one is filled by the step kernel, one is being flushed, one is slack -- with two
                               // halves the step kernel waited at every boundary for a flush that takes as long as its own segment
                               // (96.8 -> 95.2 us per step of the learning call; parts of 64 steps beat 48, 96 and 128)
+    int mix_pmax = 80;        // longest segment of the mixed schedule, in steps of a paired unit (10 / 20 / 40 / 80: 76.4 / 75.4 / 75.2 / 75.0 us
+                              // per step inside the cycles: every segment boundary joins two streams)
     int mix_ratio = 17;       // steps of a split unit per 10 steps of a paired one (the rate ratio of the two workgroup forms)
     int dw_ksplit = 0;        // > 0: K-splits per workgroup tile of the Hebbian GEMM (0: one wave of workgroups over the chip)
     int ws_prio = 1;          // 1: epilogue waves at raised priority, 2: GEMM waves, 0: neither
@@ -97,7 +99,7 @@ int parse_tuning(const char* str, Knobs& k) {
         const int val = eq == std::string::npos ? 1 : atoi(item.c_str() + eq + 1);
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
-            {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
+            {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"mix_pmax", &k.mix_pmax}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
             {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}};
         bool found = false;
         for (auto& t : table)
@@ -1298,7 +1300,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             // steps per segment for the paired units and s(p) = round(1.7 p) for the split ones (the 1 : 1.7 rate ratio of the two
             // workgroup forms: 20 / 34, 10 / 17, 3 / 5) advances every unit by a s + (lc - a) p steps; segments shorter than 3
             // steps do not pay for their launches.
-            for (int p = 20; p >= 3;) {
+            for (int p = std::max(3, std::min(e->knobs.mix_pmax, 300)); p >= 3;) {
                 const int sp = (e->knobs.mix_ratio * p + 5) / 10;
                 const int cyc = e->mix_a * sp + (e->mix_lc - e->mix_a) * p;
                 if (cyc > n) { --p; continue; }

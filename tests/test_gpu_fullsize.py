@@ -152,7 +152,7 @@ def _mixed_plan(batch, T, n_cu=256):
         return 0, 0, []
     lc = npairs // gcd(npairs, ns)
     a = ns * lc // npairs
-    cycles, steps, used, n, p = 0, 0, [], T, 20
+    cycles, steps, used, n, p = 0, 0, [], T, 80
     while p >= 3:
         sp = (17 * p + 5) // 10
         cyc = a * sp + (lc - a) * p
@@ -188,23 +188,23 @@ def test_mixed_schedule_matches_plain_schedule(monkeypatch):
 
 
 def test_mixed_schedule_all_segment_sizes_match_plain_schedule(monkeypatch):
-    """A call runs whole cycles of the mixed schedule, longest segments first: (20, 34) steps per segment (1178 steps per cycle at
-    B = 6000), then the longest that still fits, down to (3, 5) (175 steps), before the plain schedule takes what is left.
-    T = 2073 runs one cycle with (20, 34) steps per segment, one with (15, 26) (892 steps) and 3 plain steps; the shortest form, (3, 5),
+    """A call runs whole cycles of the mixed schedule, longest segments first: up to (80, 136) steps per segment (4712 steps per cycle
+    at B = 6000), then the longest that still fits, down to (3, 5) (175 steps), before the plain schedule takes what is left.
+    T = 6100 runs one cycle with (80, 136) steps per segment, one with (23, 39) (1353 steps) and 35 plain steps; the shortest form, (3, 5),
     is what test_mixed_schedule_with_per_step_tables runs, (6, 10) what test_mixed_schedule_matches_plain_schedule runs: final state and
     every record must be BITWISE those of the plain schedule."""
     W, b, y, xs = _problem()
-    T = 1178 + 892 + 3
-    assert _mixed_plan(B, T) == (2, 1178 + 892, [20, 15])
+    T = 4712 + 1353 + 35
+    assert _mixed_plan(B, T) == (2, 4712 + 1353, [80, 23])
     outs = []
     for no_mix in (False, True):
         if no_mix:
             monkeypatch.setenv("MCPC_TUNING", "no_mix=1")
         eng = _engine(B, W, b, y)
         eng.set_profiling(True)
-        res, out = _run(eng, xs, T, rec_begin=0, rec_stride=89, rec_count=23, rec_x=True)
+        res, out = _run(eng, xs, T, rec_begin=0, rec_stride=277, rec_count=23, rec_x=True)
         ms, n_cycles, n_steps = eng.last_mixed_cycles_ms()
-        assert (n_cycles, n_steps) == ((0, 0) if no_mix else (2, 1178 + 892))
+        assert (n_cycles, n_steps) == ((0, 0) if no_mix else (2, 4712 + 1353))
         outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x]))
         eng.close()
     for a, c in zip(outs[0][1], outs[1][1]):
