@@ -234,7 +234,7 @@ def main():
                            "HIP events around every launch of the plain schedule during the timed "
                            + ("learning calls (Hebbian stretches; the Hebbian GEMMs of the previous segment run beside it)" if primary_learning else "inference calls"),
                            q["n_workgroups"])
-        mixed_line = kernel_line("mcpc::mcpc_steps_ws2_kernel<2, true> + <1, true> (mixed 32-/16-chain schedule, two concurrent launches per segment)",
+        mixed_line = kernel_line("mcpc::mcpc_steps_ws2_mixed_kernel (mixed schedule: 32-chain and 16-chain workgroups in one launch per segment)",
                                  mixed_i if mixed_i is not None else mixed_l, flops_inf,
                                  "HIP events around whole cycles of the mixed schedule during the timed "
                                  + ("inference-only calls" if mixed_i is not None else "learning calls (mixing steps)"),

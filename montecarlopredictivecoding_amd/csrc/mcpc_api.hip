@@ -147,6 +147,7 @@ struct mcpc_engine {
     int slots = 0, half_slots = 0;
     hipStream_t aux = nullptr;
     hipEvent_t ev_steps[kMaxRingParts] = {}, ev_flush[kMaxRingParts] = {};
+    hipStream_t spacer = nullptr;   // never used: see ensure_spill
     hipStream_t aux3 = nullptr;     // second low-priority stream of the overlapped flush: the GEMMs of a flush alternate between the two,
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // so that the tail of one launch is filled by the next (same-stream kernels serialise)
     bool flush_pending[kMaxRingParts] = {};
@@ -179,8 +180,6 @@ struct mcpc_engine {
     int mix_ns = 0, mix_np = 0, mix_lc = 0, mix_a = 0;    // pairs split / paired per segment, segments per cycle, splits per pair per cycle
     int* mix_tab = nullptr;          // device: per segment [np pair ids][np rel][2 ns tile ids][2 ns rel]
     struct Alt { int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_ws_sync = 0, lds_bytes = 0, n_phases = 0; KPhase* phases = nullptr; } alt16;
-    hipStream_t aux2 = nullptr;
-    hipEvent_t ev_mix[2] = {nullptr, nullptr};
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events, events_mix;   // plain-schedule launches / whole mixed cycles
@@ -237,10 +236,9 @@ int free_all(mcpc_engine* e) {
     for (int h = 0; h < kMaxRingParts; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
     if (e->aux) { (void)hipStreamDestroy(e->aux); e->aux = nullptr; }
     if (e->aux3) { (void)hipStreamDestroy(e->aux3); e->aux3 = nullptr; }
+    if (e->spacer) { (void)hipStreamDestroy(e->spacer); e->spacer = nullptr; }
     if (e->ev_fork) { (void)hipEventDestroy(e->ev_fork); e->ev_fork = nullptr; }
     if (e->ev_join) { (void)hipEventDestroy(e->ev_join); e->ev_join = nullptr; }
-    if (e->aux2) { (void)hipStreamDestroy(e->aux2); e->aux2 = nullptr; }
-    for (int h = 0; h < 2; ++h) if (e->ev_mix[h]) { (void)hipEventDestroy(e->ev_mix[h]); e->ev_mix[h] = nullptr; }
     F(e->mix_tab); F(e->alt16.phases);
     for (void* q : e->retired) (void)hipFree(q);
     e->retired.clear();
@@ -533,13 +531,19 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
     // to wait for another workgroup of its XCD to finish, which doubles that segment
     const int slack = e->knobs.mix_slack;
     int ns = std::min(n_cu - slack - npairs, npairs);           // npairs + ns workgroups (np pairs + 2 ns singles) <= CUs
-    // ... and <= the CUs of every XCD: the workgroups of a launch go round-robin over the 8 XCDs starting at XCD 0, so XCD 0
-    // receives ceil(np / 8) of the pairs AND ceil(2 ns / 8) of the singles.  One workgroup too many on an XCD waits for a
-    // whole segment and doubles it (measured at 7500 chains: 214 + 42 workgroups, 27 + 6 on XCD 0: 173 us per step instead
-    // of 88; 6000 chains happen to give 15 + 17 on every XCD).
-    constexpr int kXcd = 8;
-    if (n_cu % kXcd == 0)
-        while (ns >= 1 && (npairs - ns + kXcd - 1) / kXcd + (2 * ns + kXcd - 1) / kXcd > n_cu / kXcd) --ns;
+    // The rotation repeats after npairs / gcd(npairs, ns) segments.  When that is long (> 64 segments), a few splits fewer are a
+    // good price for a cycle that fits into shorter stretches (7500 chains: 21 of 235 pairs rotate in 235 segments, 20 in 47).
+    {
+        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+        int best = ns;
+        if (npairs / gcd(npairs, ns) > 64)
+            for (int c = ns - 1; c >= 1 && c >= ns - ns / 8; --c)
+                if (gcd(npairs, c) > gcd(npairs, best)) best = c;
+        ns = best;
+    }
+    // (One launch per segment: its workgroups go round-robin over the 8 XCDs as one sequence, at most one per CU.  With the
+    // two halves as two launches each started at XCD 0 and an XCD could receive one workgroup more than it has CUs -- 7500
+    // chains: 27 + 6 on XCD 0 -- which then waited for a whole segment.)
     // A split pair advances 34 steps where a paired one advances 20: the schedule does 1 + 0.7 ns / npairs times the plain
     // schedule's work per unit of time, minus what its short launches cost.  Below 4 % expected it does not pay (8000 chains:
     // 4 of 250 pairs split, +1.1 % expected, -5 % measured).
@@ -565,8 +569,7 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
     e->n_phases = keep.n_phases; e->phases = keep.phases;
     e->ws2_chunk = k_chunk; e->ws2_ring = k_ring;
     if (rc) { g_err.clear(); return 0; }                     // no 16-chain plan: plain schedule only
-    if (hipFuncSetAttribute((const void*)mcpc_steps_ws2_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)mcpc_steps_ws2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, a.lds_bytes) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)mcpc_steps_ws2_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(e->lds_bytes, a.lds_bytes)) != hipSuccess)
         return fail(MCPC_EHIP, "hipFuncSetAttribute failed for the mixed schedule");
     // rotation tables
     int g = npairs, h = ns;
@@ -590,27 +593,7 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
     if ((rc = dmalloc(e->mix_tab, tab.size()))) return rc;
     if (hipMemcpy(e->mix_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
         return fail(MCPC_EHIP, "hipMemcpy of the mixed-schedule tables failed");
-    // The split half of a segment runs on a stream of its own, which must map to a hardware queue of its own: the HIP runtime
-    // spreads normal-priority streams over GPU_MAX_HW_QUEUES = 4 queues, and in a process that also holds an RCCL communicator
-    // (torch.distributed: its streams take queues too) this stream came to share the caller's queue -- the two launches of
-    // every segment ran one after the other, 145 us per step instead of 76.  High-priority streams have their own queues.
-    {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // hi = most urgent (numerically lowest)
-        if (hipStreamCreateWithPriority(&e->aux2, hipStreamNonBlocking, hi) != hipSuccess) return fail(MCPC_EHIP, "hipStreamCreateWithPriority failed");
-    }
-    for (int i = 0; i < 2; ++i)
-        if (hipEventCreateWithFlags(&e->ev_mix[i], hipEventDisableTiming) != hipSuccess) return fail(MCPC_EHIP, "hipEventCreate failed");
     e->mix_ns = ns; e->mix_np = np; e->mix_lc = lc; e->mix_a = cnt_a[0];
-    // first use of a stream maps a hardware queue and sizes its scratch: pay for that here, not inside a timed call
-    // (an empty network: no layers, no steps -- the kernel reads its first table entry, requests nothing and exits)
-    {
-        KParams P0{};
-        P0.phases = a.phases; P0.n_phases = a.n_phases; P0.mu1 = e->mu1; P0.err = e->err;
-        P0.wg_list = e->mix_tab; P0.wg_rel = e->mix_tab; P0.lds_ws_sync = a.lds_ws_sync; P0.lds_red = a.lds_red;
-        hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1, true>), dim3(1), dim3(kWs2Threads), a.lds_bytes, e->aux2, P0);
-        if (hipStreamSynchronize(e->aux2) != hipSuccess) return fail(MCPC_EHIP, "warm-up launch of the mixed schedule failed");
-    }
     e->mix = true;
     return 0;
 }
@@ -951,6 +934,12 @@ int ensure_spill(mcpc_engine* e) {
     if (e->half_slots < e->slots && !e->aux) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least urgent
+        // Streams become hardware queues in the order they are created, and the queues are dealt out over the pipes of the
+        // command processor: which pipe the two flush queues share with whom is worth 0.5 % of the learning call (94.3
+        // against 94.7 us per step) and can be neither asked nor requested.  One stream created in front of them -- never
+        // used -- puts them where they measured best in a process whose only other compute queue is the caller's (any one
+        // extra stream, of any priority, did; two did worse by 2 %: 96.6).
+        if (!e->spacer) (void)hipStreamCreateWithFlags(&e->spacer, hipStreamNonBlocking);
         if (hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, lo) != hipSuccess) return fail(MCPC_EHIP, "hipStreamCreateWithPriority failed");
         if (e->knobs.flush_streams >= 2 &&
             (hipStreamCreateWithPriority(&e->aux3, hipStreamNonBlocking, lo) != hipSuccess ||
@@ -1252,7 +1241,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         return 0;
     };
     // one cycle of the mixed schedule: mix_lc segments, in each of them the paired units do `mp` steps as 32-chain workgroups
-    // on `stream` while the split ones do `ms` steps as 16-chain workgroups on `aux2`; afterwards every unit is at t0 + cyc
+    // while the split ones do `ms` steps as 16-chain workgroups -- one launch per segment; afterwards every unit is at t0 + cyc
     auto run_mixed_cycle = [&](int t0, int mp, int ms) -> int {
         KParams P2 = P, P1 = P;
         for (int l = 0; l < e->L; ++l) { P1.layer[l].lds_a = e->alt16.lds_a[l]; P1.layer[l].lds_e = e->alt16.lds_e[l]; }
@@ -1271,15 +1260,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             const int* row = e->mix_tab + (size_t)seg * (2 * np + 4 * ns);
             P2.wg_list = row; P2.wg_rel = row + np;
             P1.wg_list = row + 2 * np; P1.wg_rel = row + 2 * np + 2 * ns;
-            HIP_TRY(hipEventRecord(e->ev_mix[0], stream));
-            HIP_TRY(hipStreamWaitEvent(e->aux2, e->ev_mix[0], 0));
-            hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1, true>), dim3(2 * ns), dim3(kWs2Threads), e->alt16.lds_bytes, e->aux2, P1);
-            HIP_TRY(hipEventRecord(e->ev_mix[1], e->aux2));
-            // (no timing events here: an event record between the two launches costs the segment its concurrency -- 110 instead
-            // of 79 us per step; mcpc_last_step_kernel_ms therefore covers the launches of the plain schedule only)
-            if (np > 0)        // (a shard with no more pairs than spare CUs runs entirely split)
-                hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2, true>), dim3(np), dim3(kWs2Threads), e->lds_bytes, stream, P2);
-            HIP_TRY(hipStreamWaitEvent(stream, e->ev_mix[1], 0));
+            // (no timing events inside a cycle: mcpc_last_step_kernel_ms covers the launches of the plain schedule only)
+            hipLaunchKernelGGL(mcpc_steps_ws2_mixed_kernel, dim3(np + 2 * ns), dim3(kWs2Threads), std::max(e->lds_bytes, e->alt16.lds_bytes), stream, P2, P1, np);
         }
         HIP_TRY(hipGetLastError());
         return 0;
@@ -1537,7 +1519,7 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
 
 const char* mcpc_step_kernel_name(const mcpc_engine* e) {
     if (!e) return "";
-    if (e->ws == 2 && e->mix) return "mcpc::mcpc_steps_ws2_kernel<2, false> (Hebbian stretches) / <2, true> + <1, true> (mixed schedule of inference stretches)";
+    if (e->ws == 2 && e->mix) return "mcpc::mcpc_steps_ws2_kernel<2, false> (Hebbian stretches) / mcpc_steps_ws2_mixed_kernel (mixed schedule of inference stretches)";
     if (e->ws == 2) return e->ct == 16 ? "mcpc::mcpc_steps_ws2_kernel<1, false>" : "mcpc::mcpc_steps_ws2_kernel<2, false>";
     if (e->ct == 16) return "mcpc::mcpc_steps_kernel<1, 4>";
     return e->nw == 8 ? "mcpc::mcpc_steps_kernel<2, 8>" : "mcpc::mcpc_steps_kernel<2, 4>";

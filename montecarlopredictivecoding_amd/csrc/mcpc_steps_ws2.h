@@ -208,318 +208,45 @@ __device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPha
 }
 
 // MIX: the launch is one half of a mixed schedule -- workgroups take their unit and their step offset from lists
+// (The body is a textual include, shared with mcpc_steps_ws2_mixed_kernel below: wrapped into a device function and inlined, the
+// SAME code compiled about 1 % slower -- other spills, P's fields re-read.)
 template <int CTT, bool MIX = false>
 __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps_ws2_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NW = kWs2Pairs, NTW = ws2_nt<CTT>();
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_g = wave8 < kWs2Pairs;                   // waves 0..NW-1 and NW..2NW-1 both spread evenly over the 4 SIMDs
-    const int k = wave8 & (kWs2Pairs - 1);                 // pair id
-    const int c = lane & 15, q = lane >> 4;
-    const int unit = MIX ? P.wg_list[blockIdx.x] : (int)blockIdx.x;             // pair of chain tiles (CTT = 2) or single tile
-    const int chain0 = unit * (16 * CTT);
-    // first step of this unit in this launch (mixed schedule: units advance at different rates, so each carries the number
-    // of segments it has spent split / paired since the cycle began)
-    const int t_first = MIX ? P.t0 + (P.wg_rel[blockIdx.x] & 0xffff) * P.mix_ms + (P.wg_rel[blockIdx.x] >> 16) * P.mix_mp : P.t0;
-    const int L = P.L;
-    const int n_ent = P.n_phases;
-    Ws2Sync* sync = reinterpret_cast<Ws2Sync*>(lds + P.lds_ws_sync);
-    int dead = 0;                                          // set once a bounded wait of this wave ran out
-    if (tid < 2 * kWs2Pairs) reinterpret_cast<int*>(sync)[tid] = 0;
-    // f(x_l) of the state the launch starts from; afterwards the x updates keep FX_l current
-    for (int l = 0; l < L; ++l) {
-        const KLayer& Ly = P.layer[l];
-        if (Ly.act == MCPC_ACT_RELU) ws2_fill_fx<MCPC_ACT_RELU>(Ly, lds, chain0, tid, 16 * CTT);
-        else if (Ly.act == MCPC_ACT_TANH) ws2_fill_fx<MCPC_ACT_TANH>(Ly, lds, chain0, tid, 16 * CTT);
-        else ws2_fill_fx<MCPC_ACT_IDENTITY>(Ly, lds, chain0, tid, 16 * CTT);
-    }
-    __syncthreads();                                       // the only barrier
+#define WS2_BLOCK blockIdx.x
+#define WS2_NBLOCKS gridDim.x
+#include "mcpc_steps_ws2_body.inc"
+#undef WS2_BLOCK
+#undef WS2_NBLOCKS
+}
 
-    if (is_g) {
-        // =========================== G: fragments + MFMAs ==============================================
-        if (P.ws_prio == 2) __builtin_amdgcn_s_setprio(2);
-        // Loop-carried: the descriptor of the upcoming entry and the first two k-blocks of its fragments.  The GEMM
-        // moves pre0/pre1 into its own register sets first thing, so the ONE prefetch site below refills the same
-        // variables -- with separate "next" copies hipcc put `s_waitcnt vmcnt(0)` + 16 v_mov at the loop latch, i.e.
-        // every entry waited out the L2 round trip of the prefetch it had just issued.
-        KPhase ph_next = load_phase(P.phases, 0);
-        int nt_next, aoff[NTW];
-        f32x4 pre0[NTW], pre1[NTW];
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) { pre0[i] = splat(0.f); pre1[i] = splat(0.f); aoff[i] = 0; }
-        ws2_prefetch(ph_next, k, lane, P.mu1, nt_next, aoff, pre0, pre1);
-        STAMP_DECL
-#ifdef MCPC_STAMPS
-        const unsigned long long clk_m0 = mcpc_stamp(), clk_r0 = wall_clock64();
-#endif
-        for (int s = 0; s < P.n_steps; ++s) {
-            const int base = s * n_ent;
-            f32x4 accb[NTW][CTT];                       // back-projection of the read-out error: 16 tiles over the pairs
-#pragma unroll
-            for (int i = 0; i < NTW; ++i)
-#pragma unroll
-                for (int ct = 0; ct < CTT; ++ct) accb[i][ct] = splat(0.f);
-#pragma unroll 1
-            for (int p = 0; p < n_ent; ++p) {
-                const KPhase ph = ph_next;
-                const int nt = nt_next;
-                const bool has_next = (p + 1 < n_ent) || (s + 1 < P.n_steps);
-                if (has_next) ph_next = load_phase(P.phases, p + 1 < n_ent ? p + 1 : 0);
-                const bool handoff = (ph.flags & PHF_WS2_HANDOFF) != 0;             // accb goes to the partner
-                const bool is_headb = ph.type == PH_HEADB;
-                const bool works = (ph.flags & PHF_WS_GEMM) || handoff;
-                const bool stores = works && !is_headb;
-                f32x4 acc[NTW][CTT];
-#pragma unroll
-                for (int i = 0; i < NTW; ++i)
-#pragma unroll
-                    for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = splat(0.f);
-                STAMP(0);
-#ifdef MCPC_STAMPS_ENTRY
-                const unsigned long long ge0 = mcpc_stamp();
-                unsigned long long gwait = 0;
-#endif
-                if (works) {
-                    if (ph.dep_e >= 0) ws2_wait_all(sync->prog_e, ws2_need(base, n_ent, p, ph.dep_e), P.err, dead);
-#ifdef MCPC_STAMPS_ENTRY
-                    gwait = mcpc_stamp() - ge0;
-#endif
-                    STAMP(1);
-                    if (is_headb) {
-                        if (nt > 0 MCPC_EXP_GEMM_GATE) gemm_tiles<NTW, CTT, NW>(accb, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
-                        STAMP(2);
-                    } else {
-                        if (handoff) {
-#pragma unroll
-                            for (int i = 0; i < NTW; ++i)
-#pragma unroll
-                                for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = accb[i][ct];     // one entry covers all of accb
-                        }
-                        if (nt > 0 && ph.nkb > 0 MCPC_EXP_GEMM_GATE)
-                            gemm_tiles<NTW, CTT, NW>(acc, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
-                        STAMP(3);
-                    }
-                }
-                // the one prefetch site: fragments of the next entry travel while this block is handed over
-                ws2_prefetch(ph_next, k, lane, P.mu1, nt_next, aoff, pre0, pre1);   // (past the last entry: the old descriptor again)
-                STAMP(4);
-                if (stores) {
-                    // write-after-read: the rows this block goes to may still be read by GEMMs (dep_g) or epilogues (dep_se)
-                    // of entries that share them -- waited for here, behind the GEMM, not in front of it
-#ifdef MCPC_STAMPS_ENTRY
-                    const unsigned long long gw0 = mcpc_stamp();
-#endif
-                    if (ph.dep_g >= 0) ws2_wait_all(sync->prog_g, ws2_need(base, n_ent, p, ph.dep_g), P.err, dead);
-                    if (ph.dep_se >= 0) ws2_wait_all(sync->prog_e, ws2_need(base, n_ent, p, ph.dep_se), P.err, dead);
-#ifdef MCPC_STAMPS_ENTRY
-                    gwait += mcpc_stamp() - gw0;
-#endif
-                    // the block goes where its consumer reads it; E_k finishes it in place
-                    const int kk = (k + ph.rot) & (NW - 1);
-                    int ntw = (ph.ntiles - kk + NW - 1) / NW;
-                    ntw = ntw < 0 ? 0 : (ntw > NTW ? NTW : ntw);
-                    float* const out = lds + ph.out_lds;
-                    const int col0 = (ph.type == PH_HEADF) ? 0 : 16 * ph.tile0;
-#pragma unroll
-                    for (int i = 0; i < NTW; ++i) {
-                        if (i >= ntw) continue;
-                        const int col = col0 + 16 * (kk + NW * i) + 4 * q;
-#pragma unroll
-                        for (int ct = 0; ct < CTT; ++ct) st4(out + (16 * ct + c) * ph.out_ld + col, acc[i][ct]);
-                    }
-                }
-                if (lane == 0) ws_publish(&sync->prog_g[k], base + p + 1);
-                STAMP(5);
-#ifdef MCPC_STAMPS_ENTRY
-                if (MCPC_STAMPS_ENTRY == 1) STAMP_ENTRY_ADD(p, gwait);
-                else if (MCPC_STAMPS_ENTRY == 2) STAMP_ENTRY_ADD(p, mcpc_stamp() - ge0);
-#endif
-            }
-        }
-#if defined(MCPC_STAMPS) && !defined(MCPC_STAMPS_ENTRY)
-        st_sum[6] = mcpc_stamp() - clk_m0;          // whole launch in s_memtime ticks ...
-        st_sum[7] = wall_clock64() - clk_r0;        // ... and in 100 MHz wall-clock ticks: their ratio is the shader clock
-#endif
-#ifdef MCPC_STAMPS
-        if (lane == 0 && P.dbg != nullptr)      // (null in the warm-up launch of setup_mixed_schedule)
-            for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * (2 * kWs2Pairs) + wave8) * 16 + i] = st_sum[i];
-#endif
-        return;
+// One segment of the mixed schedule as ONE launch: workgroups [0, np) are 32-chain workgroups running P2 (their units and step
+// offsets from P2.wg_list / wg_rel), the others 16-chain workgroups running P1.  (Two launches on two streams were concurrent only
+// while the streams had hardware queues of their own: the HIP runtime lets streams share queues -- GPU_MAX_HW_QUEUES = 4 per
+// priority class -- and in a process that also held RCCL communicators the two halves of every segment ran one after the
+// other.  One launch needs no second stream, no cross-stream events, and its workgroups go round-robin over the XCDs as ONE
+// sequence, so that no XCD receives more workgroups than it has CUs as long as the launch has at most one per CU.)
+__global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps_ws2_mixed_kernel(const KParams P2, const KParams P1, const int np) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x < np) {
+        constexpr int CTT = 2;
+        constexpr bool MIX = true;
+        const KParams& P = P2;
+#define WS2_BLOCK blockIdx.x
+#define WS2_NBLOCKS np
+#include "mcpc_steps_ws2_body.inc"
+#undef WS2_BLOCK
+#undef WS2_NBLOCKS
+    } else {
+        constexpr int CTT = 1;
+        constexpr bool MIX = true;
+        const KParams& P = P1;
+#define WS2_BLOCK (blockIdx.x - np)
+#define WS2_NBLOCKS (gridDim.x - np)
+#include "mcpc_steps_ws2_body.inc"
+#undef WS2_BLOCK
+#undef WS2_NBLOCKS
     }
-
-    // =============================== E: epilogues ===========================================================
-    if (P.ws_prio == 1) __builtin_amdgcn_s_setprio(2);
-    const int upd_mode = (P.update_x && P.xopt == MCPC_XOPT_SGD)
-                             ? (P.noise_mode == MCPC_NOISE_PHILOX ? 2 : (P.noise_mode == MCPC_NOISE_NONE ? 1 : 0)) : 0;
-    // lean epilogues (mcpc_ws2_lean.h): fused SGD update (or Adam without noise: the MAP warm-up), every chain of the
-    // workgroup inside the batch, 32-bit offsets fit
-    const bool lean_adam = P.update_x && P.xopt == MCPC_XOPT_ADAM && P.noise_mode == MCPC_NOISE_NONE;
-    const bool lean = (upd_mode != 0 || lean_adam) && chain0 + 16 * CTT <= P.B && P.lean_ok;
-    LeanLane<CTT> LL;
-    LL.c = c; LL.q = q;
-#pragma unroll
-    for (int ct = 0; ct < CTT; ++ct) { LL.chain[ct] = (uint32_t)(chain0 + 16 * ct + c); LL.lrow[ct] = (uint32_t)(16 * ct + c); }
-    // 0/1 targets are read bit-packed (a wave-uniform flag the library set when the target was bound)
-    const bool ybin = lean && P.has_head && *P.head.y_binary != 0;
-    // sum_t e_1 of this launch in registers (lean path, top layer of at most one tile per wave, rot == 0 for FWD entries)
-    const bool e0_in_regs = lean && P.layer[0].ntiles <= NW;
-    bool e0_dirty = false;
-    f32x4 e0acc[CTT];
-#pragma unroll
-    for (int ct = 0; ct < CTT; ++ct) e0acc[ct] = splat(0.f);
-    STAMP_DECL
-    for (int s = 0; s < P.n_steps; ++s) {
-        const int t = t_first + s;
-        const int s_tab = MIX ? t - P.t0 : s;          // index into per-step tables (Adam coefficients, external noise): they start at P.t0
-        const int base = s * n_ent;
-        const bool do_energy = (P.energy_mode == MCPC_ENERGY_ALL) || (P.energy_mode == MCPC_ENERGY_LAST && t == P.T - 1);
-        const int slot = (t >= P.acc_begin && t < P.acc_end) ? (t - P.spill_t0) : -1;
-        int rec_idx = -1;
-        if (P.rec_count > 0 && t >= P.rec_begin) {
-            const int kk = (t - P.rec_begin) / P.rec_stride;
-            if (kk < P.rec_count && P.rec_begin + kk * P.rec_stride == t) rec_idx = kk;
-        }
-        // energies of this step: lane c of every E wave carries the wave's partial sum of column c (layers 0..5, loss) in a
-        // register; the LDS scratch is written once per step, at the ENERGY entry (an LDS read-modify-write behind every
-        // epilogue cost the E waves seven LDS round trips per step)
-        float* red = lds + P.lds_red + (s & 1) * (kMaxLatent + 1) * kMaxWaves;
-        float en_acc = 0.f;
-#pragma unroll 1
-        for (int p = 0; p < n_ent; ++p) {
-            const KPhase ph = load_phase(P.phases, p);
-#ifdef MCPC_STAMPS_ENTRY
-            const unsigned long long ee0 = mcpc_stamp();
-            unsigned long long ewait = 0;
-#endif
-            if (ph.type == PH_ENERGY) {
-                if (do_energy && lane <= kMaxLatent) red[lane * kMaxWaves + k] = en_acc;
-                if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
-                if (do_energy && k == 0) {
-                    // every E wave has written its partial sums of this step
-                    ws2_wait_all(sync->prog_e + 0, base + p + 1, P.err, dead);
-                    if (lane <= kMaxLatent) {
-                        double v = 0.0;
-                        const bool used = (lane < L) || (lane == kMaxLatent && P.has_head);
-                        if (used) {
-#pragma unroll
-                            for (int w = 0; w < kWs2Pairs; ++w) v += (double)red[lane * kMaxWaves + w];
-                        }
-                        const int erow = (P.energy_mode == MCPC_ENERGY_ALL) ? t : 0;
-                        // a row has one slot per 16-chain tile: a 32-chain workgroup writes the slot of its first tile and
-                        // clears the other (a 16-chain workgroup may have written it for the same step of an earlier call)
-                        double* const ep = P.epart + (MIX ? (size_t)erow * P.epart_slots + (size_t)unit * CTT
-                                                          : (size_t)erow * (CTT * gridDim.x) + (size_t)blockIdx.x * CTT) * (kMaxLatent + 1) + lane;
-                        ep[0] = v;
-                        if (CTT == 2) ep[kMaxLatent + 1] = 0.0;
-                    }
-                }
-                continue;
-            }
-            if (!(ph.flags & PHF_WS_EPI)) {
-                if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
-                continue;
-            }
-            const int kk = (k + ph.rot) & (NW - 1);
-            int nt = (ph.ntiles - kk + NW - 1) / NW;
-            nt = nt < 0 ? 0 : (nt > NTW ? NTW : nt);
-#ifndef MCPC_EXP_NOLEAN
-            if (lean) {
-                const int act = P.layer[ph.layer].act;
-                const int* const pg = &sync->prog_g[k];
-                const int need = base + p + 1;
-#ifdef MCPC_EXP_NOEPI
-                if (P.n_steps < 0)
-#endif
-                if (ph.type == PH_FWD) {
-                    float esum;
-                    if (ph.layer == 0 && slot >= 0) e0_dirty = true;
-                    if (act == MCPC_ACT_RELU) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_RELU>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead, e0acc, e0_in_regs);
-                    else if (act == MCPC_ACT_TANH) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_TANH>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead, e0acc, e0_in_regs);
-                    else esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_IDENTITY>(P, ph, lds, nt, kk, LL, slot, rec_idx, pg, need, P.err, dead, e0acc, e0_in_regs);
-                    if (do_energy) { esum = wave_sum(esum); if (lane == ph.layer) en_acc += esum; }
-                } else if (ph.type == PH_HEADF) {
-                    float lsum = lean_headf<CTT, NW, NTW>(P, ph, lds, nt, kk, LL, slot, rec_idx, do_energy, pg, need, P.err, dead, ybin);
-                    if (do_energy) { lsum = wave_sum(lsum); if (lane == kMaxLatent) en_acc += lsum; }
-                } else if (ph.type == PH_BWD) {
-                    if (lean_adam) {
-                        if (act == MCPC_ACT_RELU) lean_bwd<CTT, NW, NTW, MCPC_ACT_RELU, false, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead, s_tab);
-                        else if (act == MCPC_ACT_TANH) lean_bwd<CTT, NW, NTW, MCPC_ACT_TANH, false, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead, s_tab);
-                        else lean_bwd<CTT, NW, NTW, MCPC_ACT_IDENTITY, false, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead, s_tab);
-                    } else if (upd_mode == 2) {
-                        if (act == MCPC_ACT_RELU) lean_bwd<CTT, NW, NTW, MCPC_ACT_RELU, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
-                        else if (act == MCPC_ACT_TANH) lean_bwd<CTT, NW, NTW, MCPC_ACT_TANH, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
-                        else lean_bwd<CTT, NW, NTW, MCPC_ACT_IDENTITY, true>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
-                    } else {
-                        if (act == MCPC_ACT_RELU) lean_bwd<CTT, NW, NTW, MCPC_ACT_RELU, false>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
-                        else if (act == MCPC_ACT_TANH) lean_bwd<CTT, NW, NTW, MCPC_ACT_TANH, false>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
-                        else lean_bwd<CTT, NW, NTW, MCPC_ACT_IDENTITY, false>(P, ph, lds, nt, kk, LL, t, pg, need, P.err, dead);
-                    }
-                }
-                if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
-                continue;
-            }
-#endif
-            f32x4 acc[NTW][CTT], pa[NTW][CTT], pb[NTW][CTT];
-#pragma unroll
-            for (int i = 0; i < NTW; ++i)
-#pragma unroll
-                for (int ct = 0; ct < CTT; ++ct) { acc[i][ct] = splat(0.f); pa[i][ct] = splat(0.f); pb[i][ct] = splat(0.f); }
-            const KLayer& Ly = P.layer[ph.layer];
-            STAMP(8);
-            // operands of the epilogue travel while the partner still computes
-            issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, kk, lane, chain0, pa, pb);
-            STAMP(9);
-            const bool from_g = ((ph.flags & PHF_WS_GEMM) && ph.nkb > 0) || (ph.flags & PHF_WS2_HANDOFF);
-            if (from_g) {
-#ifdef MCPC_STAMPS_ENTRY
-                const unsigned long long ew0 = mcpc_stamp();
-#endif
-                ws_wait_one(&sync->prog_g[k], base + p + 1, P.err, dead);
-#ifdef MCPC_STAMPS_ENTRY
-                ewait = mcpc_stamp() - ew0;
-#endif
-                STAMP(10);
-                const float* const src = lds + ph.out_lds;
-                const int col0 = (ph.type == PH_HEADF) ? 0 : 16 * ph.tile0;
-#pragma unroll
-                for (int i = 0; i < NTW; ++i) {
-                    const int col = col0 + 16 * (kk + NW * (i < nt ? i : 0)) + 4 * q;     // unused slots re-read slot 0
-#pragma unroll
-                    for (int ct = 0; ct < CTT; ++ct) acc[i][ct] = ld4(src + (16 * ct + c) * ph.out_ld + col);
-                }
-            }
-#ifdef MCPC_EXP_NOEPI   // timing experiment only (wrong results): E waves skip the epilogue arithmetic and stores
-            if (P.n_steps < 0)
-#endif
-            if (ph.type == PH_FWD) {
-                float esum;
-                if (Ly.act == MCPC_ACT_RELU) esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_RELU, false>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx);
-                else if (Ly.act == MCPC_ACT_TANH) esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_TANH, false>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx);
-                else esum = fwd_epilogue<CTT, NW, NTW, MCPC_ACT_IDENTITY, false>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx);
-                if (do_energy) { esum = wave_sum(esum); if (lane == ph.layer) en_acc += esum; }
-            } else if (ph.type == PH_HEADF) {
-                float lsum = ws2_headf_epilogue<CTT, NW, NTW>(P, ph, lds, nt, kk, lane, chain0, acc, pa, pb, slot, rec_idx, do_energy);
-                if (do_energy) { lsum = wave_sum(lsum); if (lane == kMaxLatent) en_acc += lsum; }
-            } else if (ph.type == PH_BWD) {
-                if (Ly.act == MCPC_ACT_RELU) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_RELU, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s_tab, t, upd_mode, lds);
-                else if (Ly.act == MCPC_ACT_TANH) bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_TANH, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s_tab, t, upd_mode, lds);
-                else bwd_epilogue_mode<CTT, NW, NTW, MCPC_ACT_IDENTITY, true>(P, ph, nt, kk, lane, chain0, acc, pa, pb, s_tab, t, upd_mode, lds);
-            }
-            if (lane == 0) ws_publish(&sync->prog_e[k], base + p + 1);
-            if (ph.type == PH_FWD) STAMP(11); else if (ph.type == PH_HEADF) STAMP(12); else STAMP(13);
-#ifdef MCPC_STAMPS_ENTRY
-            if (MCPC_STAMPS_ENTRY == 3) STAMP_ENTRY_ADD(p, ewait);
-            else if (MCPC_STAMPS_ENTRY == 4) STAMP_ENTRY_ADD(p, mcpc_stamp() - ee0);
-#endif
-        }
-    }
-    if (e0_in_regs && e0_dirty) lean_flush_e0<CTT>(P, k, LL, e0acc);      // (FWD entries have rot == 0: this wave's tile is k)
-#ifdef MCPC_STAMPS
-    if (lane == 0 && P.dbg != nullptr)
-        for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * 8 + wave8) * 16 + i] = st_sum[i];
-#endif
 }
 
 }  // namespace mcpc

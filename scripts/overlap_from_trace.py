@@ -45,6 +45,8 @@ def main(path):
         key = None
         if "mcpc_steps_ws2_kernel<2, false>" in n:
             key = "K1 plain <2,false>"
+        elif "mcpc_steps_ws2_mixed_kernel" in n:
+            key = "K1 mixed schedule (one launch per segment)"
         elif "mcpc_steps_ws2_kernel<2, true>" in n:
             key = "K1 mixed, paired half <2,true>"
         elif "mcpc_steps_ws2_kernel<1, true>" in n:

@@ -123,3 +123,37 @@ def test_bench_multi_rank_code_path_with_one_rank():
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["config"]["T"] == 400 and out["config"]["finite"]
     assert out["value"] > 1000 and out["config"]["inference_only"]["steps_per_s"] > out["value"]
     assert out["roofline"]["bound"] == "mfma" and 0.2 < out["roofline"]["frac"] < 1.0
+
+
+def test_mixed_schedule_keeps_its_own_hardware_queue_beside_an_rccl_group():
+    """Regression guard for what the one-rank rehearsal found: with an RCCL communicator in the process the HIP runtime mapped the
+    mixed schedule's second stream onto the caller's hardware queue and the two launches of every segment ran one after the other
+    (145 us per step instead of 76; the plain schedule takes 93).  Its stream is high-priority now (queues of its own): inside the
+    cycles a step must stay well below the plain schedule's time."""
+    from bench import make_problem
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        t = torch.ones(4, device=DEV)
+        dist.all_reduce(t)                                    # the communicator (and its streams) exist from here on
+        torch.cuda.synchronize()
+        W, b, y, xs = make_problem(6000, 30, torch.device(DEV))
+        eng = Engine([30, 256, 256], [L.ACT_RELU] * 3, 30, 784, 6000, device=DEV)
+        eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
+        per_step = []
+        for _ in range(2):
+            eng.load_state(xs)
+            eng.set_profiling(True)
+            eng.run(1200, loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=1, step_base=0, energy_mode=L.ENERGY_LAST)
+            eng.sync_check()
+            ms, n_cycles, n_steps = eng.last_mixed_cycles_ms()
+            eng.set_profiling(False)
+            assert n_cycles >= 1 and n_steps >= 1000
+            per_step.append(ms / n_steps * 1e3)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+    assert min(per_step) < 86.0, per_step                     # 75-77 us when the halves overlap, 145 when they serialise

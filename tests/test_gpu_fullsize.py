@@ -146,8 +146,12 @@ def _mixed_plan(batch, T, n_cu=256):
     from math import gcd
     npairs = (batch + 31) // 32
     ns = min(n_cu - npairs, npairs)
-    while ns >= 1 and (npairs - ns + 7) // 8 + (2 * ns + 7) // 8 > n_cu // 8:
-        ns -= 1
+    best = ns
+    if npairs // gcd(npairs, ns) > 64:
+        for c in range(ns - 1, max(0, ns - ns // 8 - 1), -1):
+            if c >= 1 and gcd(npairs, c) > gcd(npairs, best):
+                best = c
+    ns = best
     if ns < 1 or 0.7 * ns < 0.04 * npairs:
         return 0, 0, []
     lc = npairs // gcd(npairs, ns)
@@ -217,11 +221,10 @@ def test_mixed_schedule_all_segment_sizes_match_plain_schedule(monkeypatch):
 
 @pytest.mark.parametrize("batch,T", [(7500, 700), (5000, 700), (4200, 420), (8000, 300)])
 def test_mixed_schedule_other_shard_sizes(batch, T, monkeypatch):
-    """The split count of the mixed schedule is bounded by the CUs of every XCD (the workgroups of both launches go round-robin
-    over the XCDs from XCD 0), which makes the pair / single counts and the rotation length depend on the shard size:
-    7500 chains = 215 pairs + 40 singles, rotation of 47 segments; 5000 chains = 61 + 192, rotation of 157 (157 pairs: prime);
-    4200 chains = 8 + 248; 8000 chains would split 4 pairs of 250, which does not pay: plain schedule.  Trajectories and
-    records must be BITWISE those of the plain schedule for every one of them."""
+    """The pair / single counts of the mixed schedule and the length of its rotation depend on the shard size: 7500 chains =
+    215 pairs + 40 singles (20 splits rotate in 47 segments; the 21 the CUs allow would take 235), 5000 chains = 58 + 198,
+    rotation of 157 (157 pairs: prime), 4200 chains = 8 + 248; 8000 chains would split 6 pairs of 250, which does not pay:
+    plain schedule.  Trajectories and records must be BITWISE those of the plain schedule for every one of them."""
     W, b, y, xs = _problem(batch)
     cycles, steps, used = _mixed_plan(batch, T)
     assert (cycles > 0) == (batch != 8000) and steps <= T
