@@ -519,8 +519,8 @@ int build_phases(mcpc_engine* e) {
 
 namespace {
 
-// Mixed schedule (see mcpc_engine::mix): a second LDS plan and phase table for 16-chain workgroups, the rotation tables,
-// a second stream.  A shard of `nwg` 32-chain workgroups leaves n_cu - nwg CUs idle; per segment that many pairs of chain
+// Mixed schedule (see mcpc_engine::mix): a second LDS plan and phase table for 16-chain workgroups and the rotation tables.
+// A shard of `nwg` 32-chain workgroups leaves n_cu - nwg CUs idle; per segment that many pairs of chain
 // tiles are split into two 16-chain workgroups each, which advance ~1.7x as many steps in the same time.  Rotating the
 // split set cyclically over the pairs, every pair has been split equally often after nwg / gcd(nwg, ns) segments.
 // Per-chain results do not depend on the form a step is computed in (the two kernels run the same arithmetic in the same
@@ -1286,7 +1286,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
                 const int sp = (e->knobs.mix_ratio * p + 5) / 10;
                 const int cyc = e->mix_a * sp + (e->mix_lc - e->mix_a) * p;
                 if (cyc > n) { --p; continue; }
-                // (events around a whole cycle only: one between the two concurrent launches of a segment serialises them)
+                // (events around whole cycles)
                 { const int rc = prof_begin(true); if (rc) return rc; }
                 const int rc = run_mixed_cycle(t, p, sp);
                 if (rc) return rc;
