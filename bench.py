@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the inference-only calls (clean PMC passes of the learning call)")
     ap.add_argument("--only-inference", action="store_true", help="time inference-only calls only (clean PMC passes of the mixed schedule)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--no-self-check", action="store_true", help="skip the replay of one call on the serial / plain schedule (PMC passes)")
     ap.add_argument("--force-dist", action="store_true",
                     help="developer check: take the multi-rank code path (RCCL group, barriers, all-reduces) with whatever world size the "
                          "environment gives, 1 included -- the 1-GPU rehearsal of what the driver launches with torch.distributed.run")
@@ -199,6 +200,53 @@ def main():
 
     en = res.energies[-1].tolist()
     finite = all(abs(v) < 1e30 for v in en)
+
+    # ---- self-check (outside the timed region): ONE call of the timed kind from the initial state, on the tuning that was
+    # timed and on the serial / plain one (no mixed schedule, one spill-ring part flushed on the caller's stream: nothing
+    # overlaps, nothing can race).  Per chain both run the same arithmetic in the same order, so the final state and the
+    # records must agree BITWISE, the gradient bucket up to nothing (same 64-step Hebbian segments) and the energies up to
+    # the grouping of fp32 partial sums.  What the reference defines for these: pc_trainer.py:853-862 (dF/dtheta summed over
+    # accumulate_p_at), :904-914 (normalisation).
+    self_check = None
+    if not args.no_self_check:
+        def replay(engine):
+            engine.load_state(xs)
+            r_ = engine.run(T, loss_kind=L.LOSS_BERNOULLI, xopt=L.XOPT_SGD, lr=0.03, noise_mode=L.NOISE_PHILOX, noise_var=2.0,
+                            seed=30, step_base=0, chain_base=rank * B, acc_begin=mixing if primary_learning else 0,
+                            acc_end=T if primary_learning else 0, energy_mode=L.ENERGY_ALL, rec_begin=0, rec_stride=100,
+                            rec_count=(T + 99) // 100, rec_x=True)
+            st = [torch.empty_like(x) for x in xs]
+            engine.store_state(st)
+            fl = engine.read_param_grads_flat(scale=1.0) if primary_learning else None
+            engine.sync_check()
+            return r_, st, fl
+        ra, sa, fa = replay(eng)
+        serial = "no_mix=1,no_overlap=1,slot_cap=64"
+        eng_s = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=device, tuning=serial)
+        eng_s.bind_params(W, b)
+        eng_s.bind_inputs(None)
+        eng_s.bind_target(y)
+        rb, sb, fb = replay(eng_s)
+        eng_s.close()
+        ea, eb = ra.energies, rb.energies
+        self_check = {
+            "reference": "the same call (initial state, seed, Philox step base 0) on tuning '%s'" % serial,
+            "mode": "learning call" if primary_learning else "inference-only call",
+            "bitwise_state": all(torch.equal(p_, q_) for p_, q_ in zip(sa, sb)),
+            "bitwise_records": all(torch.equal(p_, q_) for p_, q_ in zip(ra.rec_x, rb.rec_x)),
+            "bucket_bitwise": None if fa is None else bool(torch.equal(fa, fb)),
+            "bucket_max_rel": None if fa is None else float((fa - fb).abs().max() / fb.abs().max()),
+            "energies_max_rel": float(((ea - eb).abs() / eb.abs().clamp_min(1e-300)).max()),
+            "energies_finite": bool(torch.isfinite(ea).all()),
+        }
+        ok = (self_check["bitwise_state"] and self_check["bitwise_records"] and self_check["energies_finite"]
+              and self_check["energies_max_rel"] <= 2e-6 and (fa is None or self_check["bucket_max_rel"] <= 1e-5))
+        if dist is not None:
+            flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item())
+        self_check["ok"] = ok
+        self_check["ranks_checked"] = world
     if rank == 0:
         q = eng.query()
         flops_inf = 4.0 * S_MACS * B     # algorithmic FLOPs per step: forward 2*S + back-projection 2*S per chain
@@ -246,6 +294,7 @@ def main():
         out = {
             "metric": "Langevin inference steps/sec (whole node), MNIST MCPC 784-256-256-30, batch 6000",
             "value": value,
+            "value_mode": "learning_call" if primary_learning else "inference_only_call",
             "unit": "steps/s",
             "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": dt / K * 1e3,
@@ -281,6 +330,8 @@ def main():
         }
         if mixed_line is not None and mixed_line is not roof:
             out["roofline"]["mixed_schedule"] = mixed_line
+        if self_check is not None:
+            out["self_check"] = self_check
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, args.cpu_budget)
             out["config"]["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
@@ -288,6 +339,9 @@ def main():
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
+    if self_check is not None and not self_check["ok"]:
+        sys.stderr.write("bench.py: SELF-CHECK FAILED: %s\n" % json.dumps(self_check))
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -18,10 +18,13 @@
  * code; mcpc_last_error() returns a human-readable message for the calling thread.
  *
  * Threading: one engine per (device, stream); an engine is not re-entrant.  All launches are
- * asynchronous on the given stream; the only calls that wait for the device are mcpc_create /
- * mcpc_destroy, mcpc_sync_check and mcpc_last_step_kernel_ms.  mcpc_run never waits for the stream:
- * buffers that have to grow (per-step tables, energy partials) are replaced and the old ones retired
- * until mcpc_destroy; the first run that accumulates Hebbian sums allocates the spill ring (hipMalloc).
+ * asynchronous on the given stream; the calls that wait for the device are mcpc_create / mcpc_destroy,
+ * mcpc_sync_check and the two profiling getters.  mcpc_run does not wait for the stream, with two
+ * bounded exceptions: a run with MCPC_XOPT_ADAM uploads its bias-correction table from one of two pinned
+ * staging buffers and waits (hipEventSynchronize) for the upload issued two Adam runs earlier if that
+ * has still not executed; and the first run that accumulates Hebbian sums allocates the spill ring
+ * (hipMalloc).  Device buffers that have to grow (per-step tables, energy partials; geometrically) are
+ * replaced, the old ones retired behind an event and freed by a later run once that event has completed.
  * The library reads no environment variables.
  */
 #ifndef MCPC_H
@@ -204,10 +207,10 @@ const char* mcpc_step_kernel_name(const mcpc_engine* e);
 /* Timing hooks.  While profiling is enabled (mcpc_set_profiling(e, 1); every call of it resets the tallies), mcpc_run
  * brackets with HIP events on its stream
  *   - every step-kernel launch of the plain schedule (all Hebbian stretches, plain inference stretches), and
- *   - every whole CYCLE of the mixed 32-/16-chain schedule (inference stretches of a shard that leaves CUs idle): its two
- *     concurrent launches per segment cannot be bracketed one by one -- an event between them would serialise them.
+ *   - every whole CYCLE of the mixed 32-/16-chain schedule (inference stretches of a shard that leaves CUs idle; a segment
+ *     of a cycle is ONE launch of mcpc_steps_ws2_mixed_kernel, a cycle is up to a few hundred of them back to back).
  * The two getters synchronise on the recorded events and return the summed time, the number of brackets and the
- * whole-shard steps they cover, accumulated over all runs since profiling was enabled. */
+ * whole-shard steps they cover, accumulated over all runs since profiling was enabled (at most 65 536 brackets per set). */
 int mcpc_set_profiling(mcpc_engine* e, int enable);
 int mcpc_last_step_kernel_ms(mcpc_engine* e, float* ms, int32_t* n_launches, int64_t* n_steps);
 int mcpc_last_mixed_cycles_ms(mcpc_engine* e, float* ms, int32_t* n_cycles, int64_t* n_steps);

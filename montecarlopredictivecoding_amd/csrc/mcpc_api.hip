@@ -165,7 +165,9 @@ struct mcpc_engine {
     size_t adam_host_cap[2] = {0, 0};
     hipEvent_t adam_ev[2] = {nullptr, nullptr};
     int adam_next = 0;
-    std::vector<void*> retired;     // device buffers replaced by larger ones while earlier launches may still read them: freed at destroy
+    struct Retired { void* p; hipEvent_t ev; };
+    std::vector<Retired> retired;   // device buffers replaced by larger ones while earlier launches may still use them: each carries an event
+                                    // recorded on the stream at retirement and is freed by the first later run that finds the event complete
     bool spill_ready = false;       // the spill ring, its stream/events and the slabs exist (allocated by the first accumulating run)
     // LDS plan
     int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_bytes = 0;
@@ -240,7 +242,7 @@ int free_all(mcpc_engine* e) {
     if (e->ev_fork) { (void)hipEventDestroy(e->ev_fork); e->ev_fork = nullptr; }
     if (e->ev_join) { (void)hipEventDestroy(e->ev_join); e->ev_join = nullptr; }
     F(e->mix_tab); F(e->alt16.phases);
-    for (void* q : e->retired) (void)hipFree(q);
+    for (auto& q : e->retired) { (void)hipFree(q.p); if (q.ev) (void)hipEventDestroy(q.ev); }
     e->retired.clear();
     for (int i = 0; i < 2; ++i) {
         if (e->adam_host[i]) { (void)hipHostFree(e->adam_host[i]); e->adam_host[i] = nullptr; }
@@ -257,6 +259,27 @@ int dmalloc(T*& p, size_t count) {
     if (err != hipSuccess) return fail(MCPC_ENOMEM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(err));
     p = (T*)q;
     return 0;
+}
+
+// A buffer that launches already in the stream may still use is not freed but retired behind an event.
+void retire(mcpc_engine* e, void* p, hipStream_t stream) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, stream) != hipSuccess) {
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;                                  // no event: the buffer waits for mcpc_destroy
+    }
+    e->retired.push_back({p, ev});
+}
+// ... and freed by a later run once that event has completed (never under a kernel that uses it)
+void free_completed_retired(mcpc_engine* e) {
+    size_t keep = 0;
+    for (size_t i = 0; i < e->retired.size(); ++i) {
+        auto& q = e->retired[i];
+        if (q.ev && hipEventQuery(q.ev) == hipSuccess) { (void)hipFree(q.p); (void)hipEventDestroy(q.ev); }
+        else e->retired[keep++] = q;
+    }
+    e->retired.resize(keep);
+    (void)hipGetLastError();                           // hipEventQuery's hipErrorNotReady is not an error of this run
 }
 
 // LDS plan: activations ping-pong between two buffers (FX_l in buffer l&1), the read-out error
@@ -1081,13 +1104,14 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     if (r->energy_mode != MCPC_ENERGY_NONE && !r->energies_out) return fail(MCPC_EINVAL, "energies_out is null");
     if (r->rec_count < 0 || (r->rec_count > 0 && r->rec_stride < 1)) return fail(MCPC_EINVAL, "bad record schedule");
     const int acc_b = std::max(r->acc_begin, 0), acc_e = std::min(r->acc_end, r->T);
+    if (!e->retired.empty()) free_completed_retired(e);
 
     // ---- per-run device tables ----------------------------------------------------------------
     if (r->xopt_kind == MCPC_XOPT_ADAM) {
         const size_t need = (size_t)r->n_steps * 2;
         if (need > e->adam_cap) {
             // earlier launches may still read the old table: retire it instead of synchronising
-            if (e->adam_coef) e->retired.push_back(e->adam_coef);
+            if (e->adam_coef) retire(e, e->adam_coef, stream);
             e->adam_coef = nullptr;
             size_t cap = 1024;
             while (cap < need) cap *= 2;
@@ -1128,11 +1152,13 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     // forms can then serve the same call)
     const size_t eslots = e->ws == 2 ? (size_t)e->Bpad / 16 : (size_t)e->nwg;
     if (r->energy_mode != MCPC_ENERGY_NONE && erows > e->epart_rows) {
-        if (e->epart) e->retired.push_back(e->epart);     // earlier launches may still write it
+        if (e->epart) retire(e, e->epart, stream);        // earlier launches may still write it
         e->epart = nullptr;
-        int rc = dmalloc(e->epart, erows * eslots * (kMaxLatent + 1));
+        // geometric growth: a caller whose T creeps up call by call re-allocates O(log T) times, not every call
+        const size_t cap = std::max(erows, e->epart_rows + e->epart_rows / 2);
+        int rc = dmalloc(e->epart, cap * eslots * (kMaxLatent + 1));
         if (rc) return rc;
-        e->epart_rows = erows;
+        e->epart_rows = cap;
     }
     // mu_1 = inputs W0^T + b0 (constant during the run: weights only change between runs)
     {
@@ -1221,10 +1247,17 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     mix_ok = false;
 #endif
     // HIP events around the launches of the plain schedule (set 0) and around whole cycles of the mixed schedule (set 1)
+    // (at most kMaxProfBrackets per set since profiling was switched on: a caller that leaves it on forever stops collecting,
+    // it does not accumulate HIP events without bound)
+    constexpr size_t kMaxProfBrackets = 1 << 16;
+    bool bracket_open = false;
     auto prof_begin = [&](bool mixed = false) -> int {
+        bracket_open = false;
         if (!e->profiling) return 0;
         auto& ev = mixed ? e->events_mix : e->events;
         size_t& used = mixed ? e->events_mix_used : e->events_used;
+        if (used >= kMaxProfBrackets) return 0;
+        bracket_open = true;
         if (used == ev.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(MCPC_EHIP, "hipEventCreate failed");
@@ -1233,7 +1266,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         return hipEventRecord(ev[used].first, stream) == hipSuccess ? 0 : fail(MCPC_EHIP, "hipEventRecord failed");
     };
     auto prof_end = [&](double steps, bool mixed = false) -> int {
-        if (!e->profiling) return 0;
+        if (!e->profiling || !bracket_open) return 0;
         auto& ev = mixed ? e->events_mix : e->events;
         size_t& used = mixed ? e->events_mix_used : e->events_used;
         if (hipEventRecord(ev[used].second, stream) != hipSuccess) return fail(MCPC_EHIP, "hipEventRecord failed");

@@ -951,62 +951,6 @@ __global__ __launch_bounds__(256, 2) void mcpc_dw_kernel(const float* __restrict
     }
 }
 
-// column sums for the bias gradients: slab[ks][u] = sum_{r in split} E[r][u]
-__global__ __launch_bounds__(256) void mcpc_colsum_kernel(const float* __restrict__ E, float* __restrict__ slab,
-                                                          int rows, int ne, int rows_per_split) {
-    __shared__ float part[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sub = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * rows_per_split, r1 = min(rows, r0 + rows_per_split);
-    float s = 0.f;
-    if (col < ne)
-        for (int r = r0 + sub; r < r1; r += 4) s += E[(size_t)r * ne + col];
-    part[sub][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (sub == 0 && col < ne)
-        slab[(size_t)blockIdx.y * ne + col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-}
-
-// dst[i] (=|+=) sign * sum_k slab[k][i], fixed order -> bitwise reproducible
-__global__ void mcpc_reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dst, size_t n, int ksplit,
-                                         float sign, int accumulate) {
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        // fixed summation order (k ascending, groups of 8 independent loads in flight)
-        float s = 0.f;
-        int k = 0;
-        for (; k + 8 <= ksplit; k += 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(slab + (size_t)(k + j) * n + idx);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[j];
-        }
-        for (; k < ksplit; ++k) s += slab[(size_t)k * n + idx];
-        dst[idx] = accumulate ? dst[idx] + sign * s : sign * s;
-    }
-}
-
-// Same contract for short vectors (bias slabs, the 256x32 matrix) and many splits: a block of 16 waves owns 64 consecutive
-// elements, wave w sums the splits w, w+16, ... (coalesced 256-B rows, ascending order) and the 16 partial sums are added
-// in wave order through LDS -- bitwise reproducible, and the ~1000 dependent loads of the form above become ~63.
-__global__ __launch_bounds__(1024) void mcpc_reduce_slabs_wide_kernel(const float* __restrict__ slab, float* __restrict__ dst, int n,
-                                                                     int ksplit, float sign, int accumulate) {
-    __shared__ float part[16][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (idx < n)
-        for (int k = w; k < ksplit; k += 16) s += __builtin_nontemporal_load(slab + (size_t)k * n + idx);
-    part[w][lane] = s;
-    __syncthreads();
-    if (w == 0 && idx < n) {
-        float t = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) t += part[j][lane];
-        dst[idx] = accumulate ? dst[idx] + sign * t : sign * t;
-    }
-}
-
 // Linear 0 (constant input): G_W0[u][k] -= sum_chain esum[chain][u] * inputs[chain][k];  G_b0[u] -= sum_chain esum[chain][u].
 // One block per (unit u, column k) -- blockIdx.y == n_in is the bias -- 256 threads stride over the chains, partial sums
 // meet in a fixed-order LDS tree: bitwise reproducible.  (One thread per output looping over 6000 chains took 2.3 ms.)

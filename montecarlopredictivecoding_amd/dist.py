@@ -29,7 +29,13 @@ def flat_param_count(linears) -> int:
 def allreduce_flat(flat: torch.Tensor, group=None) -> torch.Tensor:
     """Sum the gradient bucket over all shards in place (no-op without an initialised process group)."""
     if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=group)
+        if flat.is_cuda and torch.distributed.get_backend(group) == "gloo":
+            # gloo is the CPU backend (tests, rehearsals of several ranks on one GPU): stage the bucket through the host
+            host = flat.cpu()
+            torch.distributed.all_reduce(host, op=torch.distributed.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=group)
     return flat
 
 

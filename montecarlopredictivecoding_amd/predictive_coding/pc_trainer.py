@@ -12,12 +12,13 @@ How a call is executed
 fused     the whole T-step loop runs inside ``mcpc_run`` (libmcpc.so): network
           Sequential[Linear, PCLayer, act, ...], quadratic energies, Gaussian / Bernoulli / masked /
           no loss, SGD or Adam on x at every step, ``update_p_at`` in {'never','last'}, and either no
-          callback or this package's tagged ``random_step`` (fused as Philox noise).
+          callback or a Langevin kick -- this package's tagged ``random_step`` or any callable that behaves
+          like the reference's (utils/model.py:35-44), e.g. a script's own unmodified copy -- fused as Philox noise.
           This is every call pattern of the reference's scripts.
 stepwise  same network/loss, but arbitrary callbacks, ``update_p_at='all'``, custom x optimizers
           (any torch optimizer), dynamic x-lr ...: per step the HIP kernel produces dF/dx and
           dF/dtheta (``update_x=0``), the reference's control flow around them is replayed with the
-          user's torch optimizers and callbacks.
+          user's torch optimizers and callbacks.  A RuntimeWarning names the reason.
 rejected  anything the kernels do not express (S/M masks, non-quadratic ``energy_fn``, ``loss_x_fn``,
           optimised inputs, non-Sequential models ...) raises ``NotImplementedError`` naming the
           reason.  There is no silent torch or CPU execution of the loop.
@@ -154,7 +155,6 @@ class PCTrainer(object):
         self.mcpc_chain_base = 0              # global id of this shard's first chain
         self.mcpc_process_group = None        # torch.distributed group for the Hebbian all-reduce (or None)
         self.mcpc_world_batch = None          # global batch for the 1/(n*B) normalisation when sharded
-        self._derived_world_batch = {}
         self.mcpc_sharded = False
         self.mcpc_materialize_unused_grads = False   # reference quirk: autograd fills .grad even if never used
         self.last_call_mode = None            # 'fused' | 'stepwise' (for tests / diagnostics)
@@ -284,7 +284,10 @@ class PCTrainer(object):
         """Declare that this trainer holds one shard of a larger batch of chains.
 
         ``chain_base``  global index of the first local chain (keeps Philox noise independent of the sharding),
-        ``world_batch`` total number of chains over all shards (the reference divides grads by ``len(inputs)``),
+        ``world_batch`` total number of chains over all shards (the reference divides grads by ``len(inputs)``); ``None``:
+                        every learning call sums the local batches over the group (one int64 all-reduce -- a collective, so it
+                        is issued by every rank on every learning call and never cached on a rank-local value: shards may be
+                        uneven and the last batch of a data loader ragged),
         ``process_group`` the group whose members' Hebbian sums are all-reduced once per learning call.
         """
         self.mcpc_process_group = process_group
@@ -292,7 +295,6 @@ class PCTrainer(object):
         if world_batch is not None and int(world_batch) < 1:
             raise ValueError("world_batch must be positive")
         self.mcpc_world_batch = None if world_batch is None else int(world_batch)
-        self._derived_world_batch = {}        # local batch -> all-reduced total, when world_batch is not given
         self.mcpc_sharded = True
 
     def _global_batch(self, local_batch: int) -> int:
@@ -302,9 +304,8 @@ class PCTrainer(object):
             return local_batch
         if self.mcpc_world_batch is not None:
             return self.mcpc_world_batch
-        if local_batch not in self._derived_world_batch:
-            self._derived_world_batch[local_batch] = dist.sum_over_group(local_batch, self.mcpc_process_group)
-        return self._derived_world_batch[local_batch]
+        # a collective: every rank of the group reaches this line once per learning call (same trainer schedule on all ranks)
+        return dist.sum_over_group(local_batch, self.mcpc_process_group)
 
     # ---- the call --------------------------------------------------------------------------------------
     def train_on_batch(
@@ -385,6 +386,11 @@ class PCTrainer(object):
             self.last_call_mode = "fused"
             return self._run_fused(plan, **common)
         self.last_call_mode = "stepwise"
+        # the reference warns about everything that slows a call down (utils.py:8-16); leaving the fused loop is the one that matters here
+        warnings.warn(
+            "In PCTrainer.train_on_batch, this call leaves the fused HIP loop and runs step by step (T kernel launches with the "
+            "reference's control flow, optimizers and callbacks replayed on the host between them), this will slow down training. "
+            "Reason: {}. ".format(plan["why_stepwise"]), category=RuntimeWarning)
         return self._run_stepwise(plan, callback_after_backward=callback_after_backward,
                                   callback_after_backward_kwargs=callback_after_backward_kwargs,
                                   callback_after_t=callback_after_t, callback_after_t_kwargs=callback_after_t_kwargs,
@@ -542,6 +548,10 @@ class PCTrainer(object):
         n_rec = T if is_return_results_every_t else 1
         if is_return_outputs:
             src = res.rec_out if net.n_out > 0 else res.rec_x[-1]
+            if src.device != plan["device"]:
+                # sliced recording drains latent records to pinned host memory; `outputs` are live device tensors in the reference
+                # (pc_trainer.py:733,770) whatever mcpc_record_chunk_bytes is: a model without a read-out gets them back there
+                src = src.to(plan["device"])
             results["outputs"] = [src[k] for k in range(n_rec)]
         if is_return_representations:
             host = res.rec_x[0].cpu()
@@ -706,7 +716,7 @@ class PCTrainer(object):
         energies = torch.zeros(T, L.ENERGY_COLS, dtype=torch.float64, device=plan["device"])
         params = [p for lin in net.linears for p in ([lin.weight] if lin.bias is None else [lin.weight, lin.bias])]
         nl = len(net.sizes)
-        B_global = self._global_batch(plan["B"])
+        B_global = self._global_batch(plan["B"]) if self._update_p_at else None     # (a collective when sharded: only if used)
         for t in range(T):
             self._sync_params(eng, net)
             eng.load_state([x.data for x in xs])

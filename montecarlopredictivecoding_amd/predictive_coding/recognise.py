@@ -198,7 +198,10 @@ def describe_x_optimizer(fn, kwargs) -> typing.Tuple[typing.Optional[XOptDescrip
 
 
 def describe_callback(callback, kwargs, trainer) -> typing.Tuple[typing.Optional[typing.Optional[float]], str]:
-    """Returns (noise_var or None for 'no callback', "") if fusable, else (None, reason) with ok=False signalled by reason."""
+    """Returns (noise_var or None for 'no callback', "") if fusable, else (None, reason) with ok=False signalled by reason.
+
+    Fusable = the callback is a Langevin kick: this package's tagged ``random_step``, or ANY callable that behaves like the
+    reference's ``random_step`` (utils/model.py:35-44) when probed -- e.g. the user's own unmodified copy of those ten lines."""
     if callback is None:
         return None, ""
     tag = getattr(callback, "_mcpc", None)
@@ -212,4 +215,151 @@ def describe_callback(callback, kwargs, trainer) -> typing.Tuple[typing.Optional
         if var < 0:
             return None, "negative noise variance"
         return var, ""
-    return None, "callback_after_t is an arbitrary callable"
+    return _probe_langevin_callback(callback, kwargs, trainer)
+
+
+# ---- behavioural recognition of a Langevin callback -------------------------------------------------------------------------
+class _ProbeRefused(Exception):
+    pass
+
+
+class _SpyGrad(torch.Tensor):
+    """A gradient tensor that notes how it is filled: ``normal_(mean, std)`` calls are logged with their exact arguments."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if getattr(func, "__name__", "") == "normal_" and args and isinstance(args[0], _SpyGrad):
+            mean = args[1] if len(args) > 1 else kwargs.get("mean", 0.0)
+            std = args[2] if len(args) > 2 else kwargs.get("std", 1.0)
+            log = getattr(args[0], "_spy_log", None)
+            if log is not None:
+                log.append((float(mean), float(std), kwargs.get("generator") is not None))
+        return super().__torch_function__(func, types, args, kwargs)
+
+
+class _StubOptimizer:
+    """What random_step touches of an optimizer: ``defaults['lr']``, ``param_groups``, ``zero_grad()``, ``step()``."""
+
+    def __init__(self, params, lr):
+        self.defaults = {"lr": lr}
+        self.param_groups = [{"params": params, "lr": lr}]
+        self.state = {}
+        self.steps = []                       # per step() call: the gradients it saw
+
+    def zero_grad(self, set_to_none=False):
+        for p in self.param_groups[0]["params"]:
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def step(self, closure=None):
+        self.steps.append([None if p.grad is None else p.grad.detach().as_subclass(torch.Tensor).clone()
+                           for p in self.param_groups[0]["params"]])
+
+    def __getattr__(self, name):
+        raise _ProbeRefused(f"the callback uses optimizer_x.{name}")
+
+
+class _StubTrainer:
+    """What random_step touches of a trainer: ``get_model_xs()`` and ``get_optimizer_x()``; anything else refuses the probe."""
+
+    def __init__(self, params, optimizer):
+        self._params, self._optimizer = params, optimizer
+
+    def get_model_xs(self, is_warning_x_not_initialized=True):
+        return iter(self._params)
+
+    def get_optimizer_x(self):
+        return self._optimizer
+
+    def get_optimizer_x_lr(self):
+        return self._optimizer.param_groups[0]["lr"]
+
+    def __getattr__(self, name):
+        raise _ProbeRefused(f"the callback uses trainer.{name}")
+
+
+_PROBE_SHAPES = ((64, 48), (32, 40))          # 3072 + 1280 probe elements, two "layers"
+_PROBE_CACHE = {}
+
+
+def _probe_key(callback, kwargs, trainer, lr, T):
+    items = []
+    for k in sorted(kwargs):
+        v = kwargs[k]
+        items.append((k, "<trainer>" if v is trainer else (v if isinstance(v, (int, float, str, bool, type(None))) else id(v))))
+    return (id(callback), getattr(callback, "__code__", None), tuple(items), lr, T)
+
+
+def _probe_langevin_callback(callback, kwargs, trainer):
+    """Run ``callback(t, **kwargs)`` on a scratch trainer (the kwarg that IS the trainer is replaced by a stub whose latent
+    tensors are CPU probes) at t = 0, T // 2, T - 1 and accept it as a Langevin kick iff, every time, it
+      * fills every ``x.grad`` with ``normal_(0, std)`` -- one common std, no private generator -- and leaves it at that
+        (the gradients ``optimizer.step()`` sees have the moments of N(0, std^2): nothing rescaled them afterwards),
+      * calls ``optimizer.step()`` exactly once, and touches neither the x values nor anything else of the trainer.
+    That is the reference's ``random_step`` (utils/model.py:35-44: ``x.grad.normal_(0., sqrt(var / lr)); optimizer.step()``,
+    i.e. x <- x - lr * std * xi) whatever it is called and wherever it is defined; the fused kick is
+    x <- x + sqrt(noise_var * lr) * xi with noise_var = lr * std^2.  The probe draws from torch's CPU generator; the
+    generator states (torch, NumPy, random) are restored afterwards, so a seeded script is not disturbed."""
+    import random as _random
+
+    import numpy as np
+    xkw = getattr(trainer, "_optimizer_x_kwargs", None)
+    lr = xkw.get("lr") if isinstance(xkw, dict) else None
+    if not isinstance(lr, (int, float)) or not lr > 0:
+        return None, "callback_after_t with an x optimizer that has no positive lr"
+    lr = float(lr)
+    if not any(v is trainer for v in kwargs.values()):
+        return None, "callback_after_t is an arbitrary callable (it does not take the trainer as a keyword argument, so it cannot be probed)"
+    T = int(getattr(trainer, "_T", 1))
+    key = _probe_key(callback, kwargs, trainer, lr, T)
+    if key in _PROBE_CACHE:
+        return _PROBE_CACHE[key]
+    saved = (torch.get_rng_state(), np.random.get_state(), _random.getstate())
+    verdict = None
+    try:
+        stds = []
+        for t in sorted({0, T // 2, T - 1}):
+            g = torch.Generator().manual_seed(1234 + t)
+            params, logs = [], []
+            for shape in _PROBE_SHAPES:
+                p = torch.nn.Parameter(torch.randn(*shape, generator=g))
+                log = []
+                grad = torch.randn(*shape, generator=g).as_subclass(_SpyGrad)
+                grad._spy_log = log
+                p.grad = grad
+                params.append(p); logs.append(log)
+            before = [p.detach().clone() for p in params]
+            opt = _StubOptimizer(params, lr)
+            stub = _StubTrainer(params, opt)
+            kw = {k: (stub if v is trainer else v) for k, v in kwargs.items()}
+            callback(t, **kw)
+            if len(opt.steps) != 1:
+                raise _ProbeRefused(f"it calls optimizer_x.step() {len(opt.steps)} times, a Langevin kick calls it once")
+            if any(not torch.equal(a, p.detach()) for a, p in zip(before, params)):
+                raise _ProbeRefused("it writes to the x values directly")
+            for log, seen in zip(logs, opt.steps[0]):
+                if len(log) != 1:
+                    raise _ProbeRefused("it does not fill every x.grad with exactly one normal_() call")
+                mean, std, private_gen = log[0]
+                if mean != 0.0 or not std > 0 or private_gen:
+                    raise _ProbeRefused("its noise is not N(0, std) from the default generator")
+                stds.append(std)
+                n = seen.numel()
+                m1, m2 = float(seen.mean()) / std, float((seen * seen).mean()) / std ** 2
+                m4 = float((seen ** 4).mean()) / std ** 4
+                if abs(m1) > 6.0 / n ** 0.5 or abs(m2 - 1.0) > 6.0 * (2.0 / n) ** 0.5 or abs(m4 - 3.0) > 6.0 * (96.0 / n) ** 0.5:
+                    raise _ProbeRefused("the gradients its optimizer step sees are not the N(0, std) it drew")
+        if max(stds) - min(stds) > 1e-12 * max(stds):
+            raise _ProbeRefused("its noise scale differs between layers or steps")
+        verdict = (float("%.12g" % (lr * stds[0] ** 2)), "")
+    except _ProbeRefused as why:
+        verdict = (None, f"callback_after_t is not a plain Langevin kick: {why}")
+    except Exception as exc:                   # the callable needs more of a trainer than the stub has
+        verdict = (None, f"callback_after_t could not be probed ({type(exc).__name__}: {exc})")
+    finally:
+        torch.set_rng_state(saved[0]); np.random.set_state(saved[1]); _random.setstate(saved[2])
+    if len(_PROBE_CACHE) > 256:
+        _PROBE_CACHE.clear()
+    _PROBE_CACHE[key] = verdict
+    return verdict

@@ -2,7 +2,8 @@
 (`sample_pc`, `get_mse_rec`, `get_marginal_likelihood`), a shipped checkpoint, and the toy learning runs of
 figure_4 / figure_6.  TEST INFRASTRUCTURE ONLY; runs only in the build container (imports /root/reference).
 
-    python -m oracle.gen_golden_eval            # writes tests/golden/g10_* g11_* g12_*
+    python -m oracle.gen_golden_eval            # writes tests/golden/g10_* g11_* g12_* g14_*
+    python -m oracle.gen_golden_eval representations      # g14_representations only
 
 What is stored is data: seeded inputs (philox), the reference's outputs, and -- for g11 -- one of the reference's
 shipped weight files copied byte for byte (`models/mcpc_fid_3`, a `torch.save`d state_dict: a data file, loaded
@@ -213,10 +214,62 @@ def gen_learning(pc, um, te):
     return path
 
 
+REP_SEEDS = tuple(range(21, 33))      # 12 torch seeds: the spread of the reference's own Langevin means
+
+
+def rep_config(um):
+    import torch.optim as optim
+    return dict(EVAL_SHAPE, activation_fn="relu", loss_fn=um.bernoulli_fn, input_var=None, T_pc=60, optimizer_x_fn_pc=optim.Adam,
+                optimizer_x_kwargs_pc={"lr": 0.1}, mixing=100, sampling=400, optimizer_x_kwargs_mcpc={"lr": 0.03})
+
+
+def gen_representations(pc, um, te):
+    """`get_representations` of the reference (utils/model.py:71-163) on the g10 net (seeded weights, 48 binary images in batches
+    of 16, x0 = 3 everywhere so that the MAP inference is deterministic):
+      MAP          x_1 after 60 Adam steps per datapoint -- deterministic, pinned exactly;
+      expectation  mean of x_1 over all 500 Langevin steps started from the MAP state, for 12 torch seeds (the reference's own
+                   normal_): per-datapoint mean and spread over the seeds;
+      full         n = 10: every 40th sample after the mixing phase, one seed (shape / label layout)."""
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+    cfg = rep_config(um)
+    W, b, data, labels = eval_inputs(10001, "bernoulli")
+    model = um.get_model(cfg, False, sample_x_fn=um.sample_x_fn_cte)
+    load_params(model, W, b)
+    loader = DataLoader(TensorDataset(torch.from_numpy(data), torch.from_numpy(labels)), batch_size=16)
+    pc_tr = te.get_pc_trainer(model, cfg, training=False, is_mcpc=True)
+    mc_tr = te.get_mcpc_trainer(model, cfg, training=False)
+    blob = {"meta_json": np.array(json.dumps(dict(seed=10001, shape=EVAL_SHAPE, T_pc=60, lr_pc=0.1, mixing=100, sampling=400, lr_mcpc=0.03,
+                                                  batch_size=16, torch_seeds=list(REP_SEEDS), n_full=10))),
+            "data": data, "labels": labels}
+    for j, (w, v) in enumerate(zip(W, b)):
+        blob[f"W{j}"], blob[f"b{j}"] = w, v
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ds = um.get_representations(model, cfg, [pc_tr], loader, rep_type="MAP", use_cuda=False)
+        blob["map_reps"], blob["map_labels"] = ds.tensors[0].detach().numpy().copy(), ds.tensors[1].numpy().copy()
+        exps = []
+        for seed in REP_SEEDS:
+            torch.manual_seed(seed)
+            ds = um.get_representations(model, cfg, [pc_tr, mc_tr], loader, rep_type="expectation", use_cuda=False)
+            exps.append(ds.tensors[0].detach().numpy().copy())
+        blob["expectation_reps"] = np.array(exps)                       # [12, 48, 8]
+        blob["expectation_labels"] = ds.tensors[1].numpy().copy()
+        torch.manual_seed(REP_SEEDS[0])
+        ds = um.get_representations(model, cfg, [pc_tr, mc_tr], loader, rep_type="full", use_cuda=False, n=10)
+        blob["full_reps"], blob["full_labels"] = ds.tensors[0].detach().numpy().copy(), ds.tensors[1].numpy().copy()
+    path = os.path.join(GOLDEN, "g14_representations.npz")
+    np.savez_compressed(path, **blob)
+    return path
+
+
 def main():
     pc, um, te = import_reference_eval()
-    made = [gen_evaluators(pc, um, te, "bernoulli", 10001), gen_evaluators(pc, um, te, "gaussian", 10002),
-            gen_checkpoint(pc, um, te), gen_learning(pc, um, te)]
+    if sys.argv[1:] == ["representations"]:
+        made = [gen_representations(pc, um, te)]
+    else:
+        made = [gen_evaluators(pc, um, te, "bernoulli", 10001), gen_evaluators(pc, um, te, "gaussian", 10002),
+                gen_checkpoint(pc, um, te), gen_learning(pc, um, te), gen_representations(pc, um, te)]
     for p in made:
         print("wrote", p, os.path.getsize(p) // 1024, "KiB")
 

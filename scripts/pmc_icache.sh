@@ -15,7 +15,7 @@ for MODE in ${MODES:-inference}; do
   for G in ic1 ic2; do
     D=$OUT/raw_${MODE}_$G
     echo "== $MODE $G: ${PMCG[$G]}"
-    rocprofv3 --pmc ${PMCG[$G]} --output-format csv -d $D -o pmc -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline $ARGS > $OUT/${MODE}_$G.json 2> $OUT/${MODE}_$G.err || { echo "pass failed"; tail -3 $OUT/${MODE}_$G.err; continue; }
+    rocprofv3 --pmc ${PMCG[$G]} --output-format csv -d $D -o pmc -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-self-check $ARGS > $OUT/${MODE}_$G.json 2> $OUT/${MODE}_$G.err || { echo "pass failed"; tail -3 $OUT/${MODE}_$G.err; continue; }
     F=$(ls $D/*counter_collection.csv | head -1)
     python3 $ROOT/scripts/reduce_pmc.py "$F" $OUT/sum_${MODE}_$G.json
   done

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/ring
 for t in "$@"; do
   [ "$t" = "-" ] && t=""
-  MCPC_TUNING="$t" timeout -k 10 200 python3 bench.py --steps ${AB_STEPS:-4} --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/ring/o.json 2> gpurun_out/ring/o.err || { echo "[$t] failed"; tail -3 gpurun_out/ring/o.err; exit 1; }
+  MCPC_TUNING="$t" timeout -k 10 200 python3 bench.py --steps ${AB_STEPS:-4} --warmup 1 --no-cpu-baseline --no-self-check --no-secondary > gpurun_out/ring/o.json 2> gpurun_out/ring/o.err || { echo "[$t] failed"; tail -3 gpurun_out/ring/o.err; exit 1; }
   python3 - <<PY
 import json
 d=json.load(open("gpurun_out/ring/o.json"))

@@ -20,7 +20,9 @@ def fixture_names(prefix="", exclude=()):
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
     # g10_* / g11_* / g12_* are the evaluator, checkpoint and learning-run fixtures of oracle/gen_golden_eval.py: another
     # format, consumed by tests/test_evaluators_golden.py and tests/test_gpu_widening.py / test_gpu_learning.py
-    exclude = tuple(exclude) + ("g10_", "g11_", "g12_")
+    # g13_* (stationary statistics of the reference's own sampler, oracle/gen_golden_sampling.py) and g14_* (get_representations)
+    # are consumed by tests/test_gpu_sampling.py and tests/test_sampling_fixtures.py
+    exclude = tuple(exclude) + ("g10_", "g11_", "g12_", "g13_", "g14_")
     return [n for n in names if not any(n.startswith(x) for x in exclude)]
 
 

@@ -110,3 +110,36 @@ def test_shard_bounds_cover_everything():
         assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
     with pytest.raises(ValueError):
         dist.shard_bounds(10, 3, 3)
+
+
+def _ragged_worker(rank, world, port, out_dir):
+    import torch.distributed as tdist
+    import montecarlopredictivecoding_amd.predictive_coding as pc
+    from montecarlopredictivecoding_amd import dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    model = nn.Sequential(nn.Linear(3, 3), pc.PCLayer(), nn.Linear(3, 2))
+    tr = pc.PCTrainer(model, T=4, update_p_at="last", plot_progress_at=[])
+    tr.set_shard(process_group=tdist.group.WORLD, chain_base=64 * rank, world_batch=None)
+    # batches of a data loader whose last one is ragged on one rank only: (64, 64), (64, 36), (64, 64), (64, 36)
+    seen = []
+    for local in ((64, 64), (64, 36), (64, 64), (64, 36)):
+        seen.append(tr._global_batch(local[rank]))
+        flat = torch.full((5,), float(rank + 1))
+        dist.allreduce_flat(flat)                      # the gradient bucket's collective must pair with the other rank's bucket
+        assert flat.tolist() == [3.0] * 5
+    tr.set_shard(process_group=tdist.group.WORLD, chain_base=0, world_batch=777)
+    seen.append(tr._global_batch(5))                   # given: no collective
+    np.save(os.path.join(out_dir, f"ragged{rank}.npy"), np.array(seen))
+    tdist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_global_batch_is_a_collective_on_every_call_not_cached_per_local_size(tmp_path):
+    """the job-wide batch of a sharded learning call used to be cached per LOCAL batch size; with a ragged
+    last batch on one rank only that rank re-issued the all-reduce, the other skipped it, and the next gradient-bucket
+    all-reduce paired with the wrong collective.  Now every rank issues it on every learning call."""
+    mp.spawn(_ragged_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        assert np.load(os.path.join(tmp_path, f"ragged{rank}.npy")).tolist() == [128, 100, 128, 100, 777]

@@ -121,15 +121,19 @@ def test_bench_multi_rank_code_path_with_one_rank():
     assert len(lines) == 1, run.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["config"]["T"] == 400 and out["config"]["finite"]
-    assert out["value"] > 1000 and out["config"]["inference_only"]["steps_per_s"] > out["value"]
-    assert out["roofline"]["bound"] == "mfma" and 0.2 < out["roofline"]["frac"] < 1.0
+    assert out["value"] > 0 and out["value_mode"] == "learning_call"
+    assert out["config"]["inference_only"]["steps_per_s"] > out["value"]          # relative: no Hebbian sums, same box, same process
+    assert out["roofline"]["bound"] == "mfma" and 0.0 < out["roofline"]["frac"] < 1.0
+    sc = out["self_check"]                                    # the timed call replayed on the serial / plain schedule
+    assert sc["ok"] and sc["bitwise_state"] and sc["bitwise_records"] and sc["bucket_max_rel"] <= 1e-5 and sc["ranks_checked"] == 1
 
 
-def test_mixed_schedule_keeps_its_own_hardware_queue_beside_an_rccl_group():
+def test_mixed_schedule_stays_ahead_of_the_plain_schedule_beside_an_rccl_group():
     """Regression guard for what the one-rank rehearsal found: with an RCCL communicator in the process the HIP runtime mapped the
     mixed schedule's second stream onto the caller's hardware queue and the two launches of every segment ran one after the other
-    (145 us per step instead of 76; the plain schedule takes 93).  Its stream is high-priority now (queues of its own): inside the
-    cycles a step must stay well below the plain schedule's time."""
+    (145 us per step instead of 76; the plain schedule takes 93).  A segment is ONE launch now (both workgroup forms in
+    mcpc_steps_ws2_mixed_kernel), so there is no second stream to lose: inside the cycles a step must stay below the plain
+    schedule's time measured in the same process (a relative bound: absolute times move by several percent between boxes)."""
     from bench import make_problem
     from montecarlopredictivecoding_amd import _lib as L
     from montecarlopredictivecoding_amd.engine import Engine
@@ -141,19 +145,22 @@ def test_mixed_schedule_keeps_its_own_hardware_queue_beside_an_rccl_group():
         dist.all_reduce(t)                                    # the communicator (and its streams) exist from here on
         torch.cuda.synchronize()
         W, b, y, xs = make_problem(6000, 30, torch.device(DEV))
-        eng = Engine([30, 256, 256], [L.ACT_RELU] * 3, 30, 784, 6000, device=DEV)
-        eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
-        per_step = []
-        for _ in range(2):
-            eng.load_state(xs)
-            eng.set_profiling(True)
-            eng.run(1200, loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=1, step_base=0, energy_mode=L.ENERGY_LAST)
-            eng.sync_check()
-            ms, n_cycles, n_steps = eng.last_mixed_cycles_ms()
-            eng.set_profiling(False)
-            assert n_cycles >= 1 and n_steps >= 1000
-            per_step.append(ms / n_steps * 1e3)
-        eng.close()
+        per_step = {}
+        for key, tuning in (("mixed", None), ("plain", "no_mix=1")):
+            eng = Engine([30, 256, 256], [L.ACT_RELU] * 3, 30, 784, 6000, device=DEV, tuning=tuning)
+            eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
+            best = float("inf")
+            for _ in range(2):
+                eng.load_state(xs)
+                eng.set_profiling(True)
+                eng.run(1200, loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=1, step_base=0, energy_mode=L.ENERGY_LAST)
+                eng.sync_check()
+                ms, n, n_steps = eng.last_mixed_cycles_ms() if key == "mixed" else eng.last_step_kernel_ms()
+                eng.set_profiling(False)
+                assert n >= 1 and n_steps >= 1000
+                best = min(best, ms / n_steps * 1e3)
+            per_step[key] = best
+            eng.close()
     finally:
         dist.destroy_process_group()
-    assert min(per_step) < 86.0, per_step                     # 75-77 us when the halves overlap, 145 when they serialise
+    assert per_step["mixed"] < 0.95 * per_step["plain"], per_step      # 75-77 us against 89-93; 145 when the halves serialised

@@ -147,6 +147,62 @@ def test_fused_langevin_is_deterministic_and_matches_oracle_noise():
     np.testing.assert_allclose(res["overall"], ref.overall, rtol=5e-5)
 
 
+def _users_own_random_step(t, _pc_trainer, var=2.):
+    """What a script that keeps its own utils/model.py passes as callback_after_t: the reference's Langevin callback
+    (utils/model.py:35-44) restated verbatim in behaviour -- untagged, defined outside this package, NOT imported from
+    /root/reference."""
+    xs = _pc_trainer.get_model_xs()
+    optimizer = _pc_trainer.get_optimizer_x()
+    for x in xs:
+        x.grad.normal_(0., np.sqrt(var / optimizer.defaults['lr']))
+    optimizer.step()
+
+
+def test_untagged_reference_random_step_is_fused_and_other_callbacks_warn():
+    """north_star: "figure_*.py scripts run unchanged".  The reference's own random_step is recognised by what it DOES
+    (recognise._probe_langevin_callback) and fused as Philox noise: the call is bitwise the one made with this package's tagged
+    random_step.  A callback that is not a plain Langevin kick still runs (step-wise HIP path) -- and says so."""
+    from montecarlopredictivecoding_amd.predictive_coding import pc_trainer as pt
+    pc, um = _mods()
+    case = dict(sizes=[6, 16, 16], acts=["relu"] * 3, ecoef=[1.0] * 3, n_in=6, n_out=24, loss="bernoulli",
+                var=1.0, perc=0.5, B=40, seed=77, x0_range=2.0, calls=[dict(T=25)])
+    W, b, X0, inputs, target = make_case_inputs(case)
+    tgt = torch.from_numpy(target).to(DEV)
+    finals, overalls = {}, {}
+
+    def half_kick(t, _pc_trainer):                    # not a Langevin kick: rescales the noise after drawing it
+        for x in _pc_trainer.get_model_xs():
+            x.grad.normal_(0., 1.).mul_(0.5)
+        _pc_trainer.get_optimizer_x().step()
+
+    for key, cb, kw in (("tagged", um.random_step, {"var": 1.5}), ("own", _users_own_random_step, {"var": 1.5}), ("other", half_kick, {})):
+        model, lins = gen_golden.build_reference_model(pc, case, W, b, X0, device=DEV)
+        trainer = pc.PCTrainer(model, T=25, optimizer_x_fn=torch.optim.SGD, optimizer_x_kwargs={"lr": 0.03},
+                               update_p_at="never", plot_progress_at=[])
+        trainer.mcpc_seed = 99
+        pt._PHILOX_STEPS[0] = 700
+        torch.manual_seed(5)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            res = trainer.train_on_batch(inputs=torch.zeros(40, 6, device=DEV), loss_fn=um.bernoulli_fn,
+                                         loss_fn_kwargs={"_target": tgt, "_var": None}, callback_after_t=cb,
+                                         callback_after_t_kwargs=dict(kw, _pc_trainer=trainer), is_log_progress=False,
+                                         is_return_results_every_t=False, is_checking_after_callback_after_t=False)
+        slow = [w for w in caught if issubclass(w.category, RuntimeWarning) and "leaves the fused HIP loop" in str(w.message)]
+        if key == "other":
+            assert trainer.last_call_mode == "stepwise" and len(slow) == 1
+            assert "not the N(0, std) it drew" in str(slow[0].message)
+        else:
+            assert trainer.last_call_mode == "fused" and not slow
+        finals[key] = [x.detach().clone() for x in trainer.get_model_xs()]
+        overalls[key] = res["overall"]
+    for a, c in zip(finals["tagged"], finals["own"]):
+        assert torch.equal(a, c)
+    assert overalls["tagged"] == overalls["own"]
+    assert all(bool(torch.isfinite(x).all()) for x in finals["other"])
+    assert not torch.equal(finals["other"][1], finals["own"][1])
+
+
 def test_kat_linear_gaussian_posterior():
     """figure_2.py:29-79: prior x1~N(0.2,1), y = 2*x1 + N(0,1), y = 1  =>  posterior N(0.44, 0.2)."""
     import torch.nn as nn

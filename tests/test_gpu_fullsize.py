@@ -50,17 +50,30 @@ def test_full_size_subset_matches_oracle_and_energy_identity():
     W, b, y, xs = _problem()
     eng = _engine(B, W, b, y)
     T = 20
-    res, out = _run(eng, xs, T, acc_begin=5, acc_end=T)
+    res, out = _run(eng, xs, T, acc_begin=5, acc_end=T, rec_begin=0, rec_stride=1, rec_count=T, rec_x=True)
     en = res.energies.cpu().numpy()
     np.testing.assert_allclose(en[:, -1], en[:, 0] + en[:, 1:4].sum(1), rtol=1e-12)      # overall = loss + energies
     assert np.all(np.isfinite(en)) and np.all(en[:, 4:7] == 0)
-    # chains are independent: replay chains 4000..4031 on the oracle with the NumPy twin of the device noise
-    lo, n = 4000, 32
     Wn, bn = [w.cpu().numpy() for w in W], [x.cpu().numpy() for x in b]
     net = mo.NetSpec(sizes=SIZES, acts=[mo.ACT_RELU] * 3, W=Wn, b=bn)
+    # (1) the WHOLE batch on the oracle for the first 5 steps (NumPy twin of the device noise for all 6000 chains): per-step
+    #     loss, E_1..E_3 and overall as the reference records them (pc_trainer.py:776-797,821-836), rel 3e-5 (fp32 sums over
+    #     B*n terms in another order)
+    T5 = 5
+    ref5 = mo.run(net, np.zeros((B, 30), np.float32), [x.cpu().numpy() for x in xs], mo.LossSpec(mo.LOSS_BERNOULLI, y.cpu().numpy()),
+                  mo.XOpt(mo.OPT_SGD, 0.03), T5, noise=lambda t, l: philox.layer_normals(77, 1000 + t, l, 0, B, SIZES[l]))
+    np.testing.assert_allclose(en[:T5, 0], ref5.loss, rtol=3e-5)
+    np.testing.assert_allclose(en[:T5, 1:4], ref5.layer_energy, rtol=3e-5)
+    np.testing.assert_allclose(en[:T5, -1], ref5.overall, rtol=3e-5)
+    # (2) chains are independent: replay chains 4000..4031 on the oracle over all 20 steps and compare x_t at EVERY step
+    lo, n = 4000, 32
     ref = mo.run(net, np.zeros((n, 30), np.float32), [x[lo:lo + n].cpu().numpy() for x in xs],
                  mo.LossSpec(mo.LOSS_BERNOULLI, y[lo:lo + n].cpu().numpy()), mo.XOpt(mo.OPT_SGD, 0.03), T,
-                 noise=lambda t, l: philox.layer_normals(77, 1000 + t, l, lo, n, SIZES[l]))
+                 noise=lambda t, l: philox.layer_normals(77, 1000 + t, l, lo, n, SIZES[l]), record_at=range(T))
+    for t in range(T):
+        for l in range(3):
+            # x0 ~ U(-10, 10): values of O(10), fp32 GEMM sums in another order; the bound grows with the steps taken
+            np.testing.assert_allclose(res.rec_x[l][t, lo:lo + n].cpu().numpy(), ref.rec_xs[t][l], rtol=0, atol=1e-4 * (t + 1))
     for l in range(3):
         np.testing.assert_allclose(out[l][lo:lo + n].cpu().numpy(), ref.xs[l], rtol=0, atol=2e-3)
     eng.close()

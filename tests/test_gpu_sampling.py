@@ -1,0 +1,174 @@
+"""Distribution-level parity of the FUSED sampler: Philox4x32-10 + Box-Muller inside the x update against
+what the reference's `random_step` with torch's own `normal_` samples (/root/reference/utils/model.py:35-44).
+
+Trajectory parity always goes through injected normals (torch's CPU generator cannot be reproduced on a GPU), which cannot notice
+a fused generator whose normals are correlated between units / layers / steps / chains, or a mis-scaled kick.  Here:
+  * g13: stationary statistics (38-vector of means, full 38 x 38 covariance of the concatenated latents, mean loss / energies) of
+    6-16-16-24 tanh/Gaussian and ReLU/Bernoulli nets, 4096 chains x 2000 steps after 500 of burn-in, from the IMPORTED reference
+    for 12 torch seeds (oracle/gen_golden_sampling.py); the GPU run has to sit inside the reference's own seed-to-seed spread;
+  * Philox independence: sample correlations of the device generator's normals between consecutive steps, adjacent layers,
+    adjacent chains, adjacent units and adjacent 4-unit groups (one Philox call = 4 normals), 2^22 pairs each, |r| < 5 / sqrt(n);
+  * g14: `get_representations` (utils/model.py:71-163): MAP mode exactly, "expectation" inside the reference's seed spread.
+"""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.cases import make_case_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _z(got, ref):
+    """(got - mean of the reference seeds) in units of the spread a further seed would show; ref: [seeds, ...]."""
+    n = ref.shape[0]
+    return (got - ref.mean(0)) / (ref.std(0, ddof=1) * np.sqrt(1.0 + 1.0 / n))
+
+
+def _t_moments(nu):
+    """E[t^2], Var[t^2] of a Student t with nu degrees of freedom (nu > 4)."""
+    m2 = nu / (nu - 2.0)
+    m4 = 3.0 * nu * nu / ((nu - 2.0) * (nu - 4.0))
+    return m2, m4 - m2 * m2
+
+
+@pytest.mark.parametrize("name", ["tanh_gaussian", "relu_bernoulli"])
+def test_fused_sampler_sits_inside_the_reference_seed_spread(name):
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    g = np.load(os.path.join(GOLDEN, f"g13_sampling_moments_{name}.npz"))
+    case = json.loads(str(g["case_json"]))
+    burn, T, lr, nvar = int(g["burn"]), int(g["T"]), float(g["lr"]), float(g["noise_var"])
+    W, b, X0, inputs, target = make_case_inputs(case)
+    sizes, B = case["sizes"], case["B"]
+    act = {"tanh": L.ACT_TANH, "relu": L.ACT_RELU}[case["acts"][0]]
+    eng = Engine(sizes, [act] * 3, case["n_in"], case["n_out"], B, device=DEV)
+    eng.bind_params([torch.from_numpy(w).to(DEV) for w in W], [torch.from_numpy(v).to(DEV) for v in b])
+    eng.bind_inputs(None)
+    eng.bind_target(torch.from_numpy(target).to(DEV))
+    eng.load_state([torch.from_numpy(x).to(DEV) for x in X0])
+    kind = L.LOSS_GAUSSIAN if case["loss"] == "gaussian" else L.LOSS_BERNOULLI
+    res = eng.run(T, loss_kind=kind, loss_var=case["var"], xopt=L.XOPT_SGD, lr=lr, noise_mode=L.NOISE_PHILOX, noise_var=nvar,
+                  seed=20260104, step_base=0, energy_mode=L.ENERGY_ALL, rec_begin=burn, rec_stride=1, rec_count=T - burn, rec_x=True)
+    eng.sync_check()
+    x = torch.cat(res.rec_x, dim=2).double().reshape(-1, sum(sizes))           # [(T - burn) * B, 38]: x_t before the update of step t
+    mean = x.mean(0)
+    cov = (x.T @ x / x.shape[0] - torch.outer(mean, mean)).cpu().numpy()
+    mean = mean.cpu().numpy()
+    en = res.energies.cpu().numpy()[burn:]
+    energies = np.array([en[:, 0].mean(), en[:, 1:4].sum(1).mean(), en[:, -1].mean()])
+    eng.close()
+
+    n_seeds = g["mean"].shape[0]
+    m2, v2 = _t_moments(n_seeds - 1)
+    iu = np.triu_indices(cov.shape[0], k=1)
+    groups = {"means": _z(mean, g["mean"]),
+              "variances": _z(np.diag(cov), np.array([np.diag(c) for c in g["cov"]])),
+              "covariances": _z(cov[iu], np.array([c[iu] for c in g["cov"]])),
+              "energies": _z(energies, g["energies"])}
+    for key, z in groups.items():
+        # every entry inside 6 spreads of a further reference seed (Student t with 11 degrees of freedom: P(|t| > 6) = 9e-5) ...
+        assert np.abs(z).max() < 6.0, (key, float(np.abs(z).max()))
+        # ... and the group as a whole no further out than reference seeds are from each other
+        assert (z * z).mean() < m2 + 5.0 * np.sqrt(v2 / z.size), (key, float((z * z).mean()))
+    # in plain numbers: the stationary variances -- what a mis-scaled kick or correlated normals would move first -- within 2 % (6 spreads)
+    np.testing.assert_allclose(np.diag(cov), np.array([np.diag(c) for c in g["cov"]]).mean(0), rtol=2e-2)
+    np.testing.assert_allclose(energies, g["energies"].mean(0), rtol=2e-3)
+
+
+def _corr(a, b):
+    a = a.double().reshape(-1); b = b.double().reshape(-1)
+    a = a - a.mean(); b = b - b.mean()
+    return float((a * b).mean() / (a.std(unbiased=False) * b.std(unbiased=False)))
+
+
+def test_philox_normals_are_independent_across_steps_layers_chains_and_units():
+    """Counter = (global chain, layer << 24 | unit / 4, step_lo, step_hi), key = seed: neighbouring counters must give
+    uncorrelated normals, and so must the four normals of one call (two Box-Muller pairs), also in their squares."""
+    from montecarlopredictivecoding_amd.engine import philox_normals
+    B, N = 4096, 1024                                        # 2^22 normals per (step, layer)
+    n = B * N
+    bound = 5.0 / np.sqrt(n)
+    a = philox_normals(99, 1000, 0, 0, B, N, DEV)
+    assert abs(float(a.mean())) < 5.0 / np.sqrt(n) and abs(float(a.double().var()) - 1.0) < 5.0 * np.sqrt(2.0 / n)
+    assert abs(float((a.double() ** 4).mean()) - 3.0) < 5.0 * np.sqrt(96.0 / n)
+    pairs = {
+        "step t / t+1": (a, philox_normals(99, 1001, 0, 0, B, N, DEV)),
+        "layer l / l+1": (a, philox_normals(99, 1000, 1, 0, B, N, DEV)),
+        "seed / seed+1": (a, philox_normals(100, 1000, 0, 0, B, N, DEV)),
+        "chain c / c+1": (a[:-1], a[1:]),
+        "unit u / u+1": (a[:, :-1], a[:, 1:]),
+        "unit group g / g+1": (a[:, :-4], a[:, 4:]),
+        "step across 2^32": (philox_normals(99, (1 << 32) - 1, 0, 0, B, N, DEV), philox_normals(99, 1 << 32, 0, 0, B, N, DEV)),
+    }
+    for key, (p, q) in pairs.items():
+        assert abs(_corr(p, q)) < bound * np.sqrt(n / p.numel()), key
+        assert abs(_corr(p * p, q * q)) < bound * np.sqrt(n / p.numel()), key + " (squares)"
+    # within one Philox call: units 4g .. 4g+3 (cos / sin partners share a radius but are independent)
+    quad = a.reshape(B, N // 4, 4)
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert abs(_corr(quad[..., i], quad[..., j])) < 5.0 / np.sqrt(n / 4), (i, j)
+            assert abs(_corr(quad[..., i] ** 2, quad[..., j] ** 2)) < 5.0 / np.sqrt(n / 4), (i, j, "squares")
+    # a shard that starts at chain 2048 draws exactly the normals rows 2048.. of the unsharded job draw
+    assert torch.equal(philox_normals(99, 1000, 0, 2048, 2048, N, DEV), a[2048:])
+
+
+def _g14_setup():
+    import montecarlopredictivecoding_amd.utils.model as um
+    from montecarlopredictivecoding_amd.utils.training_evaluation import get_mcpc_trainer, get_pc_trainer
+    from torch.utils.data import DataLoader, TensorDataset
+    g = np.load(os.path.join(GOLDEN, "g14_representations.npz"))
+    meta = json.loads(str(g["meta_json"]))
+    cfg = dict(meta["shape"], activation_fn="relu", loss_fn=um.bernoulli_fn, input_var=None, T_pc=meta["T_pc"],
+               optimizer_x_fn_pc=torch.optim.Adam, optimizer_x_kwargs_pc={"lr": meta["lr_pc"]}, mixing=meta["mixing"],
+               sampling=meta["sampling"], optimizer_x_kwargs_mcpc={"lr": meta["lr_mcpc"]})
+    model = um.get_model(cfg, True, sample_x_fn=um.sample_x_fn_cte)
+    lins = [m for m in model if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        for j, lin in enumerate(lins):
+            lin.weight.copy_(torch.from_numpy(g[f"W{j}"])); lin.bias.copy_(torch.from_numpy(g[f"b{j}"]))
+    loader = DataLoader(TensorDataset(torch.from_numpy(g["data"]), torch.from_numpy(g["labels"])), batch_size=meta["batch_size"])
+    return um, g, meta, cfg, model, loader, get_pc_trainer(model, cfg, is_mcpc=True, training=False), get_mcpc_trainer(model, cfg, training=False)
+
+
+def test_get_representations_map_mode_matches_reference():
+    um, g, meta, cfg, model, loader, pc_tr, mc_tr = _g14_setup()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ds = um.get_representations(model, cfg, [pc_tr], loader, rep_type="MAP", use_cuda=True)
+    assert pc_tr.last_call_mode == "fused"
+    assert np.array_equal(ds.tensors[1].cpu().numpy(), g["map_labels"])
+    # 60 Adam steps (v_sqrt / v_rcp in the direction: 1 ulp each) from x0 = 3: x_1 per datapoint
+    np.testing.assert_allclose(ds.tensors[0].cpu().numpy(), g["map_reps"], rtol=0, atol=3e-4)
+
+
+def test_get_representations_expectation_and_full_modes_match_reference_statistics():
+    um, g, meta, cfg, model, loader, pc_tr, mc_tr = _g14_setup()
+    torch.manual_seed(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ds = um.get_representations(model, cfg, [pc_tr, mc_tr], loader, rep_type="expectation", use_cuda=True)
+        full = um.get_representations(model, cfg, [pc_tr, mc_tr], loader, rep_type="full", use_cuda=True, n=meta["n_full"])
+    assert mc_tr.last_call_mode == "fused"
+    assert np.array_equal(ds.tensors[1].cpu().numpy(), g["expectation_labels"])
+    ref = g["expectation_reps"]                                     # [12 seeds, 48 datapoints, 8 units]: one chain each, mean of 500 steps
+    z = _z(ds.tensors[0].cpu().numpy(), ref)
+    m2, v2 = _t_moments(ref.shape[0] - 1)
+    assert np.abs(z).max() < 6.0, float(np.abs(z).max())
+    assert (z * z).mean() < m2 + 5.0 * np.sqrt(v2 / z.size), float((z * z).mean())
+    # the reference's expectation differs from its MAP estimate by much more than its seed spread allows the GPU to differ from it:
+    # the check can tell a sampler from a mode finder
+    assert np.abs(ref.mean(0) - g["map_reps"]).mean() > 0.1
+    # "full": every 40th sample after the mixing phase, n = 10 per datapoint, batch-major blocks of [n * 16] as the reference lays them out
+    assert tuple(full.tensors[0].shape) == tuple(g["full_reps"].shape) and np.array_equal(full.tensors[1].cpu().numpy(), g["full_labels"])
+    got = full.tensors[0].cpu().numpy().reshape(3, meta["n_full"], 16, 8).mean(1).reshape(48, 8)      # mean of the 10 kept samples per datapoint
+    # 10 well-separated samples of a chain whose 500-step mean has spread s: their mean is within a few s / sqrt(10 / 500 * tau) of it;
+    # loose sanity only -- the layout (labels, shapes) is what this mode adds
+    assert np.isfinite(got).all() and np.abs(got - ref.mean(0)).mean() < 1.0

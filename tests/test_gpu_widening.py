@@ -254,3 +254,36 @@ def test_long_trajectories_are_recorded_in_slices_through_a_device_ring():
         assert torch.equal(p, q)
     for p, q in zip(ga, gb):                                          # Hebbian sums: one flush per slice regroups the fp32 sums
         assert torch.allclose(p, q, rtol=1e-5, atol=1e-5 * float(p.abs().max()))
+
+
+def test_outputs_of_a_model_without_read_out_stay_on_the_device_when_sliced():
+    """with no read-out Linear `outputs` is the last latent layer (pc_trainer.py:733: the Sequential's output); the
+    sliced recorder drains latent records to pinned HOST memory, but `results["outputs"]` are live device tensors in the
+    reference and on the unsliced path -- their device must not depend on mcpc_record_chunk_bytes."""
+    import montecarlopredictivecoding_amd.predictive_coding as pc
+    import montecarlopredictivecoding_amd.predictive_coding.pc_trainer as pt
+    import montecarlopredictivecoding_amd.utils.model as um
+    torch.manual_seed(2)
+    model = torch.nn.Sequential(torch.nn.Linear(4, 4), pc.PCLayer(), torch.nn.Tanh(), torch.nn.Linear(4, 12),
+                                pc.PCLayer(energy_fn=lambda inputs: 2.0 * 0.5 * (inputs["mu"] - inputs["x"]) ** 2)).to(DEV)
+    model.train()
+    outs = []
+    for chunk in (1 << 30, 8 * 16 * 4 * 6):
+        tr = pc.PCTrainer(model, T=30, optimizer_x_fn=torch.optim.SGD, optimizer_x_kwargs={"lr": 0.05}, update_p_at="never", plot_progress_at=[])
+        tr.mcpc_record_chunk_bytes = chunk
+        base = pt._PHILOX_STEPS[0]
+        torch.manual_seed(9)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = tr.train_on_batch(inputs=torch.zeros(8, 4, device=DEV), callback_after_t=um.random_step,
+                                  callback_after_t_kwargs={"_pc_trainer": tr}, is_log_progress=False, is_return_results_every_t=True,
+                                  is_return_outputs=True, is_return_xs=True)
+        pt._PHILOX_STEPS[0] = base
+        assert tr.last_call_mode == "fused"
+        outs.append((r, tr.last_record_slices))
+    (ra, sa), (rb, sb) = outs
+    assert sa == 0 and sb > 1
+    assert len(ra["outputs"]) == len(rb["outputs"]) == 30
+    for p, q in zip(ra["outputs"], rb["outputs"]):
+        assert p.is_cuda and q.is_cuda and torch.equal(p, q)
+    assert not rb["xs"][0][0].is_cuda and torch.equal(rb["xs"][5][1].to(DEV), rb["outputs"][5])

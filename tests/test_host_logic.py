@@ -180,3 +180,62 @@ def test_random_step_torch_body_matches_reference_arithmetic():
     torch.manual_seed(0)
     um.random_step(0, T_(), var=2.0)
     assert abs(float(x.std()) - np.sqrt(2.0 * 0.05)) < 0.01 and abs(float(x.mean())) < 0.01
+
+
+def _reference_random_step(t, _pc_trainer, var=2.):
+    """A user's own copy of the reference's Langevin callback (utils/model.py:35-44), verbatim in behaviour: untagged, defined
+    outside this package -- what a script that keeps its own utils/model.py passes as callback_after_t."""
+    xs = _pc_trainer.get_model_xs()
+    optimizer = _pc_trainer.get_optimizer_x()
+    for x in xs:
+        x.grad.normal_(0., np.sqrt(var / optimizer.defaults['lr']))
+    optimizer.step()
+
+
+def test_untagged_reference_random_step_is_recognised_by_behaviour():
+    m = um.get_model(CFG, False)
+    tr = get_mcpc_trainer(m, CFG, training=False)
+    assert not hasattr(_reference_random_step, "_mcpc")
+    torch.manual_seed(11); np.random.seed(12)
+    want = (torch.rand(4), np.random.rand(3))
+    torch.manual_seed(11); np.random.seed(12)
+    assert recognise.describe_callback(_reference_random_step, {"_pc_trainer": tr}, tr) == (2.0, "")
+    assert recognise.describe_callback(_reference_random_step, {"_pc_trainer": tr, "var": 0.7}, tr) == (0.7, "")
+    # the probe consumed nothing of the script's seeded generators
+    assert torch.equal(torch.rand(4), want[0]) and np.array_equal(np.random.rand(3), want[1])
+    # and the trainer's own latents / optimizer were never touched (none exist yet)
+    assert tr.get_optimizer_x() is None
+
+    def twice(t, _pc_trainer):
+        _reference_random_step(t, _pc_trainer); _pc_trainer.get_optimizer_x().step()
+
+    def uniform(t, _pc_trainer):
+        for x in _pc_trainer.get_model_xs():
+            x.grad.uniform_(-1, 1)
+        _pc_trainer.get_optimizer_x().step()
+
+    def rescaled(t, _pc_trainer):
+        for x in _pc_trainer.get_model_xs():
+            x.grad.normal_(0., 1.).mul_(3.)
+        _pc_trainer.get_optimizer_x().step()
+
+    def annealed(t, _pc_trainer):
+        for x in _pc_trainer.get_model_xs():
+            x.grad.normal_(0., 1. + t)
+        _pc_trainer.get_optimizer_x().step()
+
+    def writes_x(t, _pc_trainer):
+        for x in _pc_trainer.get_model_xs():
+            x.data.add_(1.0)
+        _reference_random_step(t, _pc_trainer)
+
+    def wants_model(t, _pc_trainer):
+        _pc_trainer.get_model().eval()
+
+    for fn, word in ((twice, "2 times"), (uniform, "normal_"), (rescaled, "not the N(0, std) it drew"), (annealed, "differs"),
+                     (writes_x, "x values"), (wants_model, "get_model")):
+        var, why = recognise.describe_callback(fn, {"_pc_trainer": tr}, tr)
+        assert var is None and word in why, (fn.__name__, why)
+    other = get_mcpc_trainer(m, CFG, training=False)
+    assert recognise.describe_callback(_reference_random_step, {"_pc_trainer": other}, tr)[0] is None     # bound to another trainer
+    assert recognise.describe_callback(lambda t: None, {}, tr)[0] is None                                  # a closure: cannot be probed
