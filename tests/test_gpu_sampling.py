@@ -73,8 +73,11 @@ def test_fused_sampler_sits_inside_the_reference_seed_spread(name):
               "covariances": _z(cov[iu], np.array([c[iu] for c in g["cov"]])),
               "energies": _z(energies, g["energies"])}
     for key, z in groups.items():
-        # every entry inside 6 spreads of a further reference seed (Student t with 11 degrees of freedom: P(|t| > 6) = 9e-5) ...
-        assert np.abs(z).max() < 6.0, (key, float(np.abs(z).max()))
+        # every entry inside 8 spreads of a further reference seed.  (The spread of an entry is itself estimated from 12 seeds:
+        # Student t with 11 degrees of freedom, P(|t| > 8) = 6e-6 per entry, 703 covariance entries.  Leaving one REFERENCE seed out
+        # and scoring it against the other 11 gives max |z| of 4.0 .. 6.0 over the 12 seeds; six GPU seeds gave 3.7 .. 6.9, their
+        # largest entries all different ones, mean z^2 1.06 .. 1.38 -- scripts/sampling_probe.py.)
+        assert np.abs(z).max() < 8.0, (key, float(np.abs(z).max()))
         # ... and the group as a whole no further out than reference seeds are from each other
         assert (z * z).mean() < m2 + 5.0 * np.sqrt(v2 / z.size), (key, float((z * z).mean()))
     # in plain numbers: the stationary variances -- what a mis-scaled kick or correlated normals would move first -- within 2 % (6 spreads)
@@ -161,7 +164,7 @@ def test_get_representations_expectation_and_full_modes_match_reference_statisti
     ref = g["expectation_reps"]                                     # [12 seeds, 48 datapoints, 8 units]: one chain each, mean of 500 steps
     z = _z(ds.tensors[0].cpu().numpy(), ref)
     m2, v2 = _t_moments(ref.shape[0] - 1)
-    assert np.abs(z).max() < 6.0, float(np.abs(z).max())
+    assert np.abs(z).max() < 8.0, float(np.abs(z).max())
     assert (z * z).mean() < m2 + 5.0 * np.sqrt(v2 / z.size), float((z * z).mean())
     # the reference's expectation differs from its MAP estimate by much more than its seed spread allows the GPU to differ from it:
     # the check can tell a sampler from a mode finder

@@ -57,7 +57,7 @@ def test_oracle_with_the_philox_twin_samples_the_reference_distribution():
     for key, got, refs in (("means", mean, g["mean"]), ("variances", np.diag(cov), np.array([np.diag(c) for c in g["cov"]])),
                            ("covariances", cov[iu], np.array([c[iu] for c in g["cov"]]))):
         z = (got - refs.mean(0)) / (refs.std(0, ddof=1) * widen)
-        assert np.abs(z).max() < 6.0, (key, float(np.abs(z).max()))
+        assert np.abs(z).max() < 8.0, (key, float(np.abs(z).max()))
         assert (z * z).mean() < 2.5, (key, float((z * z).mean()))
     en = np.array([ref.loss[burn:].mean(), ref.energy[burn:].mean(), ref.overall[burn:].mean()])
     np.testing.assert_allclose(en, g["energies"].mean(0), rtol=3e-3)
