@@ -80,6 +80,7 @@ struct Knobs {
     int stagger = 0;          // barrier kernel: start cycles of the second workgroup of a CU
     int no_lean = 0;          // 1: the in-place kernel's E waves use the generic epilogues everywhere (A/B, parity tests)
     int no_ybits = 0;         // 1: 0/1 targets are read as fp32 like any other target (A/B, parity tests)
+    int overlay16 = 0;        // 1: 16-chain plans share the LDS of the ring and the E_l like 32-chain plans do (A/B, parity tests)
 };
 
 int parse_tuning(const char* str, Knobs& k) {
@@ -100,7 +101,7 @@ int parse_tuning(const char* str, Knobs& k) {
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
             {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"mix_pmax", &k.mix_pmax}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
-            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}};
+            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}};
         bool found = false;
         for (auto& t : table)
             if (key == t.name) { *t.dst = val; found = true; }
@@ -128,6 +129,8 @@ struct mcpc_engine {
     int nw = kWaves;                // waves per workgroup: 4, or 8 with 32 chains (two waves per SIMD, one workgroup per CU)
     int ws = 0;                     // 1: wave-specialised kernel with staging slots; 2: in-place variant (4 GEMM + 4 epilogue waves, 32 chains)
     int ws2_chunk = 0, ws2_ring = 0; // in-place variant: read-out tiles per chunk, chunks in the LDS ring
+    bool ws2_overlay = true;        // the ring of read-out error chunks shares LDS with E_1 .. E_{L-1} (32-chain plans); 16-chain plans that fit
+                                    // keep them apart, which frees the order of the forward entries (build_phases_ws2)
     int lds_ws_sync = 0;
     int npad[kMaxLatent]{};
     int out_pad = 0;
@@ -318,17 +321,20 @@ int plan_lds_ws2(mcpc_engine* e) {
     e->lds_e[0] = 0;
     e->lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
     e->lds_ws_sync = off; off += 16;
-    // shared region: E_1 .. E_{L-1} stacked | ring
+    // E_1 .. E_{L-1} stacked; the ring of read-out error chunks behind them when both fit (16-chain workgroups: the forward
+    // entries are then free to run between the read-out chunks), else on top of them (shared region)
     int e_sum = 0;
     for (int l = 1; l < L; ++l) { e->lds_e[l] = off + e_sum; e_sum += CT * (e->npad[l] + kLdPad); }
     e->lds_eo = off;
-    e->ws2_chunk = 0; e->ws2_ring = 0;
+    e->ws2_chunk = 0; e->ws2_ring = 0; e->ws2_overlay = true;
     int ring_floats = 0;
     if (e->has_head) {
         // fewest chunks of at most 16 tiles whose ring of two still fits; chunks equalised; ring of three if that fits too
         const int ht = std::max(e->out_pad / 16, 1);
         const int span = kWs2Pairs * (CT == 16 ? ws2_nt<1>() : ws2_nt<2>());     // tiles a table entry hands out
-        auto fits = [&](int hc, int nb) { return (off + std::max(nb * CT * (hc * 16 + kLdPad), e_sum)) * (int)sizeof(float) <= 160 * 1024; };
+        auto ring_of = [&](int hc, int nb) { return nb * CT * (hc * 16 + kLdPad); };
+        auto fits = [&](int hc, int nb) { return (off + std::max(ring_of(hc, nb), e_sum)) * (int)sizeof(float) <= 160 * 1024; };
+        auto fits_apart = [&](int hc, int nb) { return (off + ring_of(hc, nb) + e_sum) * (int)sizeof(float) <= 160 * 1024; };
         int hc_fit = 0;
         for (int hc = std::min(span, ht); hc >= 1; --hc)
             if (fits(hc, 2)) { hc_fit = hc; break; }
@@ -336,9 +342,10 @@ int plan_lds_ws2(mcpc_engine* e) {
         const int nch = (ht + hc_fit - 1) / hc_fit;
         const int hc = (ht + nch - 1) / nch;                 // equalised: the widest chunk of the split
         const int nb = (nch >= 3 && fits(hc, 3)) ? 3 : 2;
-        e->ws2_chunk = hc; e->ws2_ring = nb; ring_floats = nb * CT * (hc * 16 + kLdPad);
+        e->ws2_chunk = hc; e->ws2_ring = nb; ring_floats = ring_of(hc, nb);
+        if (CT == 16 && L >= 2 && fits_apart(hc, nb) && !e->knobs.overlay16) { e->ws2_overlay = false; e->lds_eo = off + e_sum; }
     }
-    off += std::max(ring_floats, e_sum);
+    off += e->ws2_overlay ? std::max(ring_floats, e_sum) : ring_floats + e_sum;
     e->lds_bytes = off * (int)sizeof(float);
     if (e->lds_bytes > 160 * 1024) return fail(MCPC_ENOMEM, "in-place schedule does not fit the LDS (%d bytes)", e->lds_bytes);
     return 0;
@@ -359,6 +366,14 @@ int plan_lds_ws2(mcpc_engine* e) {
 // The others are implied: a G wave that stores into FX_l has just waited for epilogues that can only have run after every
 // G wave finished the GEMMs that read the old contents (the BWD_{L-1} hand-off after HB(last) <- HF(last) epilogues, BWD_l
 // after the FWD_{l+1} epilogues, which follow FWD_{l+1}'s GEMM over FX_l).
+//
+// 16-chain plans whose LDS holds the ring AND the E_l side by side (plan_lds_ws2: ws2_overlay == false) order a step differently:
+//   read-out:  HF(0) .. HF(R-1) HB(0) FWD_1 HF(R) HB(1) FWD_0 HB(2) FWD_2 ...   (every forward entry fills a gap of the read-out)
+//   updates:   as above.
+// With 16 chains a GEMM is half as long, the epilogues are not, and the shared region cost twice: HF(0) / HF(1) waited for the LAST
+// epilogue of the previous step (their slots overlapped the E_l it reads) and the forward GEMMs sat behind the read-out where
+// nothing hid their epilogues.  Apart, HF(c < R) needs no write-after-read wait at all, and FWD_l waits -- behind its GEMM -- for
+// the previous step's readers of E_l: dep_g <- last back-projection GEMM, dep_se <- last BWD entry.
 int build_phases_ws2(mcpc_engine* e) {
     const int L = e->L;
     const int span = kWs2Pairs * (e->ct == 16 ? ws2_nt<1>() : ws2_nt<2>());     // tiles per table entry: 16 (32-chain workgroups) or 32 (16-chain)
@@ -376,14 +391,27 @@ int build_phases_ws2(mcpc_engine* e) {
                 k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
                 k.out_lds = e->lds_e[l]; k.out_ld = e->npad[l] + kLdPad;
                 k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_BWD - (l - 1);
-                if (e->has_head) k.dep_g = REF_LAST_HB;       // E_l shares LDS with the ring
+                if (e->has_head && e->ws2_overlay) k.dep_g = REF_LAST_HB;       // E_l shares LDS with the ring
+                else if (e->has_head) {
+                    // E_l has rows of its own and the entry runs between the read-out chunks: what still reads the OLD E_l are
+                    // the previous step's back-projection GEMMs (all G waves: E_l is a B operand) and x updates (E waves)
+                    k.dep_g = REF_LAST_BWD_GEMM; k.dep_se = REF_LAST_BWD_ANY;
+                }
             }
             out.push_back(k);
         }
     };
     // FWD_0 has no GEMM and no LDS output: it fills a gap of the read-out; the others follow the read-out
     std::vector<KPhase> fill, after;
-    for (int l = L - 1; l >= 0; --l) fwd_entries(l, (l >= 1 && e->has_head) ? after : fill);
+    if (e->has_head && !e->ws2_overlay) {
+        // every forward entry fills a gap of the read-out, in the order their inputs become ready: the previous step ends with
+        // the x updates BWD_{L-1}, BWD_0, BWD_1 ... BWD_{L-2}, so FWD_1 (needs f(x_0)) first, FWD_0 (no GEMM), then FWD_2 ... FWD_{L-1}
+        if (L >= 2) fwd_entries(1, fill);
+        fwd_entries(0, fill);
+        for (int l = 2; l < L; ++l) fwd_entries(l, fill);
+    } else {
+        for (int l = L - 1; l >= 0; --l) fwd_entries(l, (l >= 1 && e->has_head) ? after : fill);
+    }
     std::vector<KPhase> ph;
     size_t nf = 0;
     if (e->has_head) {
@@ -404,7 +432,7 @@ int build_phases_ws2(mcpc_engine* e) {
             f.out_lds = e->lds_eo + (c % R) * chunk_floats; f.out_ld = hc * 16 + kLdPad;
             f.flags = PHF_WS_GEMM | PHF_WS_EPI; f.dep_e = REF_LAST_BWD - (L - 1);
             if (c >= R) f.dep_g = idx_b[c - R];
-            else if ((c % R) * chunk_floats < e_sum) { f.dep_g = REF_LAST_BWD_GEMM; f.dep_se = REF_LAST_BWD_ANY; }   // slot overlaps the E_l
+            else if (e->ws2_overlay && (c % R) * chunk_floats < e_sum) { f.dep_g = REF_LAST_BWD_GEMM; f.dep_se = REF_LAST_BWD_ANY; }   // slot overlaps the E_l
             idx_f[c] = (int)ph.size(); ph.push_back(f);
         };
         auto add_b = [&](int c) {
@@ -577,6 +605,7 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
     keep.lds_eo = e->lds_eo; keep.lds_red = e->lds_red; keep.lds_ws_sync = e->lds_ws_sync; keep.lds_bytes = e->lds_bytes;
     keep.n_phases = e->n_phases; keep.phases = e->phases;
     const int k_chunk = e->ws2_chunk, k_ring = e->ws2_ring;
+    const bool k_overlay = e->ws2_overlay;
     e->ct = 16; e->phases = nullptr;
     int rc = plan_lds_ws2(e);
     if (!rc) rc = build_phases_ws2(e);
@@ -590,7 +619,7 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
     std::copy(keep.lds_a, keep.lds_a + kMaxLatent, e->lds_a); std::copy(keep.lds_e, keep.lds_e + kMaxLatent, e->lds_e);
     e->lds_eo = keep.lds_eo; e->lds_red = keep.lds_red; e->lds_ws_sync = keep.lds_ws_sync; e->lds_bytes = keep.lds_bytes;
     e->n_phases = keep.n_phases; e->phases = keep.phases;
-    e->ws2_chunk = k_chunk; e->ws2_ring = k_ring;
+    e->ws2_chunk = k_chunk; e->ws2_ring = k_ring; e->ws2_overlay = k_overlay;
     if (rc) { g_err.clear(); return 0; }                     // no 16-chain plan: plain schedule only
     if (hipFuncSetAttribute((const void*)mcpc_steps_ws2_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(e->lds_bytes, a.lds_bytes)) != hipSuccess)
         return fail(MCPC_EHIP, "hipFuncSetAttribute failed for the mixed schedule");
@@ -935,7 +964,7 @@ HebPlan plan_hebbian(const mcpc_engine* e, int ne, int na, int rows) {
 
 template <int TE, int RA, bool SW = false>
 int launch_heb(const HebArgs& a, hipStream_t stream) {
-    constexpr int lds_bytes = 2 * kHebKB * 16 * (TE + 8 * RA) * (int)sizeof(float);
+    constexpr int lds_bytes = 2 * kHebKB * (heb_lds_stride(16 * TE) + heb_lds_stride(16 * 8 * RA)) * (int)sizeof(float);
     static bool attr_set[16] = {false};      // per device
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -39,6 +39,11 @@ struct HebArgs {
                                    // within 0.2 us per step of itself with any of them (scripts/lib_ab.sh), so the reads are not what
                                    // costs the step kernel beside it its L2 hits (0.82 against 0.95-0.99 without a flush)
 #endif
+#ifndef MCPC_HEB_LDS_PAD
+#define MCPC_HEB_LDS_PAD 16        // floats added to a 256-float panel row in LDS (0: the linear image of round 2, for A/B runs)
+#endif
+constexpr int heb_lds_stride(int row_floats) { return row_floats == 256 ? row_floats + MCPC_HEB_LDS_PAD : row_floats; }
+
 __device__ __forceinline__ void heb_glds16(const float* gsrc, float* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, MCPC_HEB_LD_AUX);
@@ -51,11 +56,17 @@ template <int TE, int RA, bool SWAPPED = false>
 __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs P) {
     constexpr int TA = 8 * RA;
     constexpr int LDE = 16 * TE, LDA = 16 * TA;               // panel row lengths (floats)
+    // LDS row strides.  An MFMA operand is one ds_read_b32 at [4 ks + lane / 16][16 t + lane % 16]: banks are (a / 4) mod 32 and
+    // lanes 0-31 (k-rows kq = 0, 1) are served together, so a row stride that is a multiple of 32 floats puts both k-rows on the
+    // same 16 banks (2-way conflict on every read: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.47 for <16, 2>, 0.08 for <17, 2>
+    // whose 272-float E rows are clear of it by themselves).  A panel whose row is exactly one 1 KiB LDS-DMA piece (256 floats)
+    // can be spread: piece r lands at r * (256 + 16) floats.  (Rows of 128 floats share a piece with their neighbour and stay.)
+    constexpr int LDE_S = heb_lds_stride(LDE), LDA_S = heb_lds_stride(LDA);
     constexpr int E_PIECES = kHebKB * LDE / 256;               // 1 KiB pieces per stage
     constexpr int A_PIECES = kHebKB * LDA / 256;
     constexpr int PIECES = E_PIECES + A_PIECES;
     constexpr int PPW = (PIECES + 7) / 8;                      // pieces per wave
-    constexpr int STAGE = kHebKB * (LDE + LDA);                // floats per stage
+    constexpr int STAGE = kHebKB * (LDE_S + LDA_S);            // floats per stage
     static_assert(kHebKB * LDE % 256 == 0 && kHebKB * LDA % 256 == 0, "panels must be whole 1 KiB pieces");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -94,7 +105,9 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
         p_is_a[k] = is_a;
         p_on[k] = p < PIECES && gcol < (is_a ? P.na : P.ne);
         g_off[k] = row * (is_a ? P.na : P.ne) + gcol;
-        l_off[k] = (is_a ? kHebKB * LDE + (p - E_PIECES) * 256 : p * 256);
+        // (one piece per row when the row stride is padded; otherwise the panel is one linear image)
+        l_off[k] = is_a ? kHebKB * LDE_S + (LDA_S != LDA ? (p - E_PIECES) * LDA_S : (p - E_PIECES) * 256)
+                        : (LDE_S != LDE ? p * LDE_S : p * 256);
     }
     auto issue_stage = [&](int s, int buf) {
         const size_t rbase = (size_t)(r0 + s * kHebKB);
@@ -117,8 +130,8 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
 
     if (n_stage > 0) issue_stage(0, 0);
     __syncthreads();                                          // (drains the DMA: hipcc waits vmcnt(0) in front of the barrier)
-    const int e_rd = kq * LDE + m;                            // lane's operand offset inside a k-step's four rows
-    const int a_rd = kHebKB * LDE + kq * LDA + 16 * RA * w + m;
+    const int e_rd = kq * LDE_S + m;                          // lane's operand offset inside a k-step's four rows
+    const int a_rd = kHebKB * LDE_S + kq * LDA_S + 16 * RA * w + m;
     for (int s = 0; s < n_stage; ++s) {
         const int buf = s & 1;
         if (s + 1 < n_stage) issue_stage(s + 1, buf ^ 1);
@@ -127,8 +140,8 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
         float eA[TE], aA[RA], eB[TE], aB[RA];
 #define HEB_LOAD(e_, a_, ks_)                                                                   \
         do {                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < TE; ++i) e_[i] = Ep[(ks_) * 4 * LDE + 16 * i]; \
-            _Pragma("unroll") for (int j = 0; j < RA; ++j) a_[j] = Ap[(ks_) * 4 * LDA + 16 * j]; \
+            _Pragma("unroll") for (int i = 0; i < TE; ++i) e_[i] = Ep[(ks_) * 4 * LDE_S + 16 * i]; \
+            _Pragma("unroll") for (int j = 0; j < RA; ++j) a_[j] = Ap[(ks_) * 4 * LDA_S + 16 * j]; \
         } while (0)
 #define HEB_MFMA(e_, a_)                                                                        \
         do {                                                                                    \
@@ -151,9 +164,9 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
 #undef HEB_LOAD
 #undef HEB_MFMA
         if (does_bias) {
-            const float* col = lds + buf * STAGE + (SWAPPED ? kHebKB * LDE : 0) + tid;
+            const float* col = lds + buf * STAGE + (SWAPPED ? kHebKB * LDE_S : 0) + tid;
 #pragma unroll 8
-            for (int r = 0; r < kHebKB; ++r) bsum += col[r * (SWAPPED ? LDA : LDE)];
+            for (int r = 0; r < kHebKB; ++r) bsum += col[r * (SWAPPED ? LDA_S : LDE_S)];
         }
         __syncthreads();      // stage s+1 has landed (vmcnt(0) in front of the barrier); every wave is done with stage s
     }

@@ -32,14 +32,24 @@ __device__ __forceinline__ void ws_st(int* p, int v) { __hip_atomic_store(p, v, 
 
 // wait until a counter is >= need; a spin that runs out records the fact in *err (host: mcpc_sync_check)
 // (a wave whose wait ran out once stops waiting altogether -- `dead` -- so a broken schedule drains in about one
-// spin limit instead of one per remaining table entry)
+// spin limit instead of one per remaining table entry).
+// Shape matters here: a wait that is already satisfied -- most are -- must cost one LDS round trip and a compare.  Written as
+// one `for` loop with the limit and the `dead` flag folded into its bounds, hipcc unrolled the poll eight times and chained
+// ~60 scalar instructions behind it to reconstruct the spin count (~450 cycles per SATISFIED wait, three or four of them per
+// table entry and pair): the satisfied case is now tested first, the polling loop is a cold, non-unrolled block.
 __device__ __forceinline__ void ws_wait_one(const int* p, int need, int* err, int& dead) {
-    int spin = dead ? kWsSpinLimit : 0;
-    for (; spin < kWsSpinLimit; ++spin) {
-        if (ws_ld(p) >= need) break;
-        if (MCPC_WS_SLEEP > 0) __builtin_amdgcn_s_sleep(MCPC_WS_SLEEP);
+    if (__builtin_expect(ws_ld(p) < need, 0)) {
+        if (!dead) {
+            int spin = 0;
+            bool ok = false;
+#pragma clang loop unroll(disable)
+            do {
+                if (MCPC_WS_SLEEP > 0) __builtin_amdgcn_s_sleep(MCPC_WS_SLEEP);
+                ok = ws_ld(p) >= need;
+            } while (!ok && ++spin < kWsSpinLimit);
+            if (!ok) { if ((threadIdx.x & 63) == 0) atomicOr(err, 2); dead = 1; }
+        }
     }
-    if (spin == kWsSpinLimit) { if (!dead && (threadIdx.x & 63) == 0) atomicOr(err, 2); dead = 1; }
     MCPC_WS_FENCE(__ATOMIC_ACQUIRE);
 }
 __device__ __forceinline__ void ws_publish(int* p, int v) {

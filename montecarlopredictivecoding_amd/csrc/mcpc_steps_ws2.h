@@ -74,22 +74,38 @@ static_assert(kWs2Pairs == 4 || kWs2Pairs == 8, "4 or 8 pairs");
 #define STAMP(i) do {} while (0)
 #endif
 
-struct Ws2Sync {
+struct alignas(16) Ws2Sync {
     int prog_e[kWs2Pairs];
     int prog_g[kWs2Pairs];
 };
 
-// wait until all kWs2Pairs counters are >= need (see ws_wait_all)
-__device__ __forceinline__ void ws2_wait_all(const int* p, int need, int* err, int& dead) {
-    int spin = dead ? kWsSpinLimit : 0;
-    for (; spin < kWsSpinLimit; ++spin) {
+// wait until all kWs2Pairs counters are >= need (shape: see ws_wait_one).  The four counters of a role are one aligned 16-byte
+// row of Ws2Sync: one ds_read_b128 per poll.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int ws2_min_all(const int* p) {
+    if constexpr (kWs2Pairs == 4) {
+        const i32x4_t v = *reinterpret_cast<const volatile i32x4_t*>(p);
+        return min(min(v.x, v.y), min(v.z, v.w));
+    } else {
         int m = ws_ld(p);
 #pragma unroll
         for (int i = 1; i < kWs2Pairs; ++i) m = min(m, ws_ld(p + i));
-        if (m >= need) break;
-        if (MCPC_WS_SLEEP > 0) __builtin_amdgcn_s_sleep(MCPC_WS_SLEEP);
+        return m;
     }
-    if (spin == kWsSpinLimit) { if (!dead && (threadIdx.x & 63) == 0) atomicOr(err, 1); dead = 1; }
+}
+__device__ __forceinline__ void ws2_wait_all(const int* p, int need, int* err, int& dead) {
+    if (__builtin_expect(ws2_min_all(p) < need, 0)) {
+        if (!dead) {
+            int spin = 0;
+            bool ok = false;
+#pragma clang loop unroll(disable)
+            do {
+                if (MCPC_WS_SLEEP > 0) __builtin_amdgcn_s_sleep(MCPC_WS_SLEEP);
+                ok = ws2_min_all(p) >= need;
+            } while (!ok && ++spin < kWsSpinLimit);
+            if (!ok) { if ((threadIdx.x & 63) == 0) atomicOr(err, 1); dead = 1; }
+        }
+    }
     MCPC_WS_FENCE(__ATOMIC_ACQUIRE);
 }
 
