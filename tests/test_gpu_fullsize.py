@@ -503,3 +503,33 @@ def test_shards_of_several_rounds_pick_the_cheaper_workgroup_form():
     eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, 16384, device=DEV)
     assert eng.query()["chains_per_wg"] == 32
     eng.close()
+
+
+def test_sixteen_chain_plans_with_and_without_the_shared_lds_region_agree():
+    """16-chain plans keep the ring of read-out error chunks and the prediction errors E_l apart in LDS when both fit and run the
+    forward entries between the read-out chunks (build_phases_ws2); `overlay16=1` forces the shared region and the order 32-chain plans
+    use.  Another schedule of the same arithmetic: states, records, energies and Hebbian sums bitwise equal -- on cfg-M's net and on
+    mcpc_ml's (20-128-128-784), SGD + kick and Adam."""
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    for sizes, batch in ((SIZES, 640), ([20, 128, 128], 256)):
+        g = torch.Generator().manual_seed(5)
+        dims = [sizes[0]] + sizes + [N_OUT]
+        W = [((torch.rand(dims[j + 1], dims[j], generator=g) * 2 - 1) / dims[j] ** 0.5).to(DEV) for j in range(4)]
+        b = [((torch.rand(dims[j + 1], generator=g) * 2 - 1) / dims[j] ** 0.5).to(DEV) for j in range(4)]
+        y = (torch.rand(batch, N_OUT, generator=g) < 0.13).float().to(DEV)
+        xs = [((torch.rand(batch, n, generator=g) * 2 - 1) * 2.0).to(DEV) for n in sizes]
+        for kw in (dict(acc_begin=10, acc_end=60), dict(noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.05)):
+            outs = []
+            for tuning in (None, "overlay16=1"):
+                eng = Engine(sizes, [L.ACT_RELU] * 3, sizes[0], N_OUT, batch, device=DEV, tuning=tuning)
+                assert eng.query()["chains_per_wg"] == 16
+                eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
+                res, out = _run(eng, xs, 60, rec_begin=0, rec_stride=20, rec_count=3, rec_x=True, **kw)
+                outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out + res.rec_x], eng.read_param_grads_flat().cpu().numpy(),
+                             eng.query()["lds_bytes"]))
+                eng.close()
+            assert outs[0][3] > outs[1][3]                         # apart: more LDS
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][2], outs[1][2])
+            for a, c in zip(outs[0][1], outs[1][1]):
+                assert np.array_equal(a, c)
