@@ -227,11 +227,7 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4*
     // (Four sets / three blocks ahead: 35.7 -> 33.3 cycles per MFMA in the isolated loop, scripts/mfma_stream_ubench.hip,
     // but no gain inside the step kernel, where the GEMMs are 12-16 k-blocks long -- measured and dropped.)
     const int c = lane & 15, q = lane >> 4;
-#ifdef MCPC_EXP_BCAST_B    // timing experiment only (wrong results): every lane of a q group reads the same row -> no LDS bank conflicts
-    const float* bp = B + 4 * q;
-#else
     const float* bp = B + c * ldb + 4 * q;
-#endif
     f32x4 aP[NT], aQ[NT], aR[NT], bP[CTT], bQ[CTT], bR[CTT];
     // Fragment addresses = wave-uniform base (SGPR pair, advanced by the scalar ALU) + a 32-bit per-lane byte offset that
     // never changes during the GEMM: `global_load_dwordx4 v, v_off, s[base]` needs no VALU address arithmetic at all (with
