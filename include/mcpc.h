@@ -88,7 +88,7 @@ typedef struct mcpc_net_desc {
     const char* tuning;                  /* NULL, or developer overrides of the schedule heuristics as "key=value,key=value"
                                           * (parsed once by mcpc_create, not kept): ws=0|2 step kernel (barrier / in-place),
                                           * ct=16|32 chains per workgroup, nw=4|8, no_mix=1, no_overlap=1, slot_cap=N,
-                                          * spill_gb=N, ring_parts=N, flush_tail=N, flush_streams=1|2, mix_slack=N, mix_ratio=N, mix_pmax=N, dw_ksplit=N, ws_prio=0|1|2, stagger=N, no_lean=1, no_ybits=1, overlay16=1.  Unknown keys are
+                                          * spill_gb=N, ring_parts=N, flush_tail=N, flush_streams=1|2, mix_slack=N, mix_ratio=N, mix_pmax=N, dw_ksplit=N, ws_prio=0|1|2, stagger=N, no_lean=1, no_ybits=1, overlay16=1, heb_fp32=1 (the Hebbian GEMM on the fp32 MFMA instead of its bf16x6 form).  Unknown keys are
                                           * an error.  Used by A/B runs and by the tests that pin every kernel variant. */
 } mcpc_net_desc;
 

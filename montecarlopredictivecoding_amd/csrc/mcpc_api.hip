@@ -38,6 +38,7 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 inline int pad16(int n) { return (n + 15) / 16 * 16; }
+inline int kblocks(int k_pad) { return (k_pad + kKB - 1) / kKB; }      // k-blocks of the GEMM core that cover k_pad (a multiple of 16)
 inline int grid_for(size_t n, int block = 256) { return (int)std::min<size_t>((n + block - 1) / block, 4096); }
 
 struct Lin {
@@ -74,13 +75,24 @@ struct Knobs {
                               // (96.8 -> 95.2 us per step of the learning call; parts of 64 steps beat 48, 96 and 128)
     int mix_pmax = 80;        // longest segment of the mixed schedule, in steps of a paired unit (10 / 20 / 40 / 80: 76.4 / 75.4 / 75.2 / 75.0 us
                               // per step inside the cycles: every segment boundary joins two streams)
+#ifndef MCPC_GEMM_BF16X6
     int mix_ratio = 17;       // steps of a split unit per 10 steps of a paired one (the rate ratio of the two workgroup forms)
+#else
+    int mix_ratio = 19;       // ... with the bf16x6 GEMM core the 16-chain form gained more than the 32-chain one: 1.7 / 1.8 / 1.9 / 2.0 / 2.1
+                              // give 67.5 / 66.7 / 65.9 / 66.9 / 68.0 us per step of an inference call at cfg-M
+#endif
     int dw_ksplit = 0;        // > 0: K-splits per workgroup tile of the Hebbian GEMM (0: one wave of workgroups over the chip)
+#ifndef MCPC_GEMM_BF16X6
     int ws_prio = 1;          // 1: epilogue waves at raised priority, 2: GEMM waves, 0: neither
+#else
+    int ws_prio = 0;          // ... the bf16x6 GEMM waves need most of the issue port themselves (48 MFMAs + ~110 VALU per 768 MFMA cycles): with
+                              // the epilogue waves at raised priority the plain schedule takes 94.2 us per step at cfg-M, without 87.7
+#endif
     int stagger = 0;          // barrier kernel: start cycles of the second workgroup of a CU
     int no_lean = 0;          // 1: the in-place kernel's E waves use the generic epilogues everywhere (A/B, parity tests)
     int no_ybits = 0;         // 1: 0/1 targets are read as fp32 like any other target (A/B, parity tests)
     int overlay16 = 0;        // 1: 16-chain plans share the LDS of the ring and the E_l like 32-chain plans do (A/B, parity tests)
+    int heb_fp32 = 0;         // 1: the tiled Hebbian GEMM runs on the fp32 MFMA (mcpc_heb_kernel) instead of the bf16x6 form (A/B, parity tests)
 };
 
 int parse_tuning(const char* str, Knobs& k) {
@@ -101,7 +113,7 @@ int parse_tuning(const char* str, Knobs& k) {
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
             {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"mix_pmax", &k.mix_pmax}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
-            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}};
+            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}, {"heb_fp32", &k.heb_fp32}};
         bool found = false;
         for (auto& t : table)
             if (key == t.name) { *t.dst = val; found = true; }
@@ -178,6 +190,7 @@ struct mcpc_engine {
     KPhase* phases = nullptr;
     int n_phases = 0;
     int* err = nullptr;             // device error word written by the kernels
+    float* dummy = nullptr;         // 4 KiB of zeros (KParams::dummy)
     // Mixed schedule of the in-place kernel (inference stretches of a shard that leaves CUs idle): most pairs of chain tiles
     // run as 32-chain workgroups, `mix_ns` pairs per segment are split into two 16-chain workgroups on the spare CUs; the
     // split set rotates, and after `mix_lc` segments every pair has done the same number of steps.
@@ -233,7 +246,7 @@ int free_all(mcpc_engine* e) {
     if (e->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(e->comm); e->comm = nullptr; e->comm_ranks = 0; }
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int l = 0; l < kMaxLatent; ++l) { F(e->x[l]); F(e->m[l]); F(e->v[l]); F(e->spill_a[l]); F(e->spill_e[l]); }
-    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err);
+    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err); F(e->dummy);
     for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : e->events_mix) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -335,12 +348,14 @@ int plan_lds_ws2(mcpc_engine* e) {
         auto ring_of = [&](int hc, int nb) { return nb * CT * (hc * 16 + kLdPad); };
         auto fits = [&](int hc, int nb) { return (off + std::max(ring_of(hc, nb), e_sum)) * (int)sizeof(float) <= 160 * 1024; };
         auto fits_apart = [&](int hc, int nb) { return (off + ring_of(hc, nb) + e_sum) * (int)sizeof(float) <= 160 * 1024; };
-        int hc_fit = 0;
-        for (int hc = std::min(span, ht); hc >= 1; --hc)
-            if (fits(hc, 2)) { hc_fit = hc; break; }
-        if (!hc_fit) return fail(MCPC_ENOMEM, "in-place schedule does not fit the LDS");
-        const int nch = (ht + hc_fit - 1) / hc_fit;
-        const int hc = (ht + nch - 1) / nch;                 // equalised: the widest chunk of the split
+        // (chunks are whole k-blocks of the back-projection GEMM: tq tiles)
+        const int tq = kKB / 16, hb = (ht + tq - 1) / tq;
+        int hcb_fit = 0;
+        for (int hcb = std::min(span / tq, hb); hcb >= 1; --hcb)
+            if (fits(hcb * tq, 2)) { hcb_fit = hcb; break; }
+        if (!hcb_fit) return fail(MCPC_ENOMEM, "in-place schedule does not fit the LDS");
+        const int nch = (hb + hcb_fit - 1) / hcb_fit;
+        const int hc = tq * ((hb + nch - 1) / nch);          // equalised: the widest chunk of the split (tiles)
         const int nb = (nch >= 3 && fits(hc, 3)) ? 3 : 2;
         e->ws2_chunk = hc; e->ws2_ring = nb; ring_floats = ring_of(hc, nb);
         if (CT == 16 && L >= 2 && fits_apart(hc, nb) && !e->knobs.overlay16) { e->ws2_overlay = false; e->lds_eo = off + e_sum; }
@@ -387,7 +402,7 @@ int build_phases_ws2(mcpc_engine* e) {
             if (l == 0) {
                 k.flags = PHF_MU1 | PHF_WS_EPI;
             } else {
-                k.A = (const f32x4*)e->lin[l].Wf; k.a_tile_stride = tiles(l - 1) * 64; k.nkb = tiles(l - 1);
+                k.A = e->lin[l].Wf; k.nkb = kblocks(16 * tiles(l - 1)); k.a_tile_stride = k.nkb * kFragBlock;
                 k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
                 k.out_lds = e->lds_e[l]; k.out_ld = e->npad[l] + kLdPad;
                 k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_BWD - (l - 1);
@@ -418,8 +433,11 @@ int build_phases_ws2(mcpc_engine* e) {
         const int hc = e->ws2_chunk, R = e->ws2_ring;        // hc: widest chunk = ring slot width
         const int ht = e->out_pad / 16;
         const int nch = (ht + hc - 1) / hc;
-        std::vector<int> c_start(nch + 1, 0);                 // chunk c = tiles [c_start[c], c_start[c+1]): sizes differ by <= 1
-        for (int c = 0; c < nch; ++c) c_start[c + 1] = c_start[c] + ht / nch + (c < ht % nch ? 1 : 0);
+        // chunk c = tiles [c_start[c], c_start[c+1]): whole k-blocks of the back-projection (tq tiles each) dealt out evenly, the last
+        // chunk clipped to the read-out's width
+        const int tq = kKB / 16, hb = (ht + tq - 1) / tq;
+        std::vector<int> c_start(nch + 1, 0);
+        for (int c = 0; c < nch; ++c) c_start[c + 1] = std::min(ht, c_start[c] + tq * (hb / nch + (c < hb % nch ? 1 : 0)));
         const int chunk_floats = e->ct * (hc * 16 + kLdPad);
         int e_sum = 0;
         for (int l = 1; l < L; ++l) e_sum += e->ct * (e->npad[l] + kLdPad);
@@ -427,7 +445,7 @@ int build_phases_ws2(mcpc_engine* e) {
         auto add_f = [&](int c) {
             KPhase f = blank();
             f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c_start[c]; f.ntiles = c_start[c + 1] - c_start[c]; f.rot = c & (kWs2Pairs - 1);
-            f.A = (const f32x4*)e->lin[L].Wf; f.a_tile_stride = tiles(L - 1) * 64; f.nkb = tiles(L - 1);
+            f.A = e->lin[L].Wf; f.nkb = kblocks(16 * tiles(L - 1)); f.a_tile_stride = f.nkb * kFragBlock;
             f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad;
             f.out_lds = e->lds_eo + (c % R) * chunk_floats; f.out_ld = hc * 16 + kLdPad;
             f.flags = PHF_WS_GEMM | PHF_WS_EPI; f.dep_e = REF_LAST_BWD - (L - 1);
@@ -438,8 +456,8 @@ int build_phases_ws2(mcpc_engine* e) {
         auto add_b = [&](int c) {
             KPhase b = blank();
             b.type = PH_HEADB; b.layer = L - 1; b.tile0 = 0; b.ntiles = tiles(L - 1);
-            b.A = (const f32x4*)e->lin[L].Wb; b.a_tile_stride = ht * 64; b.a_off0 = c_start[c] * 64;
-            b.nkb = c_start[c + 1] - c_start[c];
+            b.A = e->lin[L].Wb; b.a_tile_stride = kblocks(e->out_pad) * kFragBlock; b.a_off0 = (c_start[c] / tq) * kFragBlock;
+            b.nkb = (c_start[c + 1] - c_start[c] + tq - 1) / tq;
             b.b_lds = e->lds_eo + (c % R) * chunk_floats; b.ldb = hc * 16 + kLdPad;
             b.flags = PHF_WS_GEMM; b.dep_e = idx_f[c];
             idx_b[c] = (int)ph.size(); ph.push_back(b);
@@ -468,7 +486,7 @@ int build_phases_ws2(mcpc_engine* e) {
         for (int base = 0; base < tiles(l - 1); base += span) {
             KPhase k = blank();
             k.type = PH_BWD; k.layer = l - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(l - 1) - base);
-            k.A = (const f32x4*)e->lin[l].Wb; k.a_tile_stride = tiles(l) * 64; k.nkb = tiles(l);
+            k.A = e->lin[l].Wb; k.nkb = kblocks(16 * tiles(l)); k.a_tile_stride = k.nkb * kFragBlock;
             k.b_lds = e->lds_e[l]; k.ldb = e->npad[l] + kLdPad; k.sign = -1.0f;
             k.out_lds = e->lds_a[l - 1]; k.out_ld = e->npad[l - 1] + kLdPad;
             k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_FWD - l;
@@ -518,7 +536,7 @@ int build_phases(mcpc_engine* e) {
         for (int base = 0; base < tiles(l); base += span) {
             KPhase k{};
             k.type = PH_FWD; k.layer = l; k.tile0 = base; k.ntiles = std::min(span, tiles(l) - base);
-            k.A = (const f32x4*)e->lin[l].Wf; k.a_tile_stride = tiles(l - 1) * 64; k.nkb = tiles(l - 1);
+            k.A = e->lin[l].Wf; k.nkb = kblocks(16 * tiles(l - 1)); k.a_tile_stride = k.nkb * kFragBlock;
             k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
             k.flags = base + span >= tiles(l) ? PHF_SYNC : 0;
             ph.push_back(k);
@@ -529,13 +547,14 @@ int build_phases(mcpc_engine* e) {
             const int ntc = std::min(kChunkTiles, ht - c0);
             KPhase f{};
             f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c0; f.ntiles = ntc;
-            f.A = (const f32x4*)e->lin[L].Wf; f.a_tile_stride = tiles(L - 1) * 64; f.nkb = tiles(L - 1);
+            f.A = e->lin[L].Wf; f.nkb = kblocks(16 * tiles(L - 1)); f.a_tile_stride = f.nkb * kFragBlock;
             f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad; f.flags = PHF_SYNC;
             f.out_lds = e->lds_eo; f.out_ld = kChunkTiles * 16 + kLdPad; f.dep_e = f.dep_g = -1;
             ph.push_back(f);
             KPhase b{};
             b.type = PH_HEADB; b.layer = L - 1; b.tile0 = 0; b.ntiles = tiles(L - 1);
-            b.A = (const f32x4*)e->lin[L].Wb; b.a_tile_stride = ht * 64; b.a_off0 = c0 * 64; b.nkb = ntc;
+            b.A = e->lin[L].Wb; b.a_tile_stride = kblocks(e->out_pad) * kFragBlock; b.a_off0 = (c0 * 16 / kKB) * kFragBlock;
+            b.nkb = (ntc * 16 + kKB - 1) / kKB;
             b.b_lds = e->lds_eo; b.ldb = kChunkTiles * 16 + kLdPad;
             b.flags = PHF_ACC_FROM_B | PHF_ACC_TO_B | PHF_SYNC;
             ph.push_back(b);
@@ -554,7 +573,7 @@ int build_phases(mcpc_engine* e) {
         for (int base = 0; base < tiles(l - 1); base += span) {
             KPhase k{};
             k.type = PH_BWD; k.layer = l - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(l - 1) - base);
-            k.A = (const f32x4*)e->lin[l].Wb; k.a_tile_stride = tiles(l) * 64; k.nkb = tiles(l);
+            k.A = e->lin[l].Wb; k.nkb = kblocks(16 * tiles(l)); k.a_tile_stride = k.nkb * kFragBlock;
             k.b_lds = e->lds_e[l]; k.ldb = e->npad[l] + kLdPad; k.sign = -1.0f;
             ph.push_back(k);
         }
@@ -761,8 +780,10 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
         if (hipMemset(ln.G, 0, (size_t)ln.out_pad * ln.g_ld * 4) != hipSuccess || hipMemset(ln.Gb, 0, (size_t)ln.out_pad * 4) != hipSuccess)
             return bail(fail(MCPC_EHIP, "hipMemset failed"));
         if (j >= 1) {
-            const size_t pk = (size_t)ln.out_pad * ln.in_pad;
-            if ((rc = dmalloc(ln.Wf, pk)) || (rc = dmalloc(ln.Wb, pk)) || (rc = dmalloc(ln.bias_pad, (size_t)ln.out_pad))) return bail(rc);
+            // packed fragments (floats): tiles x k-blocks x kFragBlock 16-byte units, forward and backward
+            const size_t pkf = (size_t)(ln.out_pad / 16) * kblocks(ln.in_pad) * kFragBlock * 4;
+            const size_t pkb = (size_t)(ln.in_pad / 16) * kblocks(ln.out_pad) * kFragBlock * 4;
+            if ((rc = dmalloc(ln.Wf, pkf)) || (rc = dmalloc(ln.Wb, pkb)) || (rc = dmalloc(ln.bias_pad, (size_t)ln.out_pad))) return bail(rc);
         }
     }
     // spill ring
@@ -790,6 +811,8 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if ((rc = e->ws == 2 ? build_phases_ws2(e) : build_phases(e))) return bail(rc);
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
     if (hipMemset(e->err, 0, sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
+    if ((rc = dmalloc(e->dummy, 1024))) return bail(rc);
+    if (hipMemset(e->dummy, 0, 4096) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
     const void* kfn = e->ws == 2 ? (e->ct == 16 ? (const void*)mcpc_steps_ws2_kernel<1> : (const void*)mcpc_steps_ws2_kernel<2>)
                       : e->ct == 16 ? (const void*)mcpc_steps_kernel<1, 4>
                       : (e->nw == 8 ? (const void*)mcpc_steps_kernel<2, 8> : (const void*)mcpc_steps_kernel<2, 4>);
@@ -977,6 +1000,21 @@ int launch_heb(const HebArgs& a, hipStream_t stream) {
     return 0;
 }
 
+template <int TE, int RA>
+int launch_heb6(const HebArgs& a, hipStream_t stream) {
+    constexpr int lds_bytes = 3 * 16 * (TE + 8 * RA) * kHeb6KB * 2;
+    static bool attr_set[16] = {false};      // per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)mcpc_heb6_kernel<TE, RA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return fail(MCPC_EHIP, "hipFuncSetAttribute failed for the Hebbian kernel");
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((mcpc_heb6_kernel<TE, RA>), dim3(a.n_mt * a.n_nt * a.ksplit), dim3(kHebThreads), lds_bytes, stream, a);
+    return 0;
+}
+
 // Allocated by the first run that accumulates Hebbian sums (inference-only engines never pay for it): the spill ring, the
 // slabs of the split-K partial sums (sized for a flush of half the ring), the low-priority stream and events of the
 // overlapped flush.
@@ -1070,6 +1108,14 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
                 stream = next_stream((double)h.n_mt[part] * h.te[part] * 16 * na);
                 int rc = 0;
                 const int te = h.te[part];
+                if (!e->knobs.heb_fp32) {
+                    if (te == 17 && h.ra == 2) rc = launch_heb6<17, 2>(a, stream);
+                    else if (te == 16 && h.ra == 2) rc = launch_heb6<16, 2>(a, stream);
+                    else if (te == 8 && h.ra == 2) rc = launch_heb6<8, 2>(a, stream);
+                    else if (te == 17) rc = launch_heb6<17, 1>(a, stream);
+                    else if (te == 16) rc = launch_heb6<16, 1>(a, stream);
+                    else rc = launch_heb6<8, 1>(a, stream);
+                } else
                 if (te == 17 && h.ra == 2) rc = launch_heb<17, 2>(a, stream);
                 else if (te == 16 && h.ra == 2) rc = launch_heb<16, 2>(a, stream);
                 else if (te == 8 && h.ra == 2) rc = launch_heb<8, 2>(a, stream);
@@ -1256,7 +1302,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         for (int l = 0; l < e->L; ++l) widest = std::max(widest, e->npad[l]);
         P.lean_ok = e->Bpad < (1 << 24) && (uint64_t)e->Bpad * (uint64_t)widest * 4u < (1ull << 32) && !e->knobs.no_lean;
     }
-    P.err = e->err;
+    P.err = e->err; P.dummy = e->dummy; P.lds_floats = e->lds_bytes / 4;
 #ifdef MCPC_STAMPS
     if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * 2 * kMaxWaves * 16); if (rc) return rc; }
     P.dbg = e->dbg;
@@ -1308,7 +1354,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         KParams P2 = P, P1 = P;
         for (int l = 0; l < e->L; ++l) { P1.layer[l].lds_a = e->alt16.lds_a[l]; P1.layer[l].lds_e = e->alt16.lds_e[l]; }
         P1.head.lds_eo = e->alt16.lds_eo; P1.lds_red = e->alt16.lds_red; P1.lds_ws_sync = e->alt16.lds_ws_sync;
-        P1.phases = e->alt16.phases; P1.n_phases = e->alt16.n_phases;
+        P1.phases = e->alt16.phases; P1.n_phases = e->alt16.n_phases; P1.lds_floats = e->alt16.lds_bytes / 4;
         P2.t0 = P1.t0 = t0; P2.spill_t0 = P1.spill_t0 = t0;
         // per-step tables start at the cycle's first step; a unit indexes them with its own step minus t0
         const int s0 = t0 - r->t_begin;

@@ -192,6 +192,175 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
     }
 }
 
+constexpr int kHeb6KB = 32;            // spilled rows per stage = K of one bf16 MFMA
+
+// ---- bf16x6 form of the tiled kernel (the default; tuning heb_fp32=1 selects the fp32-MFMA kernel above) ---------------------------
+// The same GEMM with the spilled fp32 operands split into three bf16 pieces (the six products whose magnitude is above
+// 2^-24 of the leading one, fp32 accumulation, small terms first; mcpc_bf16x6.h) on v_mfma_f32_16x16x32_bf16: against an fp64 sum its error is that of
+// the fp32-MFMA kernel (max 2.7e-7 / rms 3.1e-8 of sum|terms| against 2.1e-7 / 2.7e-8 at K = 4096, scripts/heb_bf16_ubench.hip), at
+// 1.66 x its rate on the same shapes (0.785 ms against 1.30 ms for the 784 x 256 flush of 64 steps on the whole chip).
+//   global -> registers (one float4 per row and thread, a stage ahead) -> v_cvt_pk_bf16_f32 -> LDS planes -> MFMA operands:
+// TE error tiles x 8 RA activation tiles per workgroup, 8 waves, wave w owns activation tiles RA w .. RA w + RA - 1.
+// LDS: three bf16 planes of the stage's operands, TRANSPOSED: plane[p][unit][r], 32 r = 64 B per unit, so that the MFMA operand of
+// lane (m, g) -- unit m, k = 8g..8g+7 -- is ONE ds_read_b128 and a wave reads 1 KiB linearly (conflict-free).
+// Split pass: thread (ug, c) takes four consecutive units x the 8-row chunk c: 8 float4 loads (a chunk's 16 lanes = 256 contiguous bytes
+// of a spilled row), one ds_write_b128 per unit and plane.  512 units = 512 tasks = one per thread; a 17th error tile (TE = 17:
+// 784 = 17 + 16 + 16 tiles) is 512 more elements = ONE per thread (row tid / 16, unit 16 TE' + tid % 16), written with ds_write_b16.
+template <int TE, int RA>
+__global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb6_kernel(const HebArgs P) {
+    constexpr int TA = 8 * RA;
+    constexpr int TEM = TE >= 16 ? 16 : TE;             // error tiles handled by the float4 tasks
+    constexpr bool XT = TE == 17;                       // one extra error tile handled element-wise
+    static_assert(TE <= 17 && 4 * 4 * (TEM + TA) <= kHebThreads, "one task per thread");
+    constexpr int NU = 16 * (TE + TA);                  // units (columns) per stage: E panel then A panel
+    constexpr int PLANE = NU * kHeb6KB;                   // bf16 elements per plane
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds6[];       // [3][NU][32] bf16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, g = lane >> 4;
+    const int total = P.n_mt * P.n_nt * P.ksplit;
+    int id = blockIdx.x;
+    if (total % 8 == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    const int per_split = P.n_mt * P.n_nt;
+    const int split = id / per_split, rem = id - split * per_split;
+    const int nt = rem / P.n_mt, mt = rem - nt * P.n_mt;
+    const int e_col0 = P.e_col_base + mt * 16 * TE, a_col0 = nt * 16 * TA;
+    const int r0 = split * P.rows_per_split;
+    const int r1 = min(P.rows, r0 + P.rows_per_split);
+    const int n_stage = (r1 - r0) / kHeb6KB;
+
+    // the float4 task of this thread; LDS unit index: E tiles 0 .. TEM-1, [the extra tile TEM], then the A tiles
+    const int ug = tid >> 2, c = tid & 3;
+    const bool mine = ug < 4 * (TEM + TA);
+    const bool is_a = 4 * ug >= 16 * TEM;
+    const int col = is_a ? a_col0 + 4 * ug - 16 * TEM : e_col0 + 4 * ug;
+    const int width = is_a ? P.na : P.ne;
+    const bool on = mine && col < width;                  // (widths are multiples of 16: a group of four is in or out as a whole)
+    const float* const src = (is_a ? P.A : P.E) + (size_t)(r0 + 8 * c) * width + (on ? col : 0);
+    const int lunit = 4 * ug + ((XT && is_a) ? 16 : 0);
+    const int loff = (mine ? lunit : 0) * kHeb6KB + 8 * c;  // element offset of the group's first unit inside a plane
+    // the extra tile: element (row tid / 16, unit tid % 16)
+    const int xr = tid >> 4, xu = tid & 15;
+    const bool xon = XT && e_col0 + 16 * TEM + xu < P.ne;
+    const float* const xsrc = P.E + (size_t)(r0 + xr) * P.ne + (xon ? e_col0 + 16 * TEM + xu : 0);
+    const int xoff = (16 * TEM + xu) * kHeb6KB + xr;
+    f32x4 v[8];
+    float xv = 0.f;
+    auto load_stage = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(s * kHeb6KB + j) * width));
+        if constexpr (XT) xv = __builtin_nontemporal_load(xsrc + (size_t)s * kHeb6KB * P.ne);
+    };
+    f32x4 bsum = splat(0.f);
+    float xbsum = 0.f;
+    auto split_store = [&]() {
+        if (mine) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                // unit 4 ug + u: rows 8 c .. 8 c + 7 are v[0..7][u]
+                u32x4 hi, mid, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = on ? v[2 * j][u] : 0.f, b = on ? v[2 * j + 1][u] : 0.f;
+                    bsum[u] += a + b;
+                    const unsigned h = pk_bf16(a, b);
+                    const float ra = a - bf16lo_f32(h), rb = b - bf16hi_f32(h);
+                    const unsigned mm = pk_bf16(ra, rb);
+                    const float sa = ra - bf16lo_f32(mm), sb = rb - bf16hi_f32(mm);
+                    hi[j] = h; mid[j] = mm; lo[j] = pk_bf16(sa, sb);
+                }
+                *reinterpret_cast<u32x4*>(lds6 + 0 * PLANE + loff + u * kHeb6KB) = hi;
+                *reinterpret_cast<u32x4*>(lds6 + 1 * PLANE + loff + u * kHeb6KB) = mid;
+                *reinterpret_cast<u32x4*>(lds6 + 2 * PLANE + loff + u * kHeb6KB) = lo;
+            }
+        }
+        if constexpr (XT) {
+            const float a = xon ? xv : 0.f;
+            xbsum += a;
+            const unsigned h = pk_bf16(a, 0.f);
+            const float ra = a - bf16lo_f32(h);
+            const unsigned mm = pk_bf16(ra, 0.f);
+            const float sa = ra - bf16lo_f32(mm);
+            lds6[0 * PLANE + xoff] = (unsigned short)h;
+            lds6[1 * PLANE + xoff] = (unsigned short)mm;
+            lds6[2 * PLANE + xoff] = (unsigned short)pk_bf16(sa, 0.f);
+        }
+    };
+
+    f32x4 acc[TE][RA];
+#pragma unroll
+    for (int i = 0; i < TE; ++i)
+#pragma unroll
+        for (int j = 0; j < RA; ++j) acc[i][j] = splat(0.f);
+
+    if (n_stage > 0) load_stage(0);
+    const unsigned short* const base = lds6 + (size_t)m * kHeb6KB + 8 * g;       // lane (m, g) of tile t reads plane[p][16 t + m][8 g .. 8 g + 7]
+    struct Op { u32x4 h, m, l; };
+    auto ld_op = [&](int tile) {
+        const unsigned short* p = base + (size_t)(16 * tile) * kHeb6KB;
+        Op o;
+        o.h = *reinterpret_cast<const u32x4*>(p);
+        o.m = *reinterpret_cast<const u32x4*>(p + PLANE);
+        o.l = *reinterpret_cast<const u32x4*>(p + 2 * PLANE);
+        return o;
+    };
+    for (int s = 0; s < n_stage; ++s) {
+        split_store();                                    // stage s: registers -> three bf16 planes in LDS
+        __syncthreads();
+        if (s + 1 < n_stage) load_stage(s + 1);            // travels during the MFMAs
+        Op ao[RA];
+#pragma unroll
+        for (int j = 0; j < RA; ++j) ao[j] = ld_op(TE + RA * w + j);
+        Op e = ld_op(0);
+#pragma unroll
+        for (int i = 0; i < TE; ++i) {
+            // the next error tile's operands are requested before this tile's MFMAs (pinned: left alone hipcc sinks the reads)
+            Op en = e;
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < TE) en = ld_op(i + 1);
+            // six products per accumulator, small terms first, the accumulators of the tile alternating
+#define H6(ep_, ap_) _Pragma("unroll") for (int j = 0; j < RA; ++j) acc[i][j] = mfma6(e.ep_, ao[j].ap_, acc[i][j])
+            H6(m, m); H6(l, h); H6(h, l); H6(m, h); H6(h, m); H6(h, h);
+#undef H6
+            __builtin_amdgcn_sched_barrier(0);
+            e = en;
+        }
+        __syncthreads();                                  // every wave is done with the planes of stage s
+    }
+    // C layout of tile (i, j): row 4 g + reg -> error unit, column m -> activation unit
+    float* out = P.slab + (size_t)split * P.ne * P.na;
+#pragma unroll
+    for (int i = 0; i < TE; ++i) {
+        const int u0 = e_col0 + 16 * i + 4 * g;
+        if (u0 >= P.ne) continue;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int a = a_col0 + 16 * (RA * w + j) + m;
+            if (a >= P.na) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) out[(size_t)(u0 + reg) * P.na + a] = acc[i][j][reg];
+        }
+    }
+    // bias sums (column sums of E, workgroups of the first activation group only).  float4 tasks: the four chunk lanes of a unit
+    // group are adjacent lanes.  Extra tile: 32 rows spread over tid / 16 -> through LDS.
+    if (nt == 0) {
+        f32x4 bb = bsum;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { float t = bb[u]; t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); bb[u] = t; }
+        if (c == 0 && mine && !is_a && col < P.ne) *reinterpret_cast<f32x4*>(P.slab_b + (size_t)split * P.ne + col) = bb;
+        if constexpr (XT) {
+            float* red = reinterpret_cast<float*>(lds6);
+            red[tid] = xbsum;
+            __syncthreads();
+            if (tid < 16 && e_col0 + 16 * TEM + tid < P.ne) {
+                float t = 0.f;
+                for (int r = 0; r < 32; ++r) t += red[16 * r + tid];
+                P.slab_b[(size_t)split * P.ne + e_col0 + 16 * TEM + tid] = t;
+            }
+        }
+    }
+}
+
 // ---- fixed-order slab reduction for every Linear of a flush in ONE launch ---------------------------------------------
 struct ReduceJob {
     const float* slab;     // [ksplit][n]

@@ -9,6 +9,7 @@
 //                         replaces the parameter part of overall.backward(), pc_trainer.py:862.
 #pragma once
 #include "mcpc_device.h"
+#include "mcpc_bf16x6.h"
 #include "../../include/mcpc.h"
 
 namespace mcpc {
@@ -65,13 +66,13 @@ struct KHead {
 enum : int { PH_FWD = 0, PH_HEADF = 1, PH_HEADB = 2, PH_BWD = 3, PH_ENERGY = 4 };
 enum : int { PHF_ACC_FROM_B = 1, PHF_ACC_TO_B = 2, PHF_SYNC = 4, PHF_MU1 = 8 };
 struct KPhase {
-    const f32x4* A;        // packed weight fragments of this GEMM (unused when nkb == 0)
+    const void* A;         // packed weight fragments of this GEMM (unused when nkb == 0): layout of the GEMM core in use
     int type;              // PH_*
     int layer;             // FWD: layer whose prediction error is produced; BWD: layer whose x is updated
     int tile0, ntiles;     // output unit tiles of the phase; wave w owns tiles tile0 + w + 4 i
-    int a_tile_stride;     // f32x4 units between the fragments of consecutive output tiles
-    int a_off0;            // f32x4 offset of the first k-block of the k-window
-    int nkb;               // k-blocks of 16 (0: no GEMM -- top-layer pass, update without back-projection)
+    int a_tile_stride;     // 16-byte units between the fragments of consecutive output tiles
+    int a_off0;            // 16-byte offset of the first k-block of the k-window
+    int nkb;               // k-blocks of kKB (0: no GEMM -- top-layer pass, update without back-projection)
     int b_lds, ldb;        // B operand: LDS float offset and row stride
     int flags;             // PHF_*
     float sign;            // BWD: g = e + sign * f'(x) * back
@@ -126,6 +127,8 @@ struct KParams {
     int mix_ms, mix_mp;              // steps per segment of a split / a paired unit
     int epart_slots;                 // in-place kernel: energy partials are indexed by 16-chain tile, this many per row
     int lean_ok;                     // in-place kernel: every [Bpad][npad] image is < 4 GiB and Bpad < 2^24 (32-bit lane offsets)
+    const void* dummy;               // 4 KiB of valid device memory: what the branch-free fragment prefetch reads for entries without a GEMM
+    int lds_floats;                  // floats of dynamic LDS of this plan (cleared once per launch: see mcpc_gemm6.h, k ranges)
 #ifdef MCPC_STAMPS
     unsigned long long* dbg;   // diagnostic build only: [nwg][kWaves][16] cycle sums per phase
 #endif
@@ -211,6 +214,22 @@ __device__ __forceinline__ void issue_epilogue_loads(const KParams& P, const KPh
     }
 }
 
+// ---- GEMM core ------------------------------------------------------------------------------------------------------------
+// Default: v_mfma_f32_16x16x4_f32 (exact fp32).  -DMCPC_GEMM_BF16X6 builds the step kernels on fp32 products emulated in-class on the
+// bf16 matrix pipe instead (mcpc_gemm6.h; A/B runs: `make variant VARNAME=b6 VARFLAGS=-DMCPC_GEMM_BF16X6`).  Both expose
+//   frag_t, kKB (k-depth of a fragment block), kFragBlock (16-byte units per tile and block), frag_zero, load_frag,
+//   gemm_tiles, prefetch_first_blocks
+// and read the B operand from the same fp32 LDS rows.
+#ifdef MCPC_GEMM_BF16X6
+}  // namespace mcpc
+#include "mcpc_gemm6.h"
+namespace mcpc {
+#else
+typedef f32x4 frag_t;                   // one 16-deep k-block of one tile: lane (m, q) holds W[16ut+m][16kb+4q+r], r = 0..3
+constexpr int kKB = 16;
+constexpr int kFragBlock = 64;
+__device__ __forceinline__ frag_t frag_zero() { return splat(0.f); }
+__device__ __forceinline__ frag_t load_frag(const gf32x4* A, int off, int lane) { return A[off + lane]; }
 #ifdef MCPC_EXP_NOLOAD   // timing experiment only (wrong results): every fragment load re-reads k-block 0 -> L1 hits
 #define MCPC_KSEL(k_) 0
 #else
@@ -350,11 +369,11 @@ __device__ __forceinline__ void gemm_dispatch(f32x4 (&acc)[NTT][CTT], const gf32
     }
 }
 template <int NTT, int CTT, int NW>
-__device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const gf32x4* __restrict__ A,
+__device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const void* A,
                                            const int (&aoff)[NTT], int nt, int nkb,
                                            const float* B, int ldb, int lane,
                                            const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT]) {
-    gemm_dispatch<1, NTT, CTT, NW>(acc, A, aoff, nt, nkb, B, ldb, lane, pre0, pre1);
+    gemm_dispatch<1, NTT, CTT, NW>(acc, (const gf32x4*)A, aoff, nt, nkb, B, ldb, lane, pre0, pre1);
 }
 
 // request the fragments of k-blocks 0 and 1 of a phase's GEMM (issued one phase early: weights do not
@@ -375,6 +394,8 @@ __device__ __forceinline__ void prefetch_first_blocks(const KPhase& ph, int wave
         }
     }
 }
+
+#endif   // MCPC_GEMM_BF16X6
 
 // guarded scalar store of a C-layout quad into an unpadded [B][n] tensor row
 __device__ __forceinline__ void st_unpadded(float* base, int chain, int n, int u0, f32x4 v) {
@@ -651,6 +672,11 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
     // fused fast paths of the x update (wave-uniform, fixed for the launch)
     const int upd_mode = (P.update_x && P.xopt == MCPC_XOPT_SGD)
                              ? (P.noise_mode == MCPC_NOISE_PHILOX ? 2 : (P.noise_mode == MCPC_NOISE_NONE ? 1 : 0)) : 0;
+#ifdef MCPC_GEMM_BF16X6
+    // the GEMM core may read B rows a little beyond a k range (zero weights there): every float of the plan is finite from here on
+    for (int i = tid; i < P.lds_floats / 4; i += NW * 64) st4(lds + 4 * i, splat(0.f));
+    __syncthreads();
+#endif
     if (P.stagger_cycles > 0 && blockIdx.x >= 256) {
         // two workgroups share a CU: start the second one out of phase so that its GEMMs overlap the
         // first one's epilogues / barriers instead of competing for the matrix pipe in lockstep
@@ -661,9 +687,9 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
     // software pipeline over phases: descriptor + first two weight k-blocks of the upcoming phase
     KPhase ph_next = load_phase(P.phases, 0);
     int nt_next, aoff_next[NTW];
-    f32x4 pre0_next[NTW], pre1_next[NTW];
+    frag_t pre0_next[NTW], pre1_next[NTW];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) { pre0_next[i] = splat(0.f); pre1_next[i] = splat(0.f); }
+    for (int i = 0; i < NTW; ++i) { pre0_next[i] = frag_zero(); pre1_next[i] = frag_zero(); }
     prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
 
     for (int s = 0; s < P.n_steps; ++s) {
@@ -692,7 +718,7 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
             const KPhase ph = ph_next;
             const int nt = nt_next;
             int aoff[NTW];
-            f32x4 pre0[NTW], pre1[NTW];
+            frag_t pre0[NTW], pre1[NTW];
 #pragma unroll
             for (int i = 0; i < NTW; ++i) { aoff[i] = aoff_next[i]; pre0[i] = pre0_next[i]; pre1[i] = pre1_next[i]; }
             // descriptor of the phase after this one (wraps into the next step)
@@ -733,7 +759,7 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
             // (Requesting them after the GEMM's last fragment load was measured slower on MI355X.)
             if (ph.type != PH_HEADB) issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
             if (nt > 0 && ph.nkb > 0)
-                gemm_tiles<NTW, CTT, NW>(acc, (const gf32x4*)ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
+                gemm_tiles<NTW, CTT, NW>(acc, ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
             // the next phase's first weight fragments travel while this phase's epilogue runs
             if (has_next) prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
             if (ph.flags & PHF_ACC_TO_B) {
@@ -774,6 +800,7 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
 
 // ------------------------------------------------------------------------------------------------
 // Weight packing into MFMA fragment order (run once per parameter change).
+#ifndef MCPC_GEMM_BF16X6
 //   forward : Wf[ut][kb][lane][r] = W[16ut + (lane&15)][16kb + 4(lane>>4) + r]
 //   backward: Wb[it][ub][lane][r] = W[16ub + 4(lane>>4) + r][16it + (lane&15)]
 __global__ void mcpc_pack_kernel(const float* __restrict__ W, const float* __restrict__ bias,
@@ -798,6 +825,52 @@ __global__ void mcpc_pack_kernel(const float* __restrict__ W, const float* __res
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < out_tiles * 16) bias_pad[gid] = (bias != nullptr && gid < n_out) ? bias[gid] : 0.f;
 }
+
+#else
+// bf16x6 core (mcpc_gemm6.h): every weight is split into three bf16 pieces, stored as three planes per (tile, 32-deep block):
+//   forward : Wf[ut][kb][plane][lane] (16 B) = W[16ut + (lane&15)][32kb + 8(lane>>4) + j], j = 0..7
+//   backward: Wb[it][ub][plane][lane] (16 B) = W[32ub + 8(lane>>4) + j][16it + (lane&15)], j = 0..7
+// in_blocks = ceil(16 in_tiles / 32), out_blocks = ceil(16 out_tiles / 32); elements beyond the matrix are zeros.
+__global__ void mcpc_pack_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                 float* __restrict__ Wf_, float* __restrict__ Wb_, float* __restrict__ bias_pad,
+                                 int n_out, int n_in, int out_tiles, int in_tiles) {
+    u32x4* const Wf = reinterpret_cast<u32x4*>(Wf_);
+    u32x4* const Wb = reinterpret_cast<u32x4*>(Wb_);
+    const int in_blocks = (16 * in_tiles + kKB - 1) / kKB, out_blocks = (16 * out_tiles + kKB - 1) / kKB;
+    const size_t n_fwd = (size_t)out_tiles * in_blocks * 64, n_bwd = (size_t)in_tiles * out_blocks * 64;
+    const size_t total = n_fwd > n_bwd ? n_fwd : n_bwd;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int lane = idx & 63, m = lane & 15, g = lane >> 4;
+        const size_t blk = idx >> 6;
+        if (idx < n_fwd) {   // blk = ut * in_blocks + kb
+            const int ut = blk / in_blocks, kb = blk % in_blocks;
+            const int u = 16 * ut + m;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = kKB * kb + 8 * g + j;
+                v[j] = (u < n_out && k < n_in) ? W[(size_t)u * n_in + k] : 0.f;
+            }
+            const frag_t f = split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+            Wf[blk * kFragBlock + lane] = f.h; Wf[blk * kFragBlock + 64 + lane] = f.m; Wf[blk * kFragBlock + 128 + lane] = f.l;
+        }
+        if (idx < n_bwd) {   // blk = it * out_blocks + ub
+            const int it = blk / out_blocks, ub = blk % out_blocks;
+            const int i = 16 * it + m;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int u = kKB * ub + 8 * g + j;
+                v[j] = (u < n_out && i < n_in) ? W[(size_t)u * n_in + i] : 0.f;
+            }
+            const frag_t f = split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+            Wb[blk * kFragBlock + lane] = f.h; Wb[blk * kFragBlock + 64 + lane] = f.m; Wb[blk * kFragBlock + 128 + lane] = f.l;
+        }
+    }
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < out_tiles * 16) bias_pad[gid] = (bias != nullptr && gid < n_out) ? bias[gid] : 0.f;
+}
+#endif
 
 // Bit-pack a padded target image [Bpad][npad] whose values are all exactly 0.0f / 1.0f (binarised MNIST, the Bernoulli
 // read-out's usual target): 98 B per chain instead of 3 136 B re-read from HBM in every step.  *flag is cleared by the first

@@ -119,22 +119,30 @@ __device__ __forceinline__ int ws2_need(int base, int n_ent, int p, int dep) {
 // branch behind `s_waitcnt vmcnt(0)`: four serial L2 round trips (~1 k cycles) per table entry.
 template <int NT>
 __device__ __forceinline__ void ws2_prefetch(const KPhase& ph, int k, int lane, const void* dummy, int& nt_out, int (&aoff)[NT],
-                                             f32x4 (&pre0)[NT], f32x4 (&pre1)[NT]) {
+                                             frag_t (&pre0)[NT], frag_t (&pre1)[NT]) {
     const int kk = (k + ph.rot) & (kWs2Pairs - 1);
     int nt = (ph.ntiles - kk + kWs2Pairs - 1) / kWs2Pairs;
     nt = nt < 0 ? 0 : (nt > NT ? NT : nt);
     if (!(ph.flags & PHF_WS_GEMM) || ph.nkb <= 0) nt = 0;
     nt_out = nt;
     const bool valid = nt > 0;
+#ifndef MCPC_GEMM_BF16X6
     const gf32x4* const A = valid ? (const gf32x4*)ph.A : (const gf32x4*)dummy;
-    const int second = (valid && ph.nkb > 1) ? 64 : 0;
+#else
+    const gu32x4* const A = valid ? (const gu32x4*)ph.A : (const gu32x4*)dummy;      // (dummy: any 6 KiB of valid global memory)
+#endif
+#ifndef MCPC_GEMM_BF16X6
+    const int second = (valid && ph.nkb > 1) ? kFragBlock : 0;
+#endif
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int ii = i < nt ? i : 0;
         const int off = valid ? (ph.tile0 + kk + kWs2Pairs * ii) * ph.a_tile_stride + ph.a_off0 : 0;
         aoff[i] = off;
-        pre0[i] = A[off + lane];
-        pre1[i] = A[off + second + lane];
+        pre0[i] = load_frag(A, off, lane);
+#ifndef MCPC_GEMM_BF16X6
+        pre1[i] = load_frag(A, off + second, lane);
+#endif
     }
 }
 

@@ -10,7 +10,7 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 6000
 dev = torch.device("cuda", 0)
 W, b, y, xs = make_problem(B, 30, dev)
-eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=dev)
+eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=dev, tuning=os.environ.get("QUICK_TUNING"))
 eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
 base = dict(noise_mode=L.NOISE_PHILOX, loss_kind=L.LOSS_BERNOULLI, energy_mode=L.ENERGY_ALL, lr=0.03, seed=1)
 out = []

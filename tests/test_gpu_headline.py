@@ -90,11 +90,36 @@ def test_headline_call_matches_serial_plain_schedule_bitwise(problem, default_ru
     np.testing.assert_allclose(en_d[:, -1], en_d[:, 0] + en_d[:, 1:4].sum(1), rtol=1e-12)     # overall = loss + energies
 
 
-def test_headline_call_hebbian_window_matches_fp64_recomputation(problem, default_run):
+def test_headline_call_bucket_of_both_hebbian_kernels_agrees(problem, default_run):
+    """The tiled Hebbian GEMM runs the bf16x6 form by default (mcpc_hebbian.h: mcpc_heb6_kernel) and the fp32-MFMA form under
+    `heb_fp32=1`: same trajectories bitwise (the flush never writes state), buckets equal to fp32 summation-order noise --
+    both carry about 2e-7 of sum|terms| against fp64 (scripts/heb_bf16_ubench.hip), the window test below holds either to it."""
+    W, b, y, xs = problem
+    _, out_d, _, flat_d = default_run
+    eng = _engine(W, b, y, tuning="heb_fp32=1")
+    _, out_f, flat_f = _headline_call(eng, xs)
+    eng.close()
+    for a, c in zip(out_d, out_f):
+        assert torch.equal(a, c)
+    assert not torch.equal(flat_d, flat_f)            # the key does select another kernel
+    off = 0
+    for j in range(4):
+        for n in (W[j].numel(), b[j].numel()):
+            d, f = flat_d[off:off + n].double(), flat_f[off:off + n].double()
+            scale = float(f.abs().max())
+            if scale > 0:
+                assert float((d - f).abs().max()) <= 2e-6 * scale, (j, n, float((d - f).abs().max()) / scale)
+            else:
+                assert not bool(d.any())
+            off += n
+
+
+@pytest.mark.parametrize("tuning", [None, "heb_fp32=1"], ids=["bf16x6", "fp32"])
+def test_headline_call_hebbian_window_matches_fp64_recomputation(problem, default_run, tuning):
     W, b, y, xs = problem
     _, out_d, _, _ = default_run
     w0, w1 = 4700, 4900
-    eng = _engine(W, b, y)
+    eng = _engine(W, b, y, tuning=tuning)
     # accumulation ends at w1; every state of the window is recorded
     res_c, out_c, flat_c = _headline_call(eng, xs, acc_end=w1, rec_begin=w0, rec_stride=1, rec_count=w1 - w0)
     rec = res_c.rec_x
