@@ -25,6 +25,7 @@ mix -- on the host cores for a bounded sample.
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -40,7 +41,12 @@ S_MACS = 30 * 256 + 256 * 256 + 256 * 784          # 273 920 MACs per chain per 
 PEAK_FP32_TFLOPS = 157.3                           # MI355X_MICROARCH.md: fp32 MFMA = vector peak
 PEAK_HBM_GBS = 8000.0
 PEAK_L2_GBS = 34500.0                              # MI355X_MICROARCH.md, L2 (per XCD): ~34.5 TB/s aggregate
-FRAG_BYTES_PER_WG_STEP = 2 * 4 * (32 * 256 + 256 * 256 + 256 * 784)   # packed Wf + Wb of the three GEMM Linears (padded): 2.19 MB
+# packed Wf + Wb of the three GEMM Linears (padded), three bf16 planes per fp32 weight (csrc/mcpc_gemm6.h): 3.29 MB
+FRAG_BYTES_PER_WG_STEP = 2 * 6 * (32 * 256 + 256 * 256 + 256 * 784)
+# The step kernel computes its fp32 products as six bf16 MFMA products with fp32 accumulation: the ceiling of THAT pipe for
+# fp32-class work is the dense bf16 peak / 6 (MI355X_MICROARCH.md: 2516 TFLOP/s dense bf16).  `roofline.peak` stays the fp32 MFMA
+# peak -- the dense MFMA peak of the dtype the path computes in -- and the line carries this second ceiling beside it.
+PEAK_BF16X6_TFLOPS = 2516.0 / 6.0
 
 
 def make_problem(batch, seed, device):
@@ -202,8 +208,8 @@ def main():
     finite = all(abs(v) < 1e30 for v in en)
 
     # ---- self-check (outside the timed region): ONE call of the timed kind from the initial state, on the tuning that was
-    # timed and on the serial / plain one (no mixed schedule, one spill-ring part flushed on the caller's stream: nothing
-    # overlaps, nothing can race).  Per chain both run the same arithmetic in the same order, so the final state and the
+    # timed and on the serial / plain one (32-chain workgroups, one launch per segment, one spill-ring part flushed on the
+    # caller's stream: another workgroup form and schedule, nothing overlaps, nothing can race).  Per chain both run the same arithmetic in the same order, so the final state and the
     # records must agree BITWISE, the gradient bucket up to nothing (same 64-step Hebbian segments) and the energies up to
     # the grouping of fp32 partial sums.  What the reference defines for these: pc_trainer.py:853-862 (dF/dtheta summed over
     # accumulate_p_at), :904-914 (normalisation).
@@ -221,7 +227,7 @@ def main():
             engine.sync_check()
             return r_, st, fl
         ra, sa, fa = replay(eng)
-        serial = "no_mix=1,no_overlap=1,slot_cap=64"
+        serial = "rr=0,no_mix=1,no_overlap=1,slot_cap=64"
         eng_s = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=device, tuning=serial)
         eng_s.bind_params(W, b)
         eng_s.bind_inputs(None)
@@ -264,6 +270,8 @@ def main():
                     "frac": tf / PEAK_FP32_TFLOPS, "traffic": None, "brackets": n, "steps_per_bracket": spl,
                     "avg_bracket_ms": avg_s * 1e3, "us_per_step": avg_s / spl * 1e6,
                     "flop_per_chain_step": 4 * S_MACS,
+                    "bf16x6_pipe": {"peak": PEAK_BF16X6_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16X6_TFLOPS,
+                                    "note": "fp32 products as 6 bf16 MFMA products, fp32 accumulate: dense bf16 peak / 6"},
                     # the same launches against the HBM roofline (north_star asks for both): algorithmic streaming bytes, SURVEY 8(d)
                     "hbm_side": {"achieved": bytes_per_step * spl / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": bytes_per_step * spl / avg_s / 1e9 / PEAK_HBM_GBS, "bytes_per_chain_step": 7472},
@@ -277,11 +285,15 @@ def main():
         # 4000 Hebbian steps, one launch per half of the spill ring); algorithmic FLOPs of the STEP kernel = 4 S per chain-step
         # (the Hebbian GEMMs are a different kernel).  `traffic` (PMC) cannot be measured inside this run: the per-launch
         # figure of the same command lives in profiles/ (README there) and is deliberately not copied into this line.
+        km = re.search(r"round schedule: k=(\d+) .* m=(\d+)", q["step_kernel"])
+        wg_per_launch = q["n_workgroups"] if km is None else round(q["n_workgroups"] * int(km.group(2)) / int(km.group(1)))
         roof = kernel_line("mcpc::mcpc_steps_ws2_kernel<2, false>" if q["chains_per_wg"] == 32 else q["step_kernel"],
                            plain_l if primary_learning else plain_i, flops_inf,
-                           "HIP events around every launch of the plain schedule during the timed "
-                           + ("learning calls (Hebbian stretches; the Hebbian GEMMs of the previous segment run beside it)" if primary_learning else "inference calls"),
-                           q["n_workgroups"])
+                           "HIP events around every launch of the step kernel during the timed "
+                           + ("learning calls (mixing and Hebbian stretches alike; the Hebbian GEMMs of a segment run between and beside "
+                              "the launches of the next); a launch of the round schedule advances its workgroups' share of the shard, "
+                              "steps_per_bracket counts whole-shard steps" if primary_learning else "inference calls"),
+                           wg_per_launch)
         mixed_line = kernel_line("mcpc::mcpc_steps_ws2_mixed_kernel (mixed schedule: 32-chain and 16-chain workgroups in one launch per segment)",
                                  mixed_i if mixed_i is not None else mixed_l, flops_inf,
                                  "HIP events around whole cycles of the mixed schedule during the timed "

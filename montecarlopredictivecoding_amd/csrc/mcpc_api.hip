@@ -92,6 +92,8 @@ struct Knobs {
     int no_lean = 0;          // 1: the in-place kernel's E waves use the generic epilogues everywhere (A/B, parity tests)
     int no_ybits = 0;         // 1: 0/1 targets are read as fp32 like any other target (A/B, parity tests)
     int overlay16 = 0;        // 1: 16-chain plans share the LDS of the ring and the E_l like 32-chain plans do (A/B, parity tests)
+    int rr = 1;               // 0: shards of more 16-chain units than CUs run as 32-chain workgroups (+ the mixed schedule) instead of the round schedule (setup_rounds)
+    int rr_qmax = 100;        // round schedule: most steps per launch in stretches without Hebbian accumulation
     int heb_fp32 = 0;         // 1: the tiled Hebbian GEMM runs on the fp32 MFMA (mcpc_heb_kernel) instead of the bf16x6 form (A/B, parity tests)
 };
 
@@ -113,7 +115,7 @@ int parse_tuning(const char* str, Knobs& k) {
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
             {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"mix_pmax", &k.mix_pmax}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
-            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}, {"heb_fp32", &k.heb_fp32}};
+            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}, {"heb_fp32", &k.heb_fp32}, {"rr", &k.rr}, {"rr_qmax", &k.rr_qmax}};
         bool found = false;
         for (auto& t : table)
             if (key == t.name) { *t.dst = val; found = true; }
@@ -197,6 +199,12 @@ struct mcpc_engine {
     bool mix = false;
     int mix_ns = 0, mix_np = 0, mix_lc = 0, mix_a = 0;    // pairs split / paired per segment, segments per cycle, splits per pair per cycle
     int* mix_tab = nullptr;          // device: per segment [np pair ids][np rel][2 ns tile ids][2 ns rel]
+    // Round schedule (setup_rounds): a shard of more 16-chain units than CUs as `rr_k` launches per cycle, each unit in `rr_m` of them
+    bool rr = false;
+    int rr_k = 0, rr_m = 0;
+    std::string rr_name;                 // mcpc_step_kernel_name of an engine on the round schedule
+    std::vector<int> rr_count, rr_off;   // per launch of a cycle: workgroups, offset of its [ids][rel] rows in rr_tab
+    int* rr_tab = nullptr;
     struct Alt { int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_ws_sync = 0, lds_bytes = 0, n_phases = 0; KPhase* phases = nullptr; } alt16;
     // profiling
     bool profiling = false;
@@ -669,6 +677,62 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
     return 0;
 }
 
+// Round schedule of the in-place kernel for a shard of U 16-chain units on C < U CUs.  One unit per CU is what the kernel is built
+// for (a step is a chain of dependent hand-overs inside ONE workgroup: a second workgroup per CU does not fit the LDS, a launch of
+// U > C workgroups runs as ceil(U / C) hardware rounds, the last one mostly empty).  Instead the units are dealt into k groups and a
+// CYCLE is k launches of q steps; launch i runs groups i .. i+m-1 (mod k): every unit takes part in m of the k launches, in
+// order, and after the cycle every unit has advanced m q steps -- k / m launch times per m q steps where the hardware rounds need
+// ceil(U / C).  6000 chains = 375 units on 256 CUs: k = 3, m = 2, 250 workgroups per launch, 1.5 launch times per step instead of 2.
+// (k, m): the smallest k within 3 % of the smallest k / m over k <= 16 whose launches fit C workgroups.  Chains are independent, so the trajectories are those
+// of any other schedule, bitwise; in a Hebbian segment (m q <= slots of a ring part) every unit fills its own rows of all m q slots
+// before the flush, which therefore sees what the plain schedule would have written.
+int setup_rounds(mcpc_engine* e, int n_cu) {
+    const int U = e->nwg, C = n_cu - e->knobs.mix_slack;
+    if (U <= C || C < 1) return 0;
+    auto gsize = [&](int k, int g) { return (int)((int64_t)(g + 1) * U / k - (int64_t)g * U / k); };
+    // best m for every k <= 16, then the SMALLEST k within 3 % of the best k / m: short cycles mean long launches (a Hebbian segment is
+    // one cycle of at most `half_slots` steps) -- 300 units: (6, 5) at 1.200 rather than (13, 11) at 1.182
+    int bk = 0, bm = 0, mk[17] = {0};
+    for (int k = 2; k <= 16; ++k)
+        for (int m = k - 1; m >= 1; --m) {
+            int worst = 0;
+            for (int i = 0; i < k; ++i) { int s = 0; for (int j = 0; j < m; ++j) s += gsize(k, (i + j) % k); worst = std::max(worst, s); }
+            if (worst > C) continue;
+            mk[k] = m;
+            if (!bk || (int64_t)k * bm < (int64_t)bk * m) { bk = k; bm = m; }
+            break;
+        }
+    for (int k = 2; bk && k < bk; ++k)
+        if (mk[k] && 100.0 * k * bm <= 103.0 * bk * mk[k]) { bk = k; bm = mk[k]; break; }
+    if (!bk) { bk = (U + C - 1) / C; bm = 1; }            // more than 16 rounds: plain rounds of at most C units
+    const int k = bk, m = bm;
+    std::vector<int> tab;
+    e->rr_count.assign(k, 0); e->rr_off.assign(k, 0);
+    std::vector<int> done(k, 0);                              // launches of this cycle a group has taken part in
+    for (int i = 0; i < k; ++i) {
+        std::vector<int> ids, rel;
+        for (int j = 0; j < m; ++j) {
+            const int g = (i + j) % k;
+            for (int u = (int)((int64_t)g * U / k); u < (int)((int64_t)(g + 1) * U / k); ++u) { ids.push_back(u); rel.push_back(done[g]); }
+        }
+        for (int j = 0; j < m; ++j) ++done[(i + j) % k];
+        e->rr_off[i] = (int)tab.size(); e->rr_count[i] = (int)ids.size();
+        tab.insert(tab.end(), ids.begin(), ids.end());
+        tab.insert(tab.end(), rel.begin(), rel.end());
+    }
+    for (int g = 0; g < k; ++g)
+        if (done[g] != m) return fail(MCPC_EINVAL, "round schedule: unbalanced cycle");
+    int rc = dmalloc(e->rr_tab, tab.size());
+    if (rc) return rc;
+    if (hipMemcpy(e->rr_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(MCPC_EHIP, "hipMemcpy of the round-schedule tables failed");
+    if (hipFuncSetAttribute((const void*)mcpc_steps_ws2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess)
+        return fail(MCPC_EHIP, "hipFuncSetAttribute failed for the round schedule");
+    e->rr_k = k; e->rr_m = m; e->rr = true;
+    e->rr_name = "mcpc::mcpc_steps_ws2_kernel<1, true> (round schedule: k=" + std::to_string(k) + " launches per cycle, every 16-chain unit in m=" + std::to_string(m) + " of them)";
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -721,6 +785,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
         const int r32 = ((d->batch + 31) / 32 + n_cu - 1) / n_cu, r16 = ((d->batch + 15) / 16 + n_cu - 1) / n_cu;
         if (r32 >= 2 && r16 < 1.65 * r32 - 0.05) ct16 = true;
     }
+    if (kn.rr && want_ws) ct16 = true;                   // the round schedule: 16-chain units whatever the shard size
     if (kn.ws != -1) {
         want_ws = kn.ws;
         ct16 = kn.ct == 16;
@@ -820,6 +885,9 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if (herr != hipSuccess) return bail(fail(MCPC_EHIP, "hipFuncSetAttribute(%d bytes LDS) failed: %s", e->lds_bytes, hipGetErrorString(herr)));
     if (e->ws == 2 && e->ct == 32 && e->nwg < n_cu && !kn.no_mix) {
         if ((rc = setup_mixed_schedule(e, n_cu))) return bail(rc);
+    }
+    if (e->ws == 2 && e->ct == 16 && e->nwg > n_cu && kn.rr) {
+        if ((rc = setup_rounds(e, n_cu))) return bail(rc);
     }
     *out = e;
     return MCPC_OK;
@@ -1374,6 +1442,28 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         HIP_TRY(hipGetLastError());
         return 0;
     };
+    // one cycle of the round schedule (setup_rounds): rr_k launches of q steps, every unit in rr_m of them; afterwards every
+    // unit is at t0 + rr_m q.  `base` carries the spill pointers of the ring part in a Hebbian segment.
+    bool rr_ok = e->rr && r->update_x;
+#ifdef MCPC_STAMPS
+    rr_ok = false;
+#endif
+    auto run_round_cycle = [&](const KParams& base, int t0, int q) -> int {
+        KParams Q = base;
+        Q.t0 = t0; Q.spill_t0 = t0; Q.n_steps = q; Q.mix_ms = q; Q.mix_mp = 0;
+        const int s0 = t0 - r->t_begin;
+        Q.adam_coef = r->xopt_kind == MCPC_XOPT_ADAM ? e->adam_coef + 2 * (size_t)s0 : nullptr;
+        if (r->noise_mode == MCPC_NOISE_EXTERNAL)
+            for (int l = 0; l < e->L; ++l) Q.layer[l].ext_noise = r->ext_noise[l] + (size_t)s0 * e->d.batch * e->d.sizes[l];
+        for (int i = 0; i < e->rr_k; ++i) {
+            Q.wg_list = e->rr_tab + e->rr_off[i]; Q.wg_rel = Q.wg_list + e->rr_count[i];
+            { const int rc = prof_begin(); if (rc) return rc; }
+            hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1, true>), dim3(e->rr_count[i]), dim3(kWs2Threads), e->lds_bytes, stream, Q);
+            { const int rc = prof_end((double)q * e->rr_count[i] / e->nwg); if (rc) return rc; }
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
     while (t < end) {
         const bool in_acc = t >= acc_b && t < acc_e;
         int n;
@@ -1403,6 +1493,20 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             }
             if (n == 0) continue;
         }
+        int rr_q = 0;
+        if (rr_ok && in_acc) {
+            rr_q = n / e->rr_m;                               // a Hebbian segment is one cycle (fewer steps than rr_m left: plain launch)
+            if (rr_q >= 1) n = rr_q * e->rr_m;
+        } else if (rr_ok) {
+            // whole cycles, longest launches first; fewer than rr_m steps left run as one plain launch (hardware rounds)
+            while (n >= e->rr_m) {
+                const int q = std::min(std::max(1, e->knobs.rr_qmax), n / e->rr_m);
+                const int rc = run_round_cycle(P, t, q);
+                if (rc) return rc;
+                t += q * e->rr_m; n -= q * e->rr_m;
+            }
+            if (n == 0) continue;
+        }
         const int slot0 = in_acc && overlap ? half * e->half_slots : 0;
         P.t0 = t; P.n_steps = n; P.spill_t0 = t;
         const int s0 = t - r->t_begin;
@@ -1419,6 +1523,10 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             // this half of the ring may still be read by the flush that was started two segments ago
             if (overlap && e->flush_pending[half]) { HIP_TRY(hipStreamWaitEvent(stream, e->ev_flush[half], 0)); e->flush_pending[half] = false; }
         }
+        if (rr_q >= 1) {
+            const int rc = run_round_cycle(P, t, rr_q);
+            if (rc) return rc;
+        } else {
         { const int rc = prof_begin(); if (rc) return rc; }
         if (e->ws == 2 && e->ct == 16) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
         else if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
@@ -1426,6 +1534,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         else if (e->nw == 8) hipLaunchKernelGGL((mcpc_steps_kernel<2, 8>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
         else hipLaunchKernelGGL((mcpc_steps_kernel<2, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
         { const int rc = prof_end((double)n); if (rc) return rc; }
+        }
         HIP_TRY(hipGetLastError());
 #ifdef MCPC_STAMPS
         {
@@ -1627,6 +1736,7 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
 
 const char* mcpc_step_kernel_name(const mcpc_engine* e) {
     if (!e) return "";
+    if (e->rr) return e->rr_name.c_str();
     if (e->ws == 2 && e->mix) return "mcpc::mcpc_steps_ws2_kernel<2, false> (Hebbian stretches) / mcpc_steps_ws2_mixed_kernel (mixed schedule of inference stretches)";
     if (e->ws == 2) return e->ct == 16 ? "mcpc::mcpc_steps_ws2_kernel<1, false>" : "mcpc::mcpc_steps_ws2_kernel<2, false>";
     if (e->ct == 16) return "mcpc::mcpc_steps_kernel<1, 4>";

@@ -1,6 +1,5 @@
-// OPTIONAL GEMM core of the step kernels (-DMCPC_GEMM_BF16X6), "bf16x6" form: fp32 products on the bf16 matrix pipe (mcpc_bf16x6.h).
-// NOT the shipped default: see DESIGN.md section 4, "K1, round 3" for what it measured (inference calls 13 % faster, learning calls
-// 5 % slower at cfg-M, a register budget with no slack) and why the fp32-MFMA core stays.
+// GEMM core of the step kernels, "bf16x6" form: fp32 products on the bf16 matrix pipe (mcpc_bf16x6.h).  The default;
+// -DMCPC_GEMM_FP32 selects the v_mfma_f32_16x16x4_f32 core in mcpc_kernels.h instead.
 //
 // Every contraction of a Langevin step is out^T[unit][chain] = W[unit][k] . act^T[k][chain] in fp32.  On gfx950 the fp32 MFMA
 // (v_mfma_f32_16x16x4_f32) runs at the vector rate, 157 TFLOP/s; the bf16 MFMA (v_mfma_f32_16x16x32_bf16, fp32 accumulate) at 16

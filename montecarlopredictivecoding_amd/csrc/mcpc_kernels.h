@@ -8,6 +8,9 @@
 //                         activation) rows, split-K with deterministic slab reduction.
 //                         replaces the parameter part of overall.backward(), pc_trainer.py:862.
 #pragma once
+#if !defined(MCPC_GEMM_FP32) && !defined(MCPC_GEMM_BF16X6)
+#define MCPC_GEMM_BF16X6 1
+#endif
 #include "mcpc_device.h"
 #include "mcpc_bf16x6.h"
 #include "../../include/mcpc.h"
@@ -215,8 +218,8 @@ __device__ __forceinline__ void issue_epilogue_loads(const KParams& P, const KPh
 }
 
 // ---- GEMM core ------------------------------------------------------------------------------------------------------------
-// Default: v_mfma_f32_16x16x4_f32 (exact fp32).  -DMCPC_GEMM_BF16X6 builds the step kernels on fp32 products emulated in-class on the
-// bf16 matrix pipe instead (mcpc_gemm6.h; A/B runs: `make variant VARNAME=b6 VARFLAGS=-DMCPC_GEMM_BF16X6`).  Both expose
+// Default: fp32 products emulated in-class on the bf16 matrix pipe (mcpc_gemm6.h, mcpc_bf16x6.h).  -DMCPC_GEMM_FP32 builds the round-1/2
+// core on v_mfma_f32_16x16x4_f32 instead (A/B runs: `make variant VARNAME=fp32 VARFLAGS=-DMCPC_GEMM_FP32`).  Both expose
 //   frag_t, kKB (k-depth of a fragment block), kFragBlock (16-byte units per tile and block), frag_zero, load_frag,
 //   gemm_tiles, prefetch_first_blocks
 // and read the B operand from the same fp32 LDS rows.

@@ -68,8 +68,8 @@ template <int ACT> __device__ __forceinline__ f32x4 act4(f32x4 x) {
 // ---- FWD entry (layer l): e_l = c_l (x_l - mu_l), energies, E_l -> LDS, Hebbian spills ------------------------------
 // mu_l = acc (from G, in LDS at out_lds) + bias for l >= 1; the constant mu_1 row for l == 0 (no GEMM).
 // e0acc: Linear 0 sees a constant input, so only sum_t e_1 is needed for its Hebbian sums; when the top layer has at most
-// one tile per wave (n_1 <= 64) the sum of a launch's accumulating steps is kept in registers and added to the global
-// running sum once, after the step loop (lean_flush_e0), instead of a global read-modify-write in every step.
+// one tile per wave (n_1 <= 64) the running sum is held in registers for the whole launch (lean_load_e0 / lean_flush_e0)
+// instead of a global read-modify-write in every step.
 template <int CTT, int NW, int NTW, int ACT>
 __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
                                           int slot, int rec_idx, const int* prog_g, int need, int* err, int& dead,
@@ -153,17 +153,25 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
     return esum;
 }
 
-// after the step loop: e0sum[chain][unit] += the launch's register sums (wave kk owns tile kk of the top layer)
+// The running sum e0sum[chain][unit] of this wave's tile (wave kk owns tile kk of the top layer) is READ into the registers
+// before the step loop and WRITTEN back after it: every chain's sum is then one sequential fp32 chain over its steps, whatever the
+// launches a call is cut into (plain segments, the cycles of the round schedule) -- adding a launch's partial sum to the global
+// value instead made the result depend on where the launches end.
+template <int CTT>
+__device__ __forceinline__ void lean_load_e0(const KParams& P, int kk, const LeanLane<CTT>& L, f32x4 (&e0acc)[CTT]) {
+    const KLayer& Ly = P.layer[0];
+    if (kk >= Ly.ntiles) return;
+    const uint32_t npad4 = 4u * (uint32_t)Ly.npad;
+#pragma unroll
+    for (int ct = 0; ct < CTT; ++ct) e0acc[ct] = gld4s(Ly.spill_e, mul24(L.chain[ct], npad4) + 16u * L.q + 64u * (uint32_t)kk);
+}
 template <int CTT>
 __device__ __forceinline__ void lean_flush_e0(const KParams& P, int kk, const LeanLane<CTT>& L, const f32x4 (&e0acc)[CTT]) {
     const KLayer& Ly = P.layer[0];
     if (kk >= Ly.ntiles) return;
     const uint32_t npad4 = 4u * (uint32_t)Ly.npad;
 #pragma unroll
-    for (int ct = 0; ct < CTT; ++ct) {
-        const uint32_t off = mul24(L.chain[ct], npad4) + 16u * L.q + 64u * (uint32_t)kk;
-        gst4s(Ly.spill_e, off, gld4s(Ly.spill_e, off) + e0acc[ct]);
-    }
+    for (int ct = 0; ct < CTT; ++ct) gst4s(Ly.spill_e, mul24(L.chain[ct], npad4) + 16u * L.q + 64u * (uint32_t)kk, e0acc[ct]);
 }
 
 // ---- BWD entry (layer l): x_l <- x_l - lr (e_l + sign f'(x_l) back) [+ Philox kick], f(x_l new) -> FX_l ---------------

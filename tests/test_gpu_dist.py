@@ -146,7 +146,7 @@ def test_mixed_schedule_stays_ahead_of_the_plain_schedule_beside_an_rccl_group()
         torch.cuda.synchronize()
         W, b, y, xs = make_problem(6000, 30, torch.device(DEV))
         per_step = {}
-        for key, tuning in (("mixed", None), ("plain", "no_mix=1")):
+        for key, tuning in (("mixed", "ws=2,ct=32"), ("plain", "ws=2,ct=32,no_mix=1")):
             eng = Engine([30, 256, 256], [L.ACT_RELU] * 3, 30, 784, 6000, device=DEV, tuning=tuning)
             eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
             best = float("inf")

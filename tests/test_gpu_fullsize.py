@@ -23,6 +23,11 @@ def _problem(batch=B, seed=30):
     return make_problem(batch, seed, DEV)
 
 
+# The mixed schedule belongs to the 32-chain workgroup form, which default plans no longer choose (shards of more units than CUs run
+# the round schedule of 16-chain workgroups): its tests select it explicitly, with the rate ratio their mirror of the plan assumes.
+MIXED_TUNING = "ws=2,ct=32,mix_ratio=17"
+
+
 def _engine(batch, W, b, y, **kw):
     from montecarlopredictivecoding_amd import _lib as L
     from montecarlopredictivecoding_amd.engine import Engine
@@ -97,7 +102,7 @@ def test_other_full_size_modes_match_oracle_on_a_chain_subset(act, loss, sizes, 
     a_dev = L.ACT_TANH if act == "tanh" else L.ACT_RELU
     a_ora = mo.ACT_TANH if act == "tanh" else mo.ACT_RELU
     eng = Engine(sizes, [a_dev] * 3, sizes[0], N_OUT, batch, device=DEV)
-    assert eng.query()["chains_per_wg"] == 32
+    assert eng.query()["chains_per_wg"] == 16 and "round schedule" in eng.query()["step_kernel"]
     eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
     kind = {"gaussian_mask": L.LOSS_GAUSSIAN, "none": L.LOSS_NONE, "bernoulli": L.LOSS_BERNOULLI}[loss]
     T, lr = 12, 0.05
@@ -188,8 +193,7 @@ def test_mixed_schedule_matches_plain_schedule(monkeypatch):
     T = 420                                    # 400 inference steps (one cycle of (6, 10) steps per segment: 350, then plain), then 20 Hebbian steps
     outs = []
     for no_mix in (False, True):
-        if no_mix:
-            monkeypatch.setenv("MCPC_TUNING", "no_mix=1")
+        monkeypatch.setenv("MCPC_TUNING", MIXED_TUNING + (",no_mix=1" if no_mix else ""))
         eng = _engine(B, W, b, y)
         res, out = _run(eng, xs, T, acc_begin=400, acc_end=T, rec_begin=0, rec_stride=60, rec_count=7, rec_x=True)
         outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x],
@@ -215,8 +219,7 @@ def test_mixed_schedule_all_segment_sizes_match_plain_schedule(monkeypatch):
     assert _mixed_plan(B, T) == (2, 4712 + 1353, [80, 23])
     outs = []
     for no_mix in (False, True):
-        if no_mix:
-            monkeypatch.setenv("MCPC_TUNING", "no_mix=1")
+        monkeypatch.setenv("MCPC_TUNING", MIXED_TUNING + (",no_mix=1" if no_mix else ""))
         eng = _engine(B, W, b, y)
         eng.set_profiling(True)
         res, out = _run(eng, xs, T, rec_begin=0, rec_stride=277, rec_count=23, rec_x=True)
@@ -243,8 +246,7 @@ def test_mixed_schedule_other_shard_sizes(batch, T, monkeypatch):
     assert (cycles > 0) == (batch != 8000) and steps <= T
     outs = []
     for no_mix in (False, True):
-        if no_mix:
-            monkeypatch.setenv("MCPC_TUNING", "no_mix=1")
+        monkeypatch.setenv("MCPC_TUNING", MIXED_TUNING + (",no_mix=1" if no_mix else ""))
         eng = _engine(batch, W, b, y)
         eng.set_profiling(True)
         res, out = _run(eng, xs, T, rec_begin=0, rec_stride=97, rec_count=(T + 96) // 97, rec_x=True)
@@ -338,8 +340,7 @@ def test_mixed_schedule_with_per_step_tables(mode, monkeypatch):
         kw = dict(noise_mode=L.NOISE_EXTERNAL, ext_noise=ext, noise_var=2.0, lr=0.03)
     outs = []
     for no_mix in (False, True):
-        if no_mix:
-            monkeypatch.setenv("MCPC_TUNING", "no_mix=1")
+        monkeypatch.setenv("MCPC_TUNING", MIXED_TUNING + (",no_mix=1" if no_mix else ""))
         eng = _engine(B, W, b, y)
         res, out = _run(eng, xs_small, T, **kw)
         outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out]))
@@ -483,26 +484,30 @@ def test_oversized_networks_are_rejected_not_miscomputed():
         Engine([4] * 7, [0] * 7, 4, 0, 8, device=DEV)
 
 
-def test_shards_of_several_rounds_pick_the_cheaper_workgroup_form():
-    """More chains than one round of 32-chain workgroups covers: 9000 chains are 2 rounds of 32-chain workgroups or 3 of 16-chain
-    ones, which are 1.65x shorter -- the engine picks the 16-chain form; 16 384 chains (2 rounds against 4) keep the 32-chain form.
-    Per chain the two forms compute the same thing: states bitwise equal to the forced other form."""
+def test_shards_of_several_rounds_keep_sixteen_chain_workgroups():
+    """Default plans use 16-chain workgroups whatever the shard size (shards of more units than CUs run the round schedule,
+    tests/test_gpu_rounds.py); `rr=0` restores the older choice between the forms by their hardware rounds -- 9000 chains: 3 rounds
+    of 16-chain workgroups against 2 of 32-chain ones, the former 1.65x shorter each; 16 384 chains (4 against 2) 32-chain.  Per
+    chain all of them compute the same thing: states bitwise equal."""
     from montecarlopredictivecoding_amd import _lib as L
     W, b, y, xs = _problem(9000)
     outs = []
-    for tuning, want in ((None, 16), ("ws=2,ct=32", 32)):
+    for tuning, want in ((None, 16), ("rr=0", 16), ("ws=2,ct=32", 32)):
         eng = _engine(9000, W, b, y, tuning=tuning)
         assert eng.query()["chains_per_wg"] == want
+        assert ("round schedule" in eng.query()["step_kernel"]) == (tuning is None)
         res, out = _run(eng, xs, 12, acc_begin=4, acc_end=12)
         outs.append(([o.cpu().numpy() for o in out], res.energies.cpu().numpy()))
         eng.close()
-    for a, c in zip(outs[0][0], outs[1][0]):
-        assert np.array_equal(a, c)
-    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=2e-6)
+    for other in outs[1:]:
+        for a, c in zip(outs[0][0], other[0]):
+            assert np.array_equal(a, c)
+        np.testing.assert_allclose(outs[0][1], other[1], rtol=2e-6)
     from montecarlopredictivecoding_amd.engine import Engine
-    eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, 16384, device=DEV)
-    assert eng.query()["chains_per_wg"] == 32
-    eng.close()
+    for tuning, want in ((None, 16), ("rr=0", 32)):
+        eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, 16384, device=DEV, tuning=tuning)
+        assert eng.query()["chains_per_wg"] == want
+        eng.close()
 
 
 def test_sixteen_chain_plans_with_and_without_the_shared_lds_region_agree():

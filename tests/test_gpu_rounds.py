@@ -1,0 +1,142 @@
+"""The round schedule (csrc/mcpc_api.hip: setup_rounds / run_round_cycle): a shard of more 16-chain units than CUs runs as k launches
+per cycle, every unit in m of them, instead of ceil(U / CUs) hardware rounds or 32-chain workgroups.
+
+Chains are independent and every schedule runs the same per-chain arithmetic, so against
+  * the hardware rounds of the same 16-chain kernel (`ws=2,ct=16,rr=0`) and
+  * the 32-chain workgroup form with its mixed schedule (`rr=0`)
+final states and records must be BITWISE equal, energies equal up to the regrouping of fp32 partial sums, and the Hebbian sums
+bitwise (every unit has filled its own rows of a ring part before the part is flushed; the running sum of e_1 is one sequential
+chain per element whatever the launches, mcpc_ws2_lean.h: lean_load_e0).
+"""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_fullsize import B, DEV, SIZES, _engine, _problem, _run
+
+pytestmark = pytest.mark.gpu
+HW_ROUNDS = "ws=2,ct=16,rr=0"
+WG32 = "rr=0"
+
+
+def _plan(units, n_cu=256):
+    """Mirror of setup_rounds: per k <= 16 the largest m whose launches of m consecutive groups fit the CUs; the smallest k within
+    3 % of the best k / m."""
+    fit = {}
+    for k in range(2, 17):
+        sizes = [(g + 1) * units // k - g * units // k for g in range(k)]
+        for m in range(k - 1, 0, -1):
+            if max(sum(sizes[(i + j) % k] for j in range(m)) for i in range(k)) <= n_cu:
+                fit[k] = m
+                break
+    if not fit:
+        return ((units + n_cu - 1) // n_cu, 1)
+    bk = min(fit, key=lambda k: (k / fit[k], k))
+    for k in sorted(fit):
+        if k < bk and 100.0 * k * fit[bk] <= 103.0 * bk * fit[k]:
+            return (k, fit[k])
+    return (bk, fit[bk])
+
+
+def _km(eng):
+    q = eng.query()
+    mt = re.search(r"round schedule: k=(\d+) .* m=(\d+)", q["step_kernel"])
+    return (int(mt.group(1)), int(mt.group(2))) if mt else None
+
+
+def test_plan_mirror_of_known_cases():
+    assert _plan(376) == (3, 2)          # 6000 chains: 250 / 251 workgroups per launch
+    assert _plan(512) == (2, 1) and _plan(1024) == (4, 1)
+    assert _plan(300) == (6, 5)          # 1.200 launch times per step; (13, 11) would be 1.182 with launches of 5 steps in a Hebbian segment
+    assert _plan(258) == (12, 11) and _plan(3000) == (12, 1)
+
+
+@pytest.mark.parametrize("batch,T,acc0", [(6000, 331, 97), (4800, 140, 33), (4112, 90, 20), (8192, 150, 61), (12000, 70, 30)])
+def test_round_schedule_matches_other_schedules_bitwise(batch, T, acc0):
+    """A learning call (inference stretch, then Hebbian segments through the spill ring) on the default plan against the hardware
+    rounds of the 16-chain kernel and against 32-chain workgroups."""
+    W, b, y, xs = _problem(batch)
+    outs = {}
+    for key, tuning in (("rounds", None), ("hw", HW_ROUNDS), ("wg32", WG32)):
+        eng = _engine(batch, W, b, y, tuning=tuning)
+        q = eng.query()
+        if key == "rounds":
+            assert q["chains_per_wg"] == 16 and _km(eng) == _plan(q["n_workgroups"]), q
+            m = _km(eng)[1]
+        elif key == "hw":
+            assert q["chains_per_wg"] == 16 and _km(eng) is None
+        else:
+            assert _km(eng) is None
+        res, out = _run(eng, xs, T, acc_begin=acc0, acc_end=T, rec_begin=0, rec_stride=37, rec_count=(T + 36) // 37, rec_x=True)
+        outs[key] = (res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x],
+                     eng.read_param_grads_flat().cpu().numpy())
+        eng.close()
+    en = outs["rounds"][0]
+    assert np.all(np.isfinite(en))
+    np.testing.assert_allclose(en[:, -1], en[:, 0] + en[:, 1:4].sum(1), rtol=1e-12)
+    for key in ("hw", "wg32"):
+        for a, c in zip(outs["rounds"][1] + outs["rounds"][2], outs[key][1] + outs[key][2]):
+            assert np.array_equal(a, c), key
+        np.testing.assert_allclose(en, outs[key][0], rtol=2e-6)
+        if 64 % m == 0:        # Hebbian segments of 64 steps in every schedule: the flushes add the same partial sums in the same order
+            assert np.array_equal(outs["rounds"][3], outs[key][3]), key
+        else:                  # segments of m * (64 // m) steps: other partial sums of the same fp32 terms
+            scale = np.abs(outs[key][3]).max()
+            np.testing.assert_allclose(outs["rounds"][3], outs[key][3], rtol=0, atol=2e-6 * scale)
+    assert np.abs(outs["rounds"][3]).max() > 0
+
+
+@pytest.mark.parametrize("mode", ["adam", "external_noise"])
+def test_round_schedule_with_per_step_tables(mode):
+    """Adam's bias-correction table and injected normals are indexed by the step, which differs between the units of a launch of
+    the round schedule (a unit starts where its previous launch left it)."""
+    from montecarlopredictivecoding_amd import _lib as L
+    W, b, y, xs = _problem()
+    xs_small = [x * 0.1 for x in xs]
+    T = 57
+    kw = dict(noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.05)
+    if mode == "external_noise":
+        g = torch.Generator().manual_seed(3)
+        ext = [torch.randn(T, B, n, generator=g).to(DEV) for n in SIZES]
+        kw = dict(noise_mode=L.NOISE_EXTERNAL, ext_noise=ext, noise_var=2.0, lr=0.03)
+    outs = []
+    for tuning in (None, "rr_qmax=5", HW_ROUNDS):
+        eng = _engine(B, W, b, y, tuning=tuning)
+        res, out = _run(eng, xs_small, T, **kw)
+        extra = []
+        if mode == "adam":
+            m = [torch.empty_like(x) for x in xs]; v = [torch.empty_like(x) for x in xs]
+            eng.store_adam_state(m, v)
+            eng.sync_check()
+            extra = [t.cpu().numpy() for t in m + v]
+        outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out] + extra))
+        eng.close()
+    for other in outs[1:]:
+        for a, c in zip(outs[0][1], other[1]):
+            assert np.array_equal(a, c)
+        np.testing.assert_allclose(outs[0][0], other[0], rtol=2e-6)
+    assert np.all(np.isfinite(outs[0][0]))
+
+
+def test_round_schedule_sliced_calls_continue_each_other():
+    """Two calls of 40 + 53 steps (the second starts at t_begin = 40 of T = 93) against one call of 93: the cycles of a call start
+    at its own first step, so slices of any length compose."""
+    from montecarlopredictivecoding_amd import _lib as L
+    W, b, y, xs = _problem()
+    eng = _engine(B, W, b, y)
+    res, out_one = _run(eng, xs, 93)
+    en_one = res.energies.cpu().numpy()
+    eng.load_state(xs)
+    args = dict(loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=77, step_base=1000, energy_mode=L.ENERGY_ALL)
+    r1 = eng.run(93, t_begin=0, n_steps=40, **args)
+    r2 = eng.run(93, t_begin=40, n_steps=53, **args)
+    out_two = [torch.empty_like(x) for x in xs]
+    eng.store_state(out_two)
+    eng.sync_check()
+    en_two = np.concatenate([r1.energies.cpu().numpy()[:40], r2.energies.cpu().numpy()[40:]])
+    eng.close()
+    for a, c in zip(out_one, out_two):
+        assert torch.equal(a, c)
+    np.testing.assert_array_equal(en_one, en_two)
