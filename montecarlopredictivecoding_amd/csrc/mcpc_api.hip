@@ -92,6 +92,7 @@ struct Knobs {
     int no_lean = 0;          // 1: the in-place kernel's E waves use the generic epilogues everywhere (A/B, parity tests)
     int no_ybits = 0;         // 1: 0/1 targets are read as fp32 like any other target (A/B, parity tests)
     int overlay16 = 0;        // 1: 16-chain plans share the LDS of the ring and the E_l like 32-chain plans do (A/B, parity tests)
+    int no_xl = 0;            // 1: 16-chain plans keep the state and the per-step constants in global memory even when the LDS has the room (A/B, parity tests)
     int rr = 1;               // 0: shards of more 16-chain units than CUs run as 32-chain workgroups (+ the mixed schedule) instead of the round schedule (setup_rounds)
     int rr_qmax = 100;        // round schedule: most steps per launch in stretches without Hebbian accumulation
     int heb_fp32 = 0;         // 1: the tiled Hebbian GEMM runs on the fp32 MFMA (mcpc_heb_kernel) instead of the bf16x6 form (A/B, parity tests)
@@ -115,7 +116,7 @@ int parse_tuning(const char* str, Knobs& k) {
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
             {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"mix_pmax", &k.mix_pmax}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
-            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}, {"heb_fp32", &k.heb_fp32}, {"rr", &k.rr}, {"rr_qmax", &k.rr_qmax}};
+            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}, {"heb_fp32", &k.heb_fp32}, {"rr", &k.rr}, {"rr_qmax", &k.rr_qmax}, {"no_xl", &k.no_xl}};
         bool found = false;
         for (auto& t : table)
             if (key == t.name) { *t.dst = val; found = true; }
@@ -188,6 +189,8 @@ struct mcpc_engine {
     bool spill_ready = false;       // the spill ring, its stream/events and the slabs exist (allocated by the first accumulating run)
     // LDS plan
     int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_bytes = 0;
+    bool xl = false;                // 16-chain in-place plan with room: state rows, biases, mu_1 rows and target words live in LDS (KParams::xl)
+    int lds_x[kMaxLatent]{}, lds_bias[kMaxLatent]{}, lds_hbias = 0, lds_yw = 0;
     // per-step phase table (device copy)
     KPhase* phases = nullptr;
     int n_phases = 0;
@@ -335,7 +338,7 @@ int plan_lds(mcpc_engine* e) {
 // read-out) to the x updates at its end.  At cfg-M that pays for a ring of THREE chunks of 13 tiles (49 tiles =
 // 13+12+12+12; a table entry hands out up to 16 tiles, four per GEMM wave): two GEMMs of slack between a chunk's
 // epilogue and its back-projection, 15 table entries per step.
-int plan_lds_ws2(mcpc_engine* e) {
+int plan_lds_ws2(mcpc_engine* e, bool allow_xl = true) {
     const int CT = e->ct, L = e->L;
     int off = 0;
     for (int l = 0; l < L; ++l) { e->lds_a[l] = off; off += CT * (e->npad[l] + kLdPad); }
@@ -369,6 +372,21 @@ int plan_lds_ws2(mcpc_engine* e) {
         if (CT == 16 && L >= 2 && fits_apart(hc, nb) && !e->knobs.overlay16) { e->ws2_overlay = false; e->lds_eo = off + e_sum; }
     }
     off += e->ws2_overlay ? std::max(ring_floats, e_sum) : ring_floats + e_sum;
+    // with room to spare (16-chain plans: 45 KB at cfg-M) the lean epilogues keep what they read every step in LDS: the state rows
+    // X_l (layout of FX_l), the bias rows, the mu_1 rows (layout of FX_0), the read-out bias and the bit-packed target rows
+    e->xl = false;
+    if (CT == 16 && allow_xl && !e->knobs.no_xl) {
+        int extra = 0;
+        for (int l = 0; l < L; ++l) extra += CT * (e->npad[l] + kLdPad) + (l >= 1 ? e->npad[l] : CT * (e->npad[0] + kLdPad));
+        const int ywords = (e->out_pad + 31) / 32;
+        if (e->has_head) extra += e->out_pad + (CT * ywords + 3) / 4 * 4;
+        if ((off + extra) * (int)sizeof(float) <= 160 * 1024) {
+            for (int l = 0; l < L; ++l) { e->lds_x[l] = off; off += CT * (e->npad[l] + kLdPad); }
+            for (int l = 0; l < L; ++l) { e->lds_bias[l] = off; off += l >= 1 ? e->npad[l] : CT * (e->npad[0] + kLdPad); }
+            if (e->has_head) { e->lds_hbias = off; off += e->out_pad; e->lds_yw = off; off += (CT * ywords + 3) / 4 * 4; }
+            e->xl = true;
+        }
+    }
     e->lds_bytes = off * (int)sizeof(float);
     if (e->lds_bytes > 160 * 1024) return fail(MCPC_ENOMEM, "in-place schedule does not fit the LDS (%d bytes)", e->lds_bytes);
     return 0;
@@ -634,7 +652,7 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
     const int k_chunk = e->ws2_chunk, k_ring = e->ws2_ring;
     const bool k_overlay = e->ws2_overlay;
     e->ct = 16; e->phases = nullptr;
-    int rc = plan_lds_ws2(e);
+    int rc = plan_lds_ws2(e, false);
     if (!rc) rc = build_phases_ws2(e);
     mcpc_engine::Alt& a = e->alt16;
     if (!rc) {
@@ -1336,6 +1354,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         K.n = e->d.sizes[l]; K.npad = e->npad[l]; K.ntiles = e->npad[l] / 16;
         K.act = e->d.acts[l]; K.ecoef = e->d.ecoef[l];
         K.lds_a = e->lds_a[l]; K.lds_e = e->lds_e[l]; K.ld = e->npad[l] + kLdPad;
+        K.lds_x = e->lds_x[l]; K.lds_bias = e->lds_bias[l];
     }
     if (e->has_head) {
         KHead& H = P.head;
@@ -1348,6 +1367,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         H.inv_var = r->loss_kind == MCPC_LOSS_GAUSSIAN ? (float)(1.0 / (double)r->loss_var) : 1.0f;
         H.mask_start = r->loss_kind == MCPC_LOSS_NONE ? 0 : r->mask_start;
         H.lds_eo = e->lds_eo; H.ld = kChunkTiles * 16 + kLdPad;
+        H.lds_bias = e->lds_hbias; H.lds_yw = e->lds_yw;
     }
     P.mu1 = e->mu1; P.epart = e->epart; P.epart_slots = (int)eslots;
     P.phases = e->phases; P.n_phases = e->n_phases;
@@ -1371,6 +1391,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         P.lean_ok = e->Bpad < (1 << 24) && (uint64_t)e->Bpad * (uint64_t)widest * 4u < (1ull << 32) && !e->knobs.no_lean;
     }
     P.err = e->err; P.dummy = e->dummy; P.lds_floats = e->lds_bytes / 4;
+    P.xl = e->xl ? 1 : 0;
 #ifdef MCPC_STAMPS
     if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * 2 * kMaxWaves * 16); if (rc) return rc; }
     P.dbg = e->dbg;
@@ -1424,6 +1445,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         P1.head.lds_eo = e->alt16.lds_eo; P1.lds_red = e->alt16.lds_red; P1.lds_ws_sync = e->alt16.lds_ws_sync;
         P1.phases = e->alt16.phases; P1.n_phases = e->alt16.n_phases; P1.lds_floats = e->alt16.lds_bytes / 4;
         P2.t0 = P1.t0 = t0; P2.spill_t0 = P1.spill_t0 = t0;
+        P2.xl = P1.xl = 0;
         // per-step tables start at the cycle's first step; a unit indexes them with its own step minus t0
         const int s0 = t0 - r->t_begin;
         P2.adam_coef = P1.adam_coef = r->xopt_kind == MCPC_XOPT_ADAM ? e->adam_coef + 2 * (size_t)s0 : nullptr;

@@ -44,6 +44,8 @@ struct KLayer {
     float ecoef;
     int lds_a, lds_e;      // float offsets of FX_l / E_l in LDS
     int ld;                // LDS row stride (floats) = npad + kLdPad
+    int lds_x;             // KParams::xl: float offset of the state rows X_l (row stride ld)
+    int lds_bias;          // KParams::xl: float offset of the bias row [npad] (l >= 1) / of the mu_1 rows (l == 0, row stride ld)
 };
 
 struct KHead {
@@ -62,6 +64,8 @@ struct KHead {
     int mask_start;
     int lds_eo;            // float offset of the read-out error chunk
     int ld;                // its row stride = kChunkTiles*16 + kLdPad
+    int lds_bias;          // KParams::xl: float offset of the bias row [npad]
+    int lds_yw;            // KParams::xl: float offset of the bit-packed target rows [chains][ywords]
 };
 
 // One entry of the per-step phase table (built on the host, identical for every step):
@@ -131,6 +135,8 @@ struct KParams {
     int epart_slots;                 // in-place kernel: energy partials are indexed by 16-chain tile, this many per row
     int lean_ok;                     // in-place kernel: every [Bpad][npad] image is < 4 GiB and Bpad < 2^24 (32-bit lane offsets)
     const void* dummy;               // 4 KiB of valid device memory: what the branch-free fragment prefetch reads for entries without a GEMM
+    int xl;                          // in-place kernel, 16-chain plans whose LDS has the room: the state x_l, the biases, mu_1 and the bit-packed
+                                     // target of the workgroup's chains live in LDS for the whole launch (mcpc_ws2_lean.h: XL)
     int lds_floats;                  // floats of dynamic LDS of this plan (cleared once per launch: see mcpc_gemm6.h, k ranges)
 #ifdef MCPC_STAMPS
     unsigned long long* dbg;   // diagnostic build only: [nwg][kWaves][16] cycle sums per phase

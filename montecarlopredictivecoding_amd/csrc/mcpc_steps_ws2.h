@@ -147,7 +147,7 @@ __device__ __forceinline__ void ws2_prefetch(const KPhase& ph, int k, int lane, 
 }
 
 template <int ACT>
-__device__ __forceinline__ void ws2_fill_fx(const KLayer& Ly, float* lds, int chain0, int tid, int ct_rows) {
+__device__ __forceinline__ void ws2_fill_fx(const KLayer& Ly, float* lds, int chain0, int tid, int ct_rows, bool keep_x) {
     const int qpr = Ly.npad / 4;                            // quads per row
     for (int idx = tid; idx < ct_rows * qpr; idx += kWs2Threads) {
         const int r = idx / qpr, u0 = 4 * (idx - r * qpr);
@@ -155,6 +155,33 @@ __device__ __forceinline__ void ws2_fill_fx(const KLayer& Ly, float* lds, int ch
         f32x4 fx;
         fx.x = actf<ACT>(x.x); fx.y = actf<ACT>(x.y); fx.z = actf<ACT>(x.z); fx.w = actf<ACT>(x.w);
         st4(lds + Ly.lds_a + r * Ly.ld + u0, fx);
+        if (keep_x) st4(lds + Ly.lds_x + r * Ly.ld + u0, x);
+    }
+}
+
+// KParams::xl: what the epilogues of a launch read over and over and nobody else writes -- biases, the mu_1 rows and the bit-packed
+// target rows of the workgroup's chains -- copied to LDS once (the state rows X_l: ws2_fill_fx)
+__device__ __forceinline__ void ws2_fill_constants(const KParams& P, float* lds, int chain0, int tid, int ct_rows) {
+    for (int l = 1; l < P.L; ++l) {
+        const KLayer& Ly = P.layer[l];
+        for (int i = tid; i < Ly.npad / 4; i += kWs2Threads) st4(lds + Ly.lds_bias + 4 * i, ld4(Ly.bias + 4 * i));
+    }
+    {
+        const KLayer& Ly = P.layer[0];
+        const int qpr = Ly.npad / 4;
+        for (int idx = tid; idx < ct_rows * qpr; idx += kWs2Threads) {
+            const int r = idx / qpr, u0 = 4 * (idx - r * qpr);
+            st4(lds + Ly.lds_bias + r * Ly.ld + u0, ld4(P.mu1 + (size_t)(chain0 + r) * Ly.npad + u0));
+        }
+    }
+    if (P.has_head) {
+        const KHead& H = P.head;
+        for (int i = tid; i < H.npad / 4; i += kWs2Threads) st4(lds + H.lds_bias + 4 * i, ld4(H.bias + 4 * i));
+        uint32_t* const yw = reinterpret_cast<uint32_t*>(lds + H.lds_yw);
+        for (int idx = tid; idx < ct_rows * H.ywords; idx += kWs2Threads) {
+            const int r = idx / H.ywords, w = idx - r * H.ywords;
+            yw[idx] = H.ybits[(size_t)(chain0 + r) * H.ywords + w];
+        }
     }
 }
 

@@ -13,6 +13,14 @@
 //   * three loads per slot whatever the entry type   -> each entry type requests exactly its operands.
 // The arithmetic per element is the generic epilogue's, operation for operation: trajectories stay bitwise those of the
 // other kernel forms (tests/test_gpu_fullsize.py::test_workgroup_variants_agree, the mixed-schedule tests).
+//
+// XL (KParams::xl, 16-chain plans whose LDS has the room -- 45 KB more at cfg-M): the state rows x_l of the workgroup's chains, the
+// biases, the mu_1 rows and the bit-packed target rows are copied to LDS when the launch starts (ws2_fill_fx / ws2_fill_constants);
+// the epilogues read them there, the x update writes the new state there, and the rows go back to global memory once, after the
+// step loop (lean_store_x).  An E wave then issues NO global load inside the step loop.  Why that matters: a wave's vector memory
+// operations retire in order, so every operand load of an entry also waited for the Hebbian spill stores of the entry before it --
+// 12.5 us of a 96 us step in the Hebbian stretches of cfg-M (timing build without the stores: 78.5 us against 88.5 per step of a
+// learning call), and the x store / x loads of every step besides.
 #pragma once
 
 namespace mcpc {
@@ -70,7 +78,7 @@ template <int ACT> __device__ __forceinline__ f32x4 act4(f32x4 x) {
 // e0acc: Linear 0 sees a constant input, so only sum_t e_1 is needed for its Hebbian sums; when the top layer has at most
 // one tile per wave (n_1 <= 64) the running sum is held in registers for the whole launch (lean_load_e0 / lean_flush_e0)
 // instead of a global read-modify-write in every step.
-template <int CTT, int NW, int NTW, int ACT>
+template <int CTT, int NW, int NTW, int ACT, bool XL = false>
 __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
                                           int slot, int rec_idx, const int* prog_g, int need, int* err, int& dead,
                                           f32x4 (&e0acc)[CTT], bool e0_in_regs) {
@@ -93,6 +101,11 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
         const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));     // unused slots repeat slot 0
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
+            if constexpr (XL) {
+                xv[i][ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds + Ly.lds_x) + lrowb[ct] + tb);
+                bv[i][ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds + Ly.lds_bias) + (l == 0 ? lrowb[ct] : 16u * L.q) + tb);
+                (void)bsrc;
+            } else {
 #if defined(MCPC_EXP_NOX) || defined(MCPC_EXP_NOELOAD)       // timing experiment only (wrong results): the state is neither loaded nor stored
             xv[i][ct] = splat(0.5f);
 #else
@@ -103,6 +116,7 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
 #else
             bv[i][ct] = gld4(bsrc, (l == 0 ? rowb[ct] : 16u * L.q) + tb);
 #endif
+            }
         }
     }
     f32x4 av[NTW][CTT];
@@ -174,13 +188,31 @@ __device__ __forceinline__ void lean_flush_e0(const KParams& P, int kk, const Le
     for (int ct = 0; ct < CTT; ++ct) gst4s(Ly.spill_e, mul24(L.chain[ct], npad4) + 16u * L.q + 64u * (uint32_t)kk, e0acc[ct]);
 }
 
+// XL: after the step loop every E wave writes the state rows of its tiles back (the tiles its BWD entries updated: tile = kk + NW i
+// of every layer; FWD and BWD entries of a layer hand out tiles alike, rot == 0, chunk starts multiples of NW)
+template <int CTT, int NW>
+__device__ __forceinline__ void lean_store_x(const KParams& P, const float* lds, int kk, const LeanLane<CTT>& L) {
+    for (int l = 0; l < P.L; ++l) {
+        const KLayer& Ly = P.layer[l];
+        const uint32_t npad4 = 4u * (uint32_t)Ly.npad;
+        for (int tile = kk; tile < Ly.ntiles; tile += NW) {
+#pragma unroll
+            for (int ct = 0; ct < CTT; ++ct) {
+                const uint32_t lb = mul24(L.lrow[ct], 4u * (uint32_t)Ly.ld) + 16u * L.q + 64u * (uint32_t)tile;
+                gst4s(Ly.x, mul24(L.chain[ct], npad4) + 16u * L.q + 64u * (uint32_t)tile,
+                      *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds + Ly.lds_x) + lb));
+            }
+        }
+    }
+}
+
 // ---- BWD entry (layer l): x_l <- x_l - lr (e_l + sign f'(x_l) back) [+ Philox kick], f(x_l new) -> FX_l ---------------
 // back = acc from G (GEMM over E_{l+1}, or the read-out back-projection handed over in registers); none for sign == 0.
 // ADAM (the MAP warm-up, torch.optim.Adam on x without noise): the moments m, v of the wave's tiles are requested with x,
 // in front of the wait for the partner's block -- the generic epilogue loads them behind it, one L2/HBM round trip exposed
 // per x update -- and the arithmetic is the generic epilogue's, operation for operation (s_tab: row of the bias-correction
 // table).
-template <int CTT, int NW, int NTW, int ACT, bool NOISE, bool ADAM = false>
+template <int CTT, int NW, int NTW, int ACT, bool NOISE, bool ADAM = false, bool XL = false>
 __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
                                          int t, const int* prog_g, int need, int* err, int& dead, int s_tab = 0) {
     static_assert(!(NOISE && ADAM), "Adam with the fused kick takes the generic epilogue");
@@ -205,11 +237,15 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
         const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
+            if constexpr (XL) {
+                xv[i][ct] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds + Ly.lds_x) + lrowb[ct] + tb);
+            } else {
 #if defined(MCPC_EXP_NOX) || defined(MCPC_EXP_NOELOAD)
             xv[i][ct] = splat(0.5f);
 #else
             xv[i][ct] = gld4s(Ly.x, rowb[ct] + tb);
 #endif
+            }
             if constexpr (ADAM) {
                 mv[i][ct] = gld4s(Ly.m, rowb[ct] + tb);
                 vv[i][ct] = gld4s(Ly.v, rowb[ct] + tb);
@@ -217,7 +253,10 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
 #ifdef MCPC_EXP_NOELOAD
             if (l == 0) ev[i][ct] = (xv[i][ct] - splat(0.25f)) * ecoef;
 #else
-            if (l == 0) ev[i][ct] = (xv[i][ct] - gld4(P.mu1, rowb[ct] + tb)) * ecoef;       // e_1 = c_1 (x_1 - mu_1), mu_1 constant
+            if (l == 0) {                                                               // e_1 = c_1 (x_1 - mu_1), mu_1 constant
+                if constexpr (XL) ev[i][ct] = (xv[i][ct] - *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds + Ly.lds_bias) + lrowb[ct] + tb)) * ecoef;
+                else ev[i][ct] = (xv[i][ct] - gld4(P.mu1, rowb[ct] + tb)) * ecoef;
+            }
 #endif
             else if constexpr (!ADAM) ev[i][ct] = *reinterpret_cast<const f32x4*>(e_lds + lrowb[ct] + tb);
         }
@@ -287,16 +326,22 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
                 if (u0 + 2 >= n) xn.z = 0.f;
                 if (u0 + 3 >= n) xn.w = 0.f;
             }
+            if constexpr (XL) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds + Ly.lds_x) + lrowb[ct] + tb) = xn;
+            } else {
 #ifndef MCPC_EXP_NOX
             gst4s(Ly.x, rowb[ct] + tb, xn);
 #endif
+            }
             *reinterpret_cast<f32x4*>(fx_lds + lrowb[ct] + tb) = act4<ACT>(xn);      // the next step's GEMMs read f(x_new) from FX_l
         }
     }
 }
 
 // ---- HEADF entry (read-out chunk): out = acc + bias, e_o = dL/dout -> ring slot (LDS), loss, spills, output records -----
-template <int CTT, int NW, int NTW>
+// XL: bias from LDS; YB (with XL only): the target is 0/1, its words come from LDS and no fp32 target is requested -- a compile-time
+// choice, so that the 0/1 case holds no global load at all (see the note on loads under an `if` below).
+template <int CTT, int NW, int NTW, bool XL = false, bool YB = false>
 __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
                                             int slot, int rec_idx, bool do_energy, const int* prog_g, int need, int* err, int& dead,
                                             bool ybin) {
@@ -317,13 +362,25 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
     for (int i = 0; i < NTW; ++i) {
         const int tile = ph.tile0 + kk + NW * (i < nt ? i : 0);
         const uint32_t tb = 64u * (uint32_t)tile;
+        if constexpr (XL) {
+            bv[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds + H.lds_bias) + 16u * L.q + tb);
+        } else {
 #ifdef MCPC_EXP_NOELOAD
         bv[i] = splat(0.25f);
 #else
         bv[i] = gld4(H.bias, 16u * L.q + tb);
 #endif
+        }
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
+            if constexpr (XL && YB) {
+                yv[i][ct] = splat(0.f);
+                yw[i][ct] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds + H.lds_yw) + mul24(L.lrow[ct], wrow4) + 4u * (uint32_t)(tile >> 1));
+            } else if constexpr (XL) {
+                const bool has_y = kind != MCPC_LOSS_NONE;
+                yv[i][ct] = gld4s(has_y ? H.y : H.bias, has_y ? rowb[ct] + tb : 16u * L.q + tb);
+                yw[i][ct] = 0u;
+            } else {
             // Branch-free on purpose (a load under an `if` makes hipcc join the paths behind `s_waitcnt vmcnt(0)`, which here
             // would also wait for every spill store still in flight): both loads are always issued; the one that is not
             // needed reads a harmless hot address (the bias row again / the word array, which always exists).
@@ -335,6 +392,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
             yw[i][ct] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(
                 (gbytes_t)H.ybits + mul24(L.chain[ct], wrow4) + 4u * (uint32_t)(tile >> 1));
 #endif
+            }
         }
     }
     ws_wait_one(prog_g, need, err, dead);
