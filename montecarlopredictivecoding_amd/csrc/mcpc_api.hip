@@ -1392,6 +1392,12 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     }
     P.err = e->err; P.dummy = e->dummy; P.lds_floats = e->lds_bytes / 4;
     P.xl = e->xl ? 1 : 0;
+    {
+        // bytes of Hebbian spill per step: beyond 8 MB (a quarter of the eight 4 MB L2s) the stores go out at system scope
+        size_t per_step = (size_t)e->Bpad * e->out_pad;
+        for (int l = 0; l < e->L; ++l) per_step += (size_t)e->Bpad * e->npad[l] * (l >= 1 ? 2 : 1);
+        P.spill_sys = per_step * sizeof(float) > ((size_t)8 << 20) ? 1 : 0;
+    }
 #ifdef MCPC_STAMPS
     if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * 2 * kMaxWaves * 16); if (rc) return rc; }
     P.dbg = e->dbg;

@@ -137,6 +137,7 @@ struct KParams {
     const void* dummy;               // 4 KiB of valid device memory: what the branch-free fragment prefetch reads for entries without a GEMM
     int xl;                          // in-place kernel, 16-chain plans whose LDS has the room: the state x_l, the biases, mu_1 and the bit-packed
                                      // target of the workgroup's chains live in LDS for the whole launch (mcpc_ws2_lean.h: XL)
+    int spill_sys;                   // Hebbian spill stores at system scope (write-through): shards whose spill per step is far beyond the L2s
     int lds_floats;                  // floats of dynamic LDS of this plan (cleared once per launch: see mcpc_gemm6.h, k ranges)
 #ifdef MCPC_STAMPS
     unsigned long long* dbg;   // diagnostic build only: [nwg][kWaves][16] cycle sums per phase

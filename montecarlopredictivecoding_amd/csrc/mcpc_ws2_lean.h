@@ -39,22 +39,26 @@ __device__ __forceinline__ void gst4s(float* base, uint32_t boff, f32x4 v) {
 }
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 
-// Hebbian spill store through a buffer descriptor (wave-uniform base, 32-bit lane offset, selectable cache policy).  The
-// data is read next by another kernel on other CUs, so write-through / no-allocate policies were tried to keep the 5.6 MB
-// of spill per step and XCD out of the L2 that holds the 2.2 MB of packed weights: they measured 0.4 us per step SLOWER than
-// plain write-back stores (a wave's loads wait for its older stores in vmcnt order, and write-back stores retire sooner).
+// Hebbian spill store through a buffer descriptor (wave-uniform base, 32-bit lane offset, selectable cache policy).  The data is
+// read next by another kernel on other CUs, and 44 MB of it per step flow through L2s of 4 MB that hold the 3.3 MB of packed
+// weights every GEMM wave streams.  Round 2 (epilogue loads still queued behind these stores in the wave's vector-memory order):
+// plain write-back stores were 0.4 us per step faster than any other policy.  Round 3 (no global loads left in the epilogue waves,
+// XL): system-scope stores -- sc1, with or without sc0 / nt -- take the learning call of cfg-M from 80.4-81.1 to 77.6-78.0 us
+// per step, nt alone or sc0 nt do not; not issuing the stores at all: 71.7.  A shard of 256 chains, whose spill never leaves the
+// L2, loses 6 % with them (24.4 -> 25.8 us per step of a learning call): `sys` (KParams::spill_sys, wave-uniform) chooses.
 #ifndef MCPC_SPILL_AUX
-#define MCPC_SPILL_AUX 0           // 0 = plain (write-back); 2 = nt; 16 = sc1; 17 = sc0 sc1: within 0.5 us per step of each other, plain fastest
+#define MCPC_SPILL_AUX 19          // gfx950 cache-policy bits of the store: 1 = sc0, 2 = nt, 16 = sc1; 0 = plain write-back; < 0: global nontemporal store
 #endif
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void spill_st4(float* base, uint32_t image_bytes, uint32_t boff, f32x4 v) {
+__device__ __forceinline__ void spill_st4(float* base, uint32_t image_bytes, uint32_t boff, f32x4 v, bool sys = true) {
 #ifdef MCPC_EXP_NOSPILL        // timing experiment only (wrong Hebbian sums): the spill stores are not issued
-    (void)base; (void)image_bytes; (void)boff; (void)v;
+    (void)base; (void)image_bytes; (void)boff; (void)v; (void)sys;
 #elif MCPC_SPILL_AUX < 0
-    gst4s(base, boff, v);
+    gst4s(base, boff, v); (void)sys;
 #else
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)image_bytes, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)boff, 0, MCPC_SPILL_AUX);
+    if (sys) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)boff, 0, MCPC_SPILL_AUX);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)boff, 0, 0);
 #endif
 }
 
@@ -141,6 +145,7 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
     float* const spill_e = slot >= 0 ? (l > 0 ? Ly.spill_e + (size_t)slot * P.Bpad * Ly.npad : Ly.spill_e) : nullptr;
     float* const rec = (rec_idx >= 0 && Ly.rec != nullptr) ? Ly.rec + (size_t)rec_idx * P.B * Ly.n : nullptr;
     const uint32_t img_bytes = (uint32_t)P.Bpad * npad4;               // one [Bpad][npad] image (lean_ok: < 4 GiB)
+    const bool sys = P.spill_sys != 0;
     float esum = 0.f;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
@@ -154,8 +159,8 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
             const f32x4 e = d * ecoef;
             if (l > 0) *reinterpret_cast<f32x4*>(e_lds + lrowb[ct] + tb) = e;
             if (slot >= 0) {
-                spill_st4(spill_a, img_bytes, rowb[ct] + tb, act4<ACT>(x));
-                if (l > 0) spill_st4(spill_e, img_bytes, rowb[ct] + tb, e);
+                spill_st4(spill_a, img_bytes, rowb[ct] + tb, act4<ACT>(x), sys);
+                if (l > 0) spill_st4(spill_e, img_bytes, rowb[ct] + tb, e, sys);
                 else if (e0_in_regs) e0acc[ct] = e0acc[ct] + e;                          // (one tile per wave: i == 0 only)
                 else gst4s(spill_e, rowb[ct] + tb, gld4s(spill_e, rowb[ct] + tb) + e);   // Linear 0: only sum_t e_1 is needed
             }
@@ -464,7 +469,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                 e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
             }
             *reinterpret_cast<f32x4*>(eo + orowb[ct] + cb) = e;
-            if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, rowb[ct] + tb, e);
+            if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, rowb[ct] + tb, e, P.spill_sys != 0);
             if (rec != nullptr) st_unpadded(rec, (int)L.chain[ct], H.n, 16 * tile + 4 * L.q, o);
         }
     }
