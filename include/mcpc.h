@@ -88,7 +88,10 @@ typedef struct mcpc_net_desc {
     const char* tuning;                  /* NULL, or developer overrides of the schedule heuristics as "key=value,key=value"
                                           * (parsed once by mcpc_create, not kept): ws=0|2 step kernel (barrier / in-place),
                                           * ct=16|32 chains per workgroup, nw=4|8, no_mix=1, no_overlap=1, slot_cap=N,
-                                          * spill_gb=N, ring_parts=N, flush_tail=N, flush_streams=1|2, mix_slack=N, mix_ratio=N, mix_pmax=N, dw_ksplit=N, ws_prio=0|1|2, stagger=N, no_lean=1, no_ybits=1, overlay16=1, heb_fp32=1 (the Hebbian GEMM on the fp32 MFMA instead of its bf16x6 form).  Unknown keys are
+                                          * spill_gb=N, ring_parts=N, flush_tail=N, flush_streams=1|2, mix_slack=N, mix_ratio=N, mix_pmax=N, dw_ksplit=N, ws_prio=0|1|2, stagger=N, no_lean=1, no_ybits=1, overlay16=1, heb_fp32=1 (the Hebbian GEMM on the fp32 MFMA instead of its bf16x6 form),
+                                          * rr=0 (shards of more 16-chain units than CUs as 32-chain workgroups + the mixed schedule instead of the round
+                                          * schedule), rr_qmax=N (most steps per launch of the round schedule), no_xl=1 (state and per-step constants of a
+                                          * workgroup's chains in global memory instead of LDS).  Unknown keys are
                                           * an error.  Used by A/B runs and by the tests that pin every kernel variant. */
 } mcpc_net_desc;
 
@@ -206,11 +209,12 @@ const char* mcpc_step_kernel_name(const mcpc_engine* e);
 
 /* Timing hooks.  While profiling is enabled (mcpc_set_profiling(e, 1); every call of it resets the tallies), mcpc_run
  * brackets with HIP events on its stream
- *   - every step-kernel launch of the plain schedule (all Hebbian stretches, plain inference stretches), and
- *   - every whole CYCLE of the mixed 32-/16-chain schedule (inference stretches of a shard that leaves CUs idle; a segment
- *     of a cycle is ONE launch of mcpc_steps_ws2_mixed_kernel, a cycle is up to a few hundred of them back to back).
+ *   - every step-kernel launch of the plain schedule and of the round schedule (a launch of the round schedule advances only the
+ *     workgroups it holds: it counts as steps x workgroups / all workgroups whole-shard steps), and
+ *   - every whole CYCLE of the mixed 32-/16-chain schedule (tuning rr=0: inference stretches of a shard that leaves CUs idle; a
+ *     segment of a cycle is ONE launch of mcpc_steps_ws2_mixed_kernel, a cycle is up to a few hundred of them back to back).
  * The two getters synchronise on the recorded events and return the summed time, the number of brackets and the
- * whole-shard steps they cover, accumulated over all runs since profiling was enabled (at most 65 536 brackets per set). */
+ * whole-shard steps they cover (rounded down), accumulated over all runs since profiling was enabled (at most 65 536 brackets per set). */
 int mcpc_set_profiling(mcpc_engine* e, int enable);
 int mcpc_last_step_kernel_ms(mcpc_engine* e, float* ms, int32_t* n_launches, int64_t* n_steps);
 int mcpc_last_mixed_cycles_ms(mcpc_engine* e, float* ms, int32_t* n_cycles, int64_t* n_steps);

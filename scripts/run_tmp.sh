@@ -1,2 +1,6 @@
-python3 scripts/quick.py 1000 1024 2>&1 | grep -v amdgpu
-timeout -k 10 1000 python -m pytest tests -q -m gpu 2>&1 | tail -4
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/k3serial; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+QUICK_TUNING=no_overlap=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/scripts/quick.py 1000 6000 > $OUT/q.txt 2> $OUT/q.err
+cd $ROOT
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv; rm -rf $OUT/stats
+cat $OUT/q.txt | grep -v amdgpu; head -8 $OUT/kernel_stats.csv
