@@ -1088,7 +1088,7 @@ int launch_heb(const HebArgs& a, hipStream_t stream) {
 
 template <int TE, int RA>
 int launch_heb6(const HebArgs& a, hipStream_t stream) {
-    constexpr int lds_bytes = 3 * 16 * (TE + 8 * RA) * kHeb6KB * 2;
+    constexpr int lds_bytes = 3 * 16 * (TE + 8 * RA) * kHeb6LD * 2;
     static bool attr_set[16] = {false};      // per device
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -192,7 +192,12 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
     }
 }
 
-constexpr int kHeb6KB = 32;            // spilled rows per stage = K of one bf16 MFMA
+constexpr int kHeb6KB = 32;
+// bf16 elements between the rows of two units in an LDS plane: 32 of data + 8 of padding.  With rows of exactly 64 B the sixteen lanes
+// of a ds_read_b128 group (unit m = 0..15, same k chunk) start at banks 16 m mod 64 -- four lanes per bank quartet -- and the
+// ds_write_b128s of the split pass collide four ways as well (SQ_LDS_BANK_CONFLICT = 0.50 of the LDS-active cycles, round 3 PMC); with
+// 80 B they start at 20 m mod 64: sixteen different quartets, both ways.
+constexpr int kHeb6LD = 40;            // spilled rows per stage = K of one bf16 MFMA
 
 // ---- bf16x6 form of the tiled kernel (the default; tuning heb_fp32=1 selects the fp32-MFMA kernel above) ---------------------------
 // The same GEMM with the spilled fp32 operands split into three bf16 pieces (the six products whose magnitude is above
@@ -201,8 +206,8 @@ constexpr int kHeb6KB = 32;            // spilled rows per stage = K of one bf16
 // 1.66 x its rate on the same shapes (0.785 ms against 1.30 ms for the 784 x 256 flush of 64 steps on the whole chip).
 //   global -> registers (one float4 per row and thread, a stage ahead) -> v_cvt_pk_bf16_f32 -> LDS planes -> MFMA operands:
 // TE error tiles x 8 RA activation tiles per workgroup, 8 waves, wave w owns activation tiles RA w .. RA w + RA - 1.
-// LDS: three bf16 planes of the stage's operands, TRANSPOSED: plane[p][unit][r], 32 r = 64 B per unit, so that the MFMA operand of
-// lane (m, g) -- unit m, k = 8g..8g+7 -- is ONE ds_read_b128 and a wave reads 1 KiB linearly (conflict-free).
+// LDS: three bf16 planes of the stage's operands, TRANSPOSED: plane[p][unit][r], 32 r = 64 B of data per unit in rows of 80 B (kHeb6LD),
+// so that the MFMA operand of lane (m, g) -- unit m, k = 8g..8g+7 -- is ONE conflict-free ds_read_b128.
 // Split pass: thread (ug, c) takes four consecutive units x the 8-row chunk c: 8 float4 loads (a chunk's 16 lanes = 256 contiguous bytes
 // of a spilled row), one ds_write_b128 per unit and plane.  512 units = 512 tasks = one per thread; a 17th error tile (TE = 17:
 // 784 = 17 + 16 + 16 tiles) is 512 more elements = ONE per thread (row tid / 16, unit 16 TE' + tid % 16), written with ds_write_b16.
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb6_kernel(const HebArgs
     constexpr bool XT = TE == 17;                       // one extra error tile handled element-wise
     static_assert(TE <= 17 && 4 * 4 * (TEM + TA) <= kHebThreads, "one task per thread");
     constexpr int NU = 16 * (TE + TA);                  // units (columns) per stage: E panel then A panel
-    constexpr int PLANE = NU * kHeb6KB;                   // bf16 elements per plane
+    constexpr int PLANE = NU * kHeb6LD;                   // bf16 elements per plane
     extern __shared__ __attribute__((aligned(16))) unsigned short lds6[];       // [3][NU][32] bf16
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,12 +243,12 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb6_kernel(const HebArgs
     const bool on = mine && col < width;                  // (widths are multiples of 16: a group of four is in or out as a whole)
     const float* const src = (is_a ? P.A : P.E) + (size_t)(r0 + 8 * c) * width + (on ? col : 0);
     const int lunit = 4 * ug + ((XT && is_a) ? 16 : 0);
-    const int loff = (mine ? lunit : 0) * kHeb6KB + 8 * c;  // element offset of the group's first unit inside a plane
+    const int loff = (mine ? lunit : 0) * kHeb6LD + 8 * c;  // element offset of the group's first unit inside a plane
     // the extra tile: element (row tid / 16, unit tid % 16)
     const int xr = tid >> 4, xu = tid & 15;
     const bool xon = XT && e_col0 + 16 * TEM + xu < P.ne;
     const float* const xsrc = P.E + (size_t)(r0 + xr) * P.ne + (xon ? e_col0 + 16 * TEM + xu : 0);
-    const int xoff = (16 * TEM + xu) * kHeb6KB + xr;
+    const int xoff = (16 * TEM + xu) * kHeb6LD + xr;
     f32x4 v[8];
     float xv = 0.f;
     auto load_stage = [&](int s) {
@@ -269,9 +274,9 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb6_kernel(const HebArgs
                     const float sa = ra - bf16lo_f32(mm), sb = rb - bf16hi_f32(mm);
                     hi[j] = h; mid[j] = mm; lo[j] = pk_bf16(sa, sb);
                 }
-                *reinterpret_cast<u32x4*>(lds6 + 0 * PLANE + loff + u * kHeb6KB) = hi;
-                *reinterpret_cast<u32x4*>(lds6 + 1 * PLANE + loff + u * kHeb6KB) = mid;
-                *reinterpret_cast<u32x4*>(lds6 + 2 * PLANE + loff + u * kHeb6KB) = lo;
+                *reinterpret_cast<u32x4*>(lds6 + 0 * PLANE + loff + u * kHeb6LD) = hi;
+                *reinterpret_cast<u32x4*>(lds6 + 1 * PLANE + loff + u * kHeb6LD) = mid;
+                *reinterpret_cast<u32x4*>(lds6 + 2 * PLANE + loff + u * kHeb6LD) = lo;
             }
         }
         if constexpr (XT) {
@@ -294,10 +299,10 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb6_kernel(const HebArgs
         for (int j = 0; j < RA; ++j) acc[i][j] = splat(0.f);
 
     if (n_stage > 0) load_stage(0);
-    const unsigned short* const base = lds6 + (size_t)m * kHeb6KB + 8 * g;       // lane (m, g) of tile t reads plane[p][16 t + m][8 g .. 8 g + 7]
+    const unsigned short* const base = lds6 + (size_t)m * kHeb6LD + 8 * g;       // lane (m, g) of tile t reads plane[p][16 t + m][8 g .. 8 g + 7]
     struct Op { u32x4 h, m, l; };
     auto ld_op = [&](int tile) {
-        const unsigned short* p = base + (size_t)(16 * tile) * kHeb6KB;
+        const unsigned short* p = base + (size_t)(16 * tile) * kHeb6LD;
         Op o;
         o.h = *reinterpret_cast<const u32x4*>(p);
         o.m = *reinterpret_cast<const u32x4*>(p + PLANE);

@@ -1,6 +1,6 @@
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/k3serial; mkdir -p $OUT
-cd /tmp && export TMPDIR=/tmp
-QUICK_TUNING=no_overlap=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ROOT/scripts/quick.py 1000 6000 > $OUT/q.txt 2> $OUT/q.err
-cd $ROOT
-cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv; rm -rf $OUT/stats
-cat $OUT/q.txt | grep -v amdgpu; head -8 $OUT/kernel_stats.csv
+for v in base heb_nopad base heb_nopad; do
+  L=$PWD/scripts/bin/libmcpc_$v.so; [ $v = base ] && L=$PWD/montecarlopredictivecoding_amd/libmcpc.so
+  MCPC_LIB=$L python3 scripts/quick.py 1000 6000 2>&1 | grep -v amdgpu | sed 's/mcpc::mcpc_steps_ws2_kernel<1, true> (round schedule: k=3 launches per cycle, every 16-chain unit in m=2 of them)//'
+  MCPC_LIB=$L python3 scripts/quick.py 1000 4000 2>&1 | grep -v amdgpu
+done
+timeout -k 10 600 python -m pytest tests -q -m gpu -k "headline or hebbian or rounds" 2>&1 | tail -3
