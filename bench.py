@@ -47,6 +47,9 @@ FRAG_BYTES_PER_WG_STEP = 2 * 6 * (32 * 256 + 256 * 256 + 256 * 784)
 # fp32-class work is the dense bf16 peak / 6 (MI355X_MICROARCH.md: 2516 TFLOP/s dense bf16).  `roofline.peak` stays the fp32 MFMA
 # peak -- the dense MFMA peak of the dtype the path computes in -- and the line carries this second ceiling beside it.
 PEAK_BF16X6_TFLOPS = 2516.0 / 6.0
+# What binds a 16-chain workgroup of the step kernel with this core: the packed weights it streams out of L2 once per step through its
+# CU's vector-memory return path, 64 B per clock (MI355X_MICROARCH.md) at the 2.4 GHz peak shader clock.
+PEAK_L1_FILL_GBS_PER_CU = 64 * 2.4
 
 
 def make_problem(batch, seed, device):
@@ -259,7 +262,7 @@ def main():
         flops_heb = 2.0 * S_MACS * B     # + the Hebbian sums e^T f(x) on accumulating steps
         bytes_per_step = 7472.0 * B
 
-        def kernel_line(kernel, ms_n_steps, flops_per_step, note, n_wg):
+        def kernel_line(kernel, ms_n_steps, flops_per_step, note, n_wg, wg_per_launch=None):
             ms, n, steps = ms_n_steps
             if not n or not steps:
                 return None
@@ -279,6 +282,13 @@ def main():
                     "l2_fragment_stream": {"achieved": n_wg * FRAG_BYTES_PER_WG_STEP * spl / avg_s / 1e9, "peak": PEAK_L2_GBS,
                                            "unit": "GB/s", "frac": n_wg * FRAG_BYTES_PER_WG_STEP * spl / avg_s / 1e9 / PEAK_L2_GBS,
                                            "workgroups": n_wg, "bytes_per_workgroup_step": FRAG_BYTES_PER_WG_STEP},
+                    # the same stream per CU: a workgroup of a launch does spl * n_wg / wg_per_launch steps in it
+                    "l1_fill_per_cu": {"achieved": FRAG_BYTES_PER_WG_STEP * spl * n_wg / (wg_per_launch or n_wg) / avg_s / 1e9,
+                                       "peak": PEAK_L1_FILL_GBS_PER_CU, "unit": "GB/s",
+                                       "frac": FRAG_BYTES_PER_WG_STEP * spl * n_wg / (wg_per_launch or n_wg) / avg_s / 1e9 / PEAK_L1_FILL_GBS_PER_CU,
+                                       "workgroups_per_launch": wg_per_launch or n_wg,
+                                       "note": "the resource that binds the bf16x6 step kernel at 16 chains per workgroup (DESIGN section 4): "
+                                               "six MFMAs of 16 cycles per 3 KiB of fragments, four GEMM waves per CU on one 64 B/clk return path"},
                     "note": note}
 
         # the dominant kernel of the timed call: the step kernel's launches of the plain schedule (in a learning call: the
@@ -293,7 +303,7 @@ def main():
                            + ("learning calls (mixing and Hebbian stretches alike; the Hebbian GEMMs of a segment run between and beside "
                               "the launches of the next); a launch of the round schedule advances its workgroups' share of the shard, "
                               "steps_per_bracket counts whole-shard steps" if primary_learning else "inference calls"),
-                           wg_per_launch)
+                           q["n_workgroups"], wg_per_launch)
         mixed_line = kernel_line("mcpc::mcpc_steps_ws2_mixed_kernel (mixed schedule: 32-chain and 16-chain workgroups in one launch per segment)",
                                  mixed_i if mixed_i is not None else mixed_l, flops_inf,
                                  "HIP events around whole cycles of the mixed schedule during the timed "
@@ -330,7 +340,10 @@ def main():
                 "inference_only": None if (dt_inf is None or not primary_learning) else {
                     "steps_per_s": world * K * T / dt_inf, "us_per_langevin_step": dt_inf / (K * T) * 1e6, "calls": K,
                     "achieved_tflops": flops_inf * K * T / dt_inf / 1e12,
-                    "frac_of_fp32_peak": flops_inf * K * T / dt_inf / 1e12 / PEAK_FP32_TFLOPS},
+                    "frac_of_fp32_peak": flops_inf * K * T / dt_inf / 1e12 / PEAK_FP32_TFLOPS,
+                    # the packed weights every workgroup streams out of L2 once per step (wall clock of the calls)
+                    "l2_fragment_stream_gbs": q["n_workgroups"] * FRAG_BYTES_PER_WG_STEP * K * T / dt_inf / 1e9,
+                    "l2_fragment_stream_frac_of_peak": q["n_workgroups"] * FRAG_BYTES_PER_WG_STEP * K * T / dt_inf / 1e9 / PEAK_L2_GBS},
                 "learning_call_flops": None if not primary_learning else {
                     "achieved_tflops": (flops_inf * T + flops_heb * (T - mixing)) * K / dt / 1e12,
                     "frac_of_fp32_peak": (flops_inf * T + flops_heb * (T - mixing)) * K / dt / 1e12 / PEAK_FP32_TFLOPS,

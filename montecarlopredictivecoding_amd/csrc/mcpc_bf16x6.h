@@ -30,6 +30,24 @@ __device__ __forceinline__ void split3_pair(float a, float b, unsigned& h, unsig
     m = pk_bf16(ra, rb);
     l = pk_bf16(ra - bf16lo_f32(m), rb - bf16hi_f32(m));
 }
+// The same split for the step kernels' GEMM loops, where its instruction count is what the loop waits for (2.6 VALU instructions
+// per MFMA).  Written like split3_pair, hipcc converts the low element of every pair twice (`(pack(a, b)) << 16` becomes a second
+// v_cvt_pk_bf16_f32 of a alone) and subtracts element by element: 13 instructions per pair.  Here the conversion is opaque to the
+// optimiser (one v_cvt_pk_bf16_f32 per pair and level) and the residuals of a pair are ONE packed subtraction (v_pk_add_f32 with
+// negated second operand): 9 per pair, 36 instead of 52 per 8 values.  Same arithmetic, bit for bit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16_opaque(f32x2 v) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v.x), "v"(v.y));
+    return r;
+}
+__device__ __forceinline__ void split3_pair_fast(f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16_opaque(x);
+    const f32x2 r = x - f32x2{bf16lo_f32(h), bf16hi_f32(h)};
+    m = cvt_pk_bf16_opaque(r);
+    const f32x2 r2 = r - f32x2{bf16lo_f32(m), bf16hi_f32(m)};
+    l = cvt_pk_bf16_opaque(r2);
+}
 __device__ __forceinline__ f32x4 mfma6(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }

@@ -39,10 +39,10 @@ __device__ __forceinline__ frag_t load_frag(const gu32x4* A, int off, int lane) 
 
 __device__ __forceinline__ frag_t split8(f32x4 x0, f32x4 x1) {
     unsigned h[4], m[4], l[4];
-    split3_pair(x0.x, x0.y, h[0], m[0], l[0]);
-    split3_pair(x0.z, x0.w, h[1], m[1], l[1]);
-    split3_pair(x1.x, x1.y, h[2], m[2], l[2]);
-    split3_pair(x1.z, x1.w, h[3], m[3], l[3]);
+    split3_pair_fast(f32x2{x0.x, x0.y}, h[0], m[0], l[0]);
+    split3_pair_fast(f32x2{x0.z, x0.w}, h[1], m[1], l[1]);
+    split3_pair_fast(f32x2{x1.x, x1.y}, h[2], m[2], l[2]);
+    split3_pair_fast(f32x2{x1.z, x1.w}, h[3], m[3], l[3]);
     frag_t f;
     f.h = u32x4{h[0], h[1], h[2], h[3]}; f.m = u32x4{m[0], m[1], m[2], m[3]}; f.l = u32x4{l[0], l[1], l[2], l[3]};
     return f;
