@@ -159,8 +159,13 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
             const f32x4 e = d * ecoef;
             if (l > 0) *reinterpret_cast<f32x4*>(e_lds + lrowb[ct] + tb) = e;
             if (slot >= 0) {
-                spill_st4(spill_a, img_bytes, rowb[ct] + tb, act4<ACT>(x), sys);
-                if (l > 0) spill_st4(spill_e, img_bytes, rowb[ct] + tb, e, sys);
+#ifdef MCPC_EXP_SPILL_LINEAR      // timing experiment only (rows permuted inside the workgroup's block): one contiguous KiB per store
+                const uint32_t sb = mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q);
+#else
+                const uint32_t sb = rowb[ct] + tb;
+#endif
+                spill_st4(spill_a, img_bytes, sb, act4<ACT>(x), sys);
+                if (l > 0) spill_st4(spill_e, img_bytes, sb, e, sys);
                 else if (e0_in_regs) e0acc[ct] = e0acc[ct] + e;                          // (one tile per wave: i == 0 only)
                 else gst4s(spill_e, rowb[ct] + tb, gld4s(spill_e, rowb[ct] + tb) + e);   // Linear 0: only sum_t e_1 is needed
             }
@@ -469,7 +474,11 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                 e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
             }
             *reinterpret_cast<f32x4*>(eo + orowb[ct] + cb) = e;
+#ifdef MCPC_EXP_SPILL_LINEAR
+            if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q), e, P.spill_sys != 0);
+#else
             if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, rowb[ct] + tb, e, P.spill_sys != 0);
+#endif
             if (rec != nullptr) st_unpadded(rec, (int)L.chain[ct], H.n, 16 * tile + 4 * L.q, o);
         }
     }
