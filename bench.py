@@ -230,7 +230,7 @@ def main():
             engine.sync_check()
             return r_, st, fl
         ra, sa, fa = replay(eng)
-        serial = "rr=0,no_mix=1,no_overlap=1,slot_cap=64"
+        serial = "rr=0,no_mix=1,no_overlap=1,slot_cap=128"
         eng_s = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=device, tuning=serial)
         eng_s.bind_params(W, b)
         eng_s.bind_inputs(None)

@@ -83,7 +83,7 @@ typedef struct mcpc_net_desc {
     int32_t n_out;                       /* width of the read-out Linear; 0 = model ends with a PCLayer */
     int32_t batch;                       /* chains held by this engine (local shard) */
     int32_t device;                      /* HIP device ordinal */
-    int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default: room for 192 steps in three parts (8.5 GB at 6000
+    int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default: room for 384 steps in three parts (17 GB at 6000
                                           * chains of cfg-M's net), at least 6 GiB, at most a quarter of the device's memory */
     const char* tuning;                  /* NULL, or developer overrides of the schedule heuristics as "key=value,key=value"
                                           * (parsed once by mcpc_create, not kept): ws=0|2 step kernel (barrier / in-place),

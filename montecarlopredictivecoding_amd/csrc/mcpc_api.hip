@@ -65,7 +65,7 @@ struct Knobs {
     int nw = 0;               // 0: automatic; 4 / 8 waves per workgroup of the barrier kernel
     int no_mix = 0;           // 1: never use the mixed 32-/16-chain schedule
     int no_overlap = 0;       // 1: Hebbian flushes run serially on the caller's stream (one ring segment = the whole ring)
-    int slot_cap = 192;       // spill-ring slots at most (3 parts of 64 steps)
+    int slot_cap = 384;       // spill-ring slots at most (3 parts of 128 steps)
     int spill_gb = 0;         // > 0: spill budget in GiB (overrides mcpc_net_desc::spill_budget_bytes)
     int mix_slack = 0;        // CUs the mixed schedule leaves free
     int flush_streams = 2;    // low-priority streams the GEMMs of an overlapped flush are spread over (1 or 2)

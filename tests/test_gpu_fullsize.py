@@ -262,7 +262,7 @@ def test_mixed_schedule_other_shard_sizes(batch, T, monkeypatch):
 
 def test_hebbian_ring_wraps_full_size():
     """B = 6000, Hebbian sums over 400 steps (pc_trainer.py:853-862: autograd adds dF/dtheta of every accumulating step).
-    The default ring (192 slots, three parts of 64, overlapped flush) wraps twice.  Checked against
+    A ring of 192 slots (three parts of 64, overlapped flush; the default is 384 in parts of 128) wraps twice.  Checked against
       (1) the serial flush with the same segment length (no_overlap, 64 slots): BITWISE -- the overlap (second stream,
           ev_flush waits, ring halves) must not change a single bit of the bucket;
       (2) a ring that never wraps (448 slots, one flush of all 400 steps): equal up to summation order;
@@ -274,7 +274,7 @@ def test_hebbian_ring_wraps_full_size():
     T, acc0 = 420, 20
     n_acc = T - acc0
     runs = {}
-    for key, tuning in (("overlap", None), ("serial", "no_overlap=1,slot_cap=64"), ("nowrap", "no_overlap=1,slot_cap=448,spill_gb=24")):
+    for key, tuning in (("overlap", "slot_cap=192"), ("serial", "no_overlap=1,slot_cap=64"), ("nowrap", "no_overlap=1,slot_cap=448,spill_gb=24")):
         eng = _engine(B, W, b, y, tuning=tuning)
         kw = dict(acc_begin=acc0, acc_end=T)
         if key == "overlap":

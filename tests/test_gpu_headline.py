@@ -4,11 +4,11 @@
 T = 5000 = 1000 mixing + 4000 sampling Langevin steps with the fused Philox kick, Hebbian sums over the sampling steps
 (reference pc_trainer.py:853-862: `optimizer_p.zero_grad()` at accumulate_p_at[0], autograd adds dF/dtheta of every later
 step; :904-914 normalise and step), loss + energies every step, x every 100 steps.  Default tuning = 376 16-chain workgroups on
-the round schedule (three launches per cycle, every unit in two of them), 62 + 1 Hebbian segments of 2 x 32 steps through a
-three-part spill ring that wraps 20 times, flushes overlapped on two low-priority streams.  This file runs exactly that call and
+the round schedule (three launches per cycle, every unit in two of them), 31 + 1 Hebbian segments of 2 x 64 steps through a
+three-part spill ring that wraps 10 times, flushes overlapped on two low-priority streams.  This file runs exactly that call and
 checks it against
 
-  (1) the same call on the serial / plain tuning (`rr=0,no_mix=1,no_overlap=1,slot_cap=64`: 188 32-chain workgroups, one launch
+  (1) the same call on the serial / plain tuning (`rr=0,no_mix=1,no_overlap=1,slot_cap=128`: 188 32-chain workgroups, one launch
       per segment, one stream, one ring part -- another workgroup form, and nothing can race): final state, all 50 records
       and the 276 146-float gradient bucket BITWISE, loss / energies rel 2e-6 (fp32 partial sums are grouped per workgroup);
   (2) an fp64 recomputation of dF/dtheta of every Linear over the 200-step window [4700, 4900) -- late in the call, after
@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 SIZES, N_OUT, B = [30, 256, 256], 784, 6000
 T, MIXING = 5000, 1000
-SERIAL_TUNING = "rr=0,no_mix=1,no_overlap=1,slot_cap=64"
+SERIAL_TUNING = "rr=0,no_mix=1,no_overlap=1,slot_cap=128"
 
 
 def _engine(W, b, y, tuning=None):
@@ -66,7 +66,7 @@ def default_run(problem):
     q = eng.query()
     assert (q["chains_per_wg"], q["n_workgroups"]) == (16, 376) and "round schedule: k=3 " in q["step_kernel"] and "m=2 " in q["step_kernel"]
     res, out, flat = _headline_call(eng, xs)
-    assert eng.query()["spill_slots"] == 192
+    assert eng.query()["spill_slots"] == 384
     eng.close()
     return res.energies.cpu().numpy(), out, [r.clone() for r in res.rec_x], flat
 
@@ -76,7 +76,7 @@ def test_headline_call_matches_serial_plain_schedule_bitwise(problem, default_ru
     en_d, out_d, rec_d, flat_d = default_run
     eng = _engine(W, b, y, tuning=SERIAL_TUNING)
     res, out_s, flat_s = _headline_call(eng, xs)
-    assert eng.query()["spill_slots"] == 64 and eng.query()["chains_per_wg"] == 32
+    assert eng.query()["spill_slots"] == 128 and eng.query()["chains_per_wg"] == 32
     eng.close()
     for a, c in zip(out_d, out_s):
         assert torch.equal(a, c)

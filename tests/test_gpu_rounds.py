@@ -80,9 +80,9 @@ def test_round_schedule_matches_other_schedules_bitwise(batch, T, acc0):
         for a, c in zip(outs["rounds"][1] + outs["rounds"][2], outs[key][1] + outs[key][2]):
             assert np.array_equal(a, c), key
         np.testing.assert_allclose(en, outs[key][0], rtol=2e-6)
-        if 64 % m == 0:        # Hebbian segments of 64 steps in every schedule: the flushes add the same partial sums in the same order
+        if 128 % m == 0:       # Hebbian segments of 128 steps in every schedule: the flushes add the same partial sums in the same order
             assert np.array_equal(outs["rounds"][3], outs[key][3]), key
-        else:                  # segments of m * (64 // m) steps: other partial sums of the same fp32 terms
+        else:                  # segments of m * (128 // m) steps: other partial sums of the same fp32 terms
             scale = np.abs(outs[key][3]).max()
             np.testing.assert_allclose(outs["rounds"][3], outs[key][3], rtol=0, atol=2e-6 * scale)
     assert np.abs(outs["rounds"][3]).max() > 0
