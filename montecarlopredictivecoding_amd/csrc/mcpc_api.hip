@@ -140,6 +140,8 @@ struct mcpc_engine {
     ncclComm_t comm = nullptr;      // mcpc_comm_init: the shards' communicator (RCCL), one rank per engine
     int comm_ranks = 0;
     int L = 0, Bpad = 0, nwg = 0, has_head = 0;
+    int nwg_live = 0;               // 16-chain in-place plans: workgroups that hold at least one chain of the batch (Bpad is a multiple of 32, so
+                                    // the last 16-chain unit may be all padding: it is never launched -- its spill rows and energy slots stay zero)
     int ct = kCT;                   // chains per workgroup: 16 (two workgroups per CU) or 32
     int nw = kWaves;                // waves per workgroup: 4, or 8 with 32 chains (two waves per SIMD, one workgroup per CU)
     int ws = 0;                     // 1: wave-specialised kernel with staging slots; 2: in-place variant (4 GEMM + 4 epilogue waves, 32 chains)
@@ -705,7 +707,7 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
 // of any other schedule, bitwise; in a Hebbian segment (m q <= slots of a ring part) every unit fills its own rows of all m q slots
 // before the flush, which therefore sees what the plain schedule would have written.
 int setup_rounds(mcpc_engine* e, int n_cu) {
-    const int U = e->nwg, C = n_cu - e->knobs.mix_slack;
+    const int U = e->nwg_live, C = n_cu - e->knobs.mix_slack;
     if (U <= C || C < 1) return 0;
     auto gsize = [&](int k, int g) { return (int)((int64_t)(g + 1) * U / k - (int64_t)g * U / k); };
     // best m for every k <= 16, then the SMALLEST k within 3 % of the best k / m: short cycles mean long launches (a Hebbian segment is
@@ -834,6 +836,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
         rc = plan_lds(e);
     }
     if (rc) { delete e; return rc; }
+    e->nwg_live = (e->ws == 2 && e->ct == 16) ? (d->batch + 15) / 16 : e->nwg;
 
     auto bail = [&](int code) { free_all(e); delete e; return code; };
     for (int l = 0; l < e->L; ++l) {
@@ -874,9 +877,10 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     for (int l = 0; l < e->L; ++l) per_slot += (size_t)e->Bpad * e->npad[l] * (l >= 1 ? 2 : 1);
     per_slot += (size_t)e->Bpad * e->out_pad;
     per_slot *= sizeof(float);
-    // defaults sized for 288 GB of HBM per GPU: room for `slot_cap` steps (128: Hebbian segments of 64 steps; 5.7 GB at cfg-M,
-    // 45 GB for a shard of 48 000 chains), at least 6 GiB, at most a quarter of the device's memory.  A 2 GiB ring (segments of 24)
-    // cost 1.4 % more per step at cfg-M; 6 GiB instead of 24 cost 13 % at 24 000 chains (segments of 17 steps).
+    // defaults sized for 288 GB of HBM per GPU: room for `slot_cap` steps (384: Hebbian segments of 128 steps; 17 GB at cfg-M, capped
+    // by the quarter of the device's memory for a shard of 48 000 chains), at least 6 GiB.  Round 2: a 2 GiB ring (segments of 24)
+    // cost 1.4 % more per step at cfg-M; 6 GiB instead of 24 cost 13 % at 24 000 chains (segments of 17 steps).  Round 3 (step kernel
+    // on every CU, the flush a phase of its own): 192 / 384 / 576 slots = 12 290 / 12 930 / 13 070 steps/s on the headline call.
     int64_t budget = d->spill_budget_bytes;
     if (budget <= 0) {
         size_t free_b = 0, total_b = 0;
@@ -889,7 +893,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if (kn.no_overlap || e->slots < 2) e->half_slots = e->slots;          // serial flushes on the caller's stream: one part
     else if (e->slots >= kn.ring_parts) { e->half_slots = e->slots / kn.ring_parts; e->slots = e->half_slots * kn.ring_parts; }
     else { e->slots &= ~1; e->half_slots = e->slots / 2; }                   // fewer slots than parts: two halves
-    // (the ring itself -- up to 6 GiB -- is allocated by the first run that accumulates Hebbian sums: ensure_spill)
+    // (the ring itself is allocated by the first run that accumulates Hebbian sums: ensure_spill)
 
     if ((rc = e->ws == 2 ? build_phases_ws2(e) : build_phases(e))) return bail(rc);
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
@@ -904,7 +908,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if (e->ws == 2 && e->ct == 32 && e->nwg < n_cu && !kn.no_mix) {
         if ((rc = setup_mixed_schedule(e, n_cu))) return bail(rc);
     }
-    if (e->ws == 2 && e->ct == 16 && e->nwg > n_cu && kn.rr) {
+    if (e->ws == 2 && e->ct == 16 && e->nwg_live > n_cu && kn.rr) {
         if ((rc = setup_rounds(e, n_cu))) return bail(rc);
     }
     *out = e;
@@ -1133,6 +1137,17 @@ int ensure_spill(mcpc_engine* e) {
         if (l >= 1 && !e->spill_e[l] && (rc = dmalloc(e->spill_e[l], n))) return rc;
     }
     if (e->has_head && !e->spill_eo && (rc = dmalloc(e->spill_eo, (size_t)e->slots * e->Bpad * e->out_pad))) return rc;
+    // rows of a 16-chain unit that is all padding (never launched) read as zero in every slot: the Hebbian GEMMs sum over all Bpad rows
+    if (e->nwg_live * e->ct < e->Bpad && e->ws == 2 && e->ct == 16) {
+        const size_t live = (size_t)e->nwg_live * 16, dead = (size_t)e->Bpad - live;
+        auto zero_tail = [&](float* base, int npad) {
+            return hipMemset2D(base + live * npad, (size_t)e->Bpad * npad * sizeof(float), 0, dead * npad * sizeof(float), (size_t)e->slots) == hipSuccess;
+        };
+        bool ok = true;
+        for (int l = 0; l < e->L; ++l) { ok = ok && zero_tail(e->spill_a[l], e->npad[l]); if (l >= 1) ok = ok && zero_tail(e->spill_e[l], e->npad[l]); }
+        if (e->has_head) ok = ok && zero_tail(e->spill_eo, e->out_pad);
+        if (!ok) return fail(MCPC_EHIP, "hipMemset2D of the spill ring's padding rows failed");
+    }
     const int nlin = e->L + (e->has_head ? 1 : 0);
     const int max_rows = e->half_slots * e->Bpad;
     size_t total = 0;
@@ -1319,6 +1334,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         const size_t cap = std::max(erows, e->epart_rows + e->epart_rows / 2);
         int rc = dmalloc(e->epart, cap * eslots * (kMaxLatent + 1));
         if (rc) return rc;
+        // (the slots of a 16-chain unit that is all padding are never written: they must read as zero)
+        HIP_TRY(hipMemsetAsync(e->epart, 0, cap * eslots * (kMaxLatent + 1) * sizeof(double), stream));
         e->epart_rows = cap;
     }
     // mu_1 = inputs W0^T + b0 (constant during the run: weights only change between runs)
@@ -1487,7 +1504,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             Q.wg_list = e->rr_tab + e->rr_off[i]; Q.wg_rel = Q.wg_list + e->rr_count[i];
             { const int rc = prof_begin(); if (rc) return rc; }
             hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1, true>), dim3(e->rr_count[i]), dim3(kWs2Threads), e->lds_bytes, stream, Q);
-            { const int rc = prof_end((double)q * e->rr_count[i] / e->nwg); if (rc) return rc; }
+            { const int rc = prof_end((double)q * e->rr_count[i] / e->nwg_live); if (rc) return rc; }
         }
         HIP_TRY(hipGetLastError());
         return 0;
@@ -1556,7 +1573,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             if (rc) return rc;
         } else {
         { const int rc = prof_begin(); if (rc) return rc; }
-        if (e->ws == 2 && e->ct == 16) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
+        if (e->ws == 2 && e->ct == 16) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1>), dim3(e->nwg_live), dim3(kWs2Threads), e->lds_bytes, stream, P);
         else if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
         else if (e->ct == 16) hipLaunchKernelGGL((mcpc_steps_kernel<1, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
         else if (e->nw == 8) hipLaunchKernelGGL((mcpc_steps_kernel<2, 8>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
@@ -1757,7 +1774,7 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
     if (!e) return fail(MCPC_EINVAL, "null engine");
     if (lds_bytes) *lds_bytes = e->lds_bytes;
     if (chains_per_wg) *chains_per_wg = e->ct;
-    if (n_workgroups) *n_workgroups = e->nwg;
+    if (n_workgroups) *n_workgroups = e->nwg_live;
     if (spill_slots) *spill_slots = e->slots;
     return MCPC_OK;
 }

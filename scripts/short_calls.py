@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Short calls at cfg-M's size: ms per call and us per step for T in a few lengths, mixed schedule on / off, Adam (MAP) / SGD + noise.
-Developer measurement: where the mixed schedule starts to pay."""
+"""Short calls at cfg-M's size: ms per call and us per step for T in a few lengths, Adam (MAP) / SGD + noise, on the default plan
+(16-chain workgroups, round schedule) and on the round-2 plan (`rr=0`: 32-chain workgroups + mixed schedule).
+Developer measurement: what a call costs outside its steps."""
 import os
 import sys
 import time
@@ -25,7 +26,7 @@ else:
     y = (torch.rand(B, 784, generator=g) < 0.13).float().to(DEV)
     xs = [((torch.rand(B, n, generator=g) * 2 - 1) * 10).to(DEV) for n in SIZES]
 xs = [x * 0.1 for x in xs]
-for tuning in (None, "no_mix=1"):
+for tuning in (None, "rr=0"):
     eng = Engine(SIZES, [L.ACT_RELU] * len(SIZES), SIZES[0], 784, B, device=DEV, tuning=tuning)
     eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
     for name, kw in (("adam", dict(noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.1)),
@@ -40,5 +41,5 @@ for tuning in (None, "no_mix=1"):
             for _ in range(5):
                 call()
             dt = (time.perf_counter() - t0) / 5
-            print(f"{'mixed' if tuning is None else 'plain':5s} {name:9s} T={T:5d}: {dt*1e3:7.2f} ms per call, {dt/T*1e6:6.1f} us per step", flush=True)
+            print(f"{'rounds' if tuning is None else 'wg32':6s} {name:9s} T={T:5d}: {dt*1e3:7.2f} ms per call, {dt/T*1e6:6.1f} us per step", flush=True)
     eng.close()

@@ -3,7 +3,7 @@
 `bench.py` quotes its number on ONE call shape: cfg-M (30-256-256-784 ReLU, Bernoulli read-out), 6000 chains,
 T = 5000 = 1000 mixing + 4000 sampling Langevin steps with the fused Philox kick, Hebbian sums over the sampling steps
 (reference pc_trainer.py:853-862: `optimizer_p.zero_grad()` at accumulate_p_at[0], autograd adds dF/dtheta of every later
-step; :904-914 normalise and step), loss + energies every step, x every 100 steps.  Default tuning = 376 16-chain workgroups on
+step; :904-914 normalise and step), loss + energies every step, x every 100 steps.  Default tuning = 375 16-chain workgroups on
 the round schedule (three launches per cycle, every unit in two of them), 31 + 1 Hebbian segments of 2 x 64 steps through a
 three-part spill ring that wraps 10 times, flushes overlapped on two low-priority streams.  This file runs exactly that call and
 checks it against
@@ -64,7 +64,7 @@ def default_run(problem):
     W, b, y, xs = problem
     eng = _engine(W, b, y)
     q = eng.query()
-    assert (q["chains_per_wg"], q["n_workgroups"]) == (16, 376) and "round schedule: k=3 " in q["step_kernel"] and "m=2 " in q["step_kernel"]
+    assert (q["chains_per_wg"], q["n_workgroups"]) == (16, 375) and "round schedule: k=3 " in q["step_kernel"] and "m=2 " in q["step_kernel"]
     res, out, flat = _headline_call(eng, xs)
     assert eng.query()["spill_slots"] == 384
     eng.close()

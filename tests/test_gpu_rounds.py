@@ -47,7 +47,7 @@ def _km(eng):
 
 
 def test_plan_mirror_of_known_cases():
-    assert _plan(376) == (3, 2)          # 6000 chains: 250 / 251 workgroups per launch
+    assert _plan(375) == (3, 2)          # 6000 chains: 250 workgroups per launch
     assert _plan(512) == (2, 1) and _plan(1024) == (4, 1)
     assert _plan(300) == (6, 5)          # 1.200 launch times per step; (13, 11) would be 1.182 with launches of 5 steps in a Hebbian segment
     assert _plan(258) == (12, 11) and _plan(3000) == (12, 1)
@@ -140,3 +140,57 @@ def test_round_schedule_sliced_calls_continue_each_other():
     for a, c in zip(out_one, out_two):
         assert torch.equal(a, c)
     np.testing.assert_array_equal(en_one, en_two)
+
+
+@pytest.mark.parametrize("sizes,act,loss,xopt", [([30, 256, 256], "relu", "bernoulli", "sgd_noise"), ([20, 128, 128], "tanh", "gaussian", "sgd_noise"),
+                                                 ([30, 256, 256], "relu", "bernoulli", "adam"), ([24, 96], "tanh", "gaussian", "sgd"),
+                                                 ([20, 128, 128], "relu", "none", "sgd_noise")])
+def test_epilogue_operands_in_lds_match_global_memory(sizes, act, loss, xopt):
+    """16-chain plans with the room keep the state rows, biases, mu_1 rows and bit-packed target rows of a workgroup's chains in LDS
+    for the whole launch (KParams::xl, mcpc_ws2_lean.h); `no_xl=1` leaves them in global memory.  Same arithmetic either way: states,
+    records, energies, Hebbian sums and Adam moments bitwise equal -- 0/1 targets (bit words from LDS), fp32 targets (still read from
+    global memory), no loss, every lean x update (SGD, SGD + Philox kick, Adam), a partially filled last workgroup (the generic
+    epilogues, which never use the LDS copies) and a call cut into launches by a Hebbian window."""
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    batch, T, n_out = 1000, 45, 784 if len(sizes) == 3 else 40            # 1000 = 62 full workgroups + one of 8 chains
+    g = torch.Generator().manual_seed(11)
+    dims = [sizes[0]] + sizes + [n_out]
+    W = [((torch.rand(dims[j + 1], dims[j], generator=g) * 2 - 1) / dims[j] ** 0.5).to(DEV) for j in range(len(dims) - 1)]
+    b = [((torch.rand(dims[j + 1], generator=g) * 2 - 1) / dims[j] ** 0.5).to(DEV) for j in range(len(dims) - 1)]
+    y = (torch.rand(batch, n_out, generator=g) < 0.2).float().to(DEV) if loss == "bernoulli" else torch.rand(batch, n_out, generator=g).to(DEV)
+    xs = [((torch.rand(batch, n, generator=g) * 2 - 1) * 0.5).to(DEV) for n in sizes]
+    inputs = torch.rand(batch, sizes[0], generator=g).to(DEV)
+    a_dev = L.ACT_TANH if act == "tanh" else L.ACT_RELU
+    kw = dict(loss_kind={"bernoulli": L.LOSS_BERNOULLI, "gaussian": L.LOSS_GAUSSIAN, "none": L.LOSS_NONE}[loss], energy_mode=L.ENERGY_ALL,
+              seed=5, step_base=7, acc_begin=13, acc_end=T, rec_begin=0, rec_stride=9, rec_count=5, rec_x=True)
+    if loss == "gaussian":
+        kw.update(loss_var=0.7, mask_start=3)
+    if xopt == "adam":
+        kw.update(xopt=L.XOPT_ADAM, lr=0.05, noise_mode=L.NOISE_NONE)
+    else:
+        kw.update(lr=0.03, noise_mode=L.NOISE_PHILOX if xopt == "sgd_noise" else L.NOISE_NONE, noise_var=1.5)
+    outs = []
+    for tuning in (None, "no_xl=1"):
+        eng = Engine(sizes, [a_dev] * len(sizes), sizes[0], n_out, batch, device=DEV, tuning=tuning)
+        assert eng.query()["chains_per_wg"] == 16
+        lds = eng.query()["lds_bytes"]
+        eng.bind_params(W, b); eng.bind_inputs(inputs); eng.bind_target(y)
+        eng.load_state(xs)
+        res = eng.run(T, **kw)
+        out = [torch.empty_like(x) for x in xs]
+        eng.store_state(out)
+        extra = []
+        if xopt == "adam":
+            m = [torch.empty_like(x) for x in xs]; v = [torch.empty_like(x) for x in xs]
+            eng.store_adam_state(m, v)
+            extra = m + v
+        flat = eng.read_param_grads_flat(scale=1.0)
+        eng.sync_check()
+        outs.append((lds, [t.cpu().numpy() for t in out + list(res.rec_x) + extra + [flat]], res.energies.cpu().numpy()))
+        eng.close()
+    assert outs[0][0] > outs[1][0]                      # the default plan did take the extra LDS
+    for a, c in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, c)
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.all(np.isfinite(outs[0][2]))
+    assert np.abs(outs[0][1][-1]).max() > 0
