@@ -8,8 +8,11 @@
 // their instruction count on things these paths do not need:
 //   * 64-bit per-lane addresses for every access   -> wave-uniform base (SGPR pair) + one 32-bit byte offset per lane:
 //     a row offset per chain tile computed once per entry (v_mul_u32_u24), one v_add per tile;
-//   * per-element `live` / padding / mask predicates -> the workgroup is known to be fully live; padded units and partial
-//     loss masks are handled by a wave-uniform branch on the one tile that has them;
+//   * per-element `live` / padding / mask predicates -> padded units and partial loss masks are handled by a wave-uniform branch on
+//     the one tile that has them; padding CHAINS (the last workgroup of a batch that is not a multiple of 16) cost one per-lane mask:
+//     they evolve like any chain, and their energy terms are multiplied by 0, their spills ANDed with 0, their records skipped
+//     (LeanLane::livef / livem) -- until round 3 such a workgroup took the generic epilogues and every launch waited for it (+17 %
+//     per step at 7000 chains);
 //   * three loads per slot whatever the entry type   -> each entry type requests exactly its operands.
 // The arithmetic per element is the generic epilogue's, operation for operation: trajectories stay bitwise those of the
 // other kernel forms (tests/test_gpu_fullsize.py::test_workgroup_variants_agree, the mixed-schedule tests).
@@ -68,7 +71,15 @@ struct LeanLane {
     int c, q;
     uint32_t chain[CTT];       // global row (chain) of this lane in chain tile ct
     uint32_t lrow[CTT];        // 16 ct + c: row inside the workgroup's LDS images
+    float livef[CTT];          // 1.0f for a chain of the batch, 0.0f for a padding chain
+    uint32_t livem[CTT];       // ~0u / 0u
 };
+__device__ __forceinline__ f32x4 mask4(f32x4 v, uint32_t m) {
+    f32x4 r;
+    r.x = __uint_as_float(__float_as_uint(v.x) & m); r.y = __uint_as_float(__float_as_uint(v.y) & m);
+    r.z = __uint_as_float(__float_as_uint(v.z) & m); r.w = __uint_as_float(__float_as_uint(v.w) & m);
+    return r;
+}
 
 // tiles of this wave in an entry: tile(i) = tile0 + kk + NW i, i < nt
 template <int ACT> __device__ __forceinline__ f32x4 act4(f32x4 x) {
@@ -164,14 +175,14 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
 #else
                 const uint32_t sb = rowb[ct] + tb;
 #endif
-                spill_st4(spill_a, img_bytes, sb, act4<ACT>(x), sys);
-                if (l > 0) spill_st4(spill_e, img_bytes, sb, e, sys);
+                spill_st4(spill_a, img_bytes, sb, mask4(act4<ACT>(x), L.livem[ct]), sys);
+                if (l > 0) spill_st4(spill_e, img_bytes, sb, mask4(e, L.livem[ct]), sys);
                 else if (e0_in_regs) e0acc[ct] = e0acc[ct] + e;                          // (one tile per wave: i == 0 only)
                 else gst4s(spill_e, rowb[ct] + tb, gld4s(spill_e, rowb[ct] + tb) + e);   // Linear 0: only sum_t e_1 is needed
             }
-            if (rec != nullptr) st_unpadded(rec, (int)L.chain[ct], Ly.n, 16 * tile + 4 * L.q, x);
+            if (rec != nullptr && L.livem[ct]) st_unpadded(rec, (int)L.chain[ct], Ly.n, 16 * tile + 4 * L.q, x);
             const f32x4 dd = d * d;
-            esum += 0.5f * ecoef * (dd.x + dd.y + dd.z + dd.w);
+            esum += L.livef[ct] * (0.5f * ecoef * (dd.x + dd.y + dd.z + dd.w));
         }
     }
     return esum;
@@ -443,7 +454,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                         const bool on = inside || ((u0 + r) >= mask_start && (u0 + r) < n);
                         const float dlt = ov[r] - yy[r];
                         ev[r] = on ? inv_var * dlt : 0.f;
-                        lsum += on ? 0.5f * inv_var * dlt * dlt : 0.f;
+                        lsum += on ? L.livef[ct] * (0.5f * inv_var * dlt * dlt) : 0.f;
                     }
                 } else if (do_energy) {
                     if (inside) {
@@ -452,7 +463,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                             float sg, bc;
                             sigmoid_bce_f(ov[r], yy[r], sg, bc);
                             ev[r] = sg - yy[r];
-                            lsum += bc;
+                            lsum += L.livef[ct] * bc;
                         }
                     } else {
 #pragma unroll
@@ -461,7 +472,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                             float sg, bc;
                             sigmoid_bce_f(ov[r], yy[r], sg, bc);
                             ev[r] = on ? sg - yy[r] : 0.f;
-                            lsum += on ? bc : 0.f;
+                            lsum += on ? L.livef[ct] * bc : 0.f;
                         }
                     }
                 } else {
@@ -475,11 +486,11 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
             }
             *reinterpret_cast<f32x4*>(eo + orowb[ct] + cb) = e;
 #ifdef MCPC_EXP_SPILL_LINEAR
-            if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q), e, P.spill_sys != 0);
+            if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q), mask4(e, L.livem[ct]), P.spill_sys != 0);
 #else
-            if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, rowb[ct] + tb, e, P.spill_sys != 0);
+            if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, rowb[ct] + tb, mask4(e, L.livem[ct]), P.spill_sys != 0);
 #endif
-            if (rec != nullptr) st_unpadded(rec, (int)L.chain[ct], H.n, 16 * tile + 4 * L.q, o);
+            if (rec != nullptr && L.livem[ct]) st_unpadded(rec, (int)L.chain[ct], H.n, 16 * tile + 4 * L.q, o);
         }
     }
     return lsum;

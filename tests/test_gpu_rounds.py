@@ -149,8 +149,9 @@ def test_epilogue_operands_in_lds_match_global_memory(sizes, act, loss, xopt):
     """16-chain plans with the room keep the state rows, biases, mu_1 rows and bit-packed target rows of a workgroup's chains in LDS
     for the whole launch (KParams::xl, mcpc_ws2_lean.h); `no_xl=1` leaves them in global memory.  Same arithmetic either way: states,
     records, energies, Hebbian sums and Adam moments bitwise equal -- 0/1 targets (bit words from LDS), fp32 targets (still read from
-    global memory), no loss, every lean x update (SGD, SGD + Philox kick, Adam), a partially filled last workgroup (the generic
-    epilogues, which never use the LDS copies) and a call cut into launches by a Hebbian window."""
+    global memory), no loss, every lean x update (SGD, SGD + Philox kick, Adam), a partially filled last workgroup (lean epilogues
+    with per-lane masks for its padding chains) and a call cut into launches by a Hebbian window.  `no_lean=1` runs the generic
+    epilogues everywhere: the same bits again, energies included."""
     from montecarlopredictivecoding_amd import _lib as L
     from montecarlopredictivecoding_amd.engine import Engine
     batch, T, n_out = 1000, 45, 784 if len(sizes) == 3 else 40            # 1000 = 62 full workgroups + one of 8 chains
@@ -171,7 +172,7 @@ def test_epilogue_operands_in_lds_match_global_memory(sizes, act, loss, xopt):
     else:
         kw.update(lr=0.03, noise_mode=L.NOISE_PHILOX if xopt == "sgd_noise" else L.NOISE_NONE, noise_var=1.5)
     outs = []
-    for tuning in (None, "no_xl=1"):
+    for tuning in (None, "no_xl=1", "no_lean=1"):
         eng = Engine(sizes, [a_dev] * len(sizes), sizes[0], n_out, batch, device=DEV, tuning=tuning)
         assert eng.query()["chains_per_wg"] == 16
         lds = eng.query()["lds_bytes"]
@@ -190,7 +191,9 @@ def test_epilogue_operands_in_lds_match_global_memory(sizes, act, loss, xopt):
         outs.append((lds, [t.cpu().numpy() for t in out + list(res.rec_x) + extra + [flat]], res.energies.cpu().numpy()))
         eng.close()
     assert outs[0][0] > outs[1][0]                      # the default plan did take the extra LDS
-    for a, c in zip(outs[0][1], outs[1][1]):
-        assert np.array_equal(a, c)
-    assert np.array_equal(outs[0][2], outs[1][2]) and np.all(np.isfinite(outs[0][2]))
+    for other in outs[1:]:
+        for a, c in zip(outs[0][1], other[1]):
+            assert np.array_equal(a, c)
+        assert np.array_equal(outs[0][2], other[2])
+    assert np.all(np.isfinite(outs[0][2]))
     assert np.abs(outs[0][1][-1]).max() > 0
