@@ -200,8 +200,9 @@ int mcpc_philox_normals(int device, uint64_t seed, uint64_t step, int layer, uin
  * Returns MCPC_ESTATE if the last results must not be used.  The only host-synchronising call besides create/destroy. */
 int mcpc_sync_check(mcpc_engine* e, void* stream);
 
-/* Introspection for benchmarks / DESIGN.md: bytes of LDS per workgroup, chains per workgroup,
- * workgroups per step launch, spill slots. */
+/* Introspection for benchmarks / DESIGN.md: bytes of LDS per workgroup, chains per workgroup, workgroups of the shard (units
+ * of `chains_per_wg` chains that hold at least one chain of the batch; a launch of the round schedule holds a part of them, see
+ * mcpc_step_kernel_name), spill slots. */
 int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg, int32_t* n_workgroups,
                int32_t* spill_slots);
 /* Name of the step kernel this engine launches, as it appears in a rocprofv3 kernel trace (static string). */
