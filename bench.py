@@ -330,6 +330,10 @@ def main():
                             "bench step = ONE CALL of T = %d Langevin steps (%d mixing + %d sampling), energies every step, "
                             "x every 100 steps; value = n_gpus * steps * T / wall; ms_per_step = ms per call" % (B, T, mixing, T - mixing),
                 "T": T, "mixing": mixing, "sampling": T - mixing, "steps_are": "calls",
+                # `dtype` f32: state, weights, energies and sums are fp32; every contraction multiplies fp32 operands as six bf16 MFMA
+                # products (hi/mid/lo pieces, all terms above 2^-24 of the leading one) with fp32 accumulation -- error against fp64 that
+                # of an fp32 MFMA chain, parity tolerances unchanged
+                "arithmetic": "fp32 operands, products as 6 bf16 MFMA terms (bf16x6), fp32 accumulate: fp32-class accuracy",
                 "timed_mode": ("learning call: Hebbian sums over the sampling steps + normalised grad read-out"
                                + (" + 1 RCCL all-reduce of %d floats" % n_params if world > 1 else "")) if primary_learning
                               else "inference-only call (no Hebbian sums)",
