@@ -253,3 +253,48 @@ def test_two_engines_on_two_streams_run_concurrently():
             assert torch.equal(a, c)
         assert torch.equal(flat, alone[i][2])
         eng.close()
+
+
+def test_gemm_core_accuracy_against_fp64():
+    """The step kernel multiplies fp32 operands as six bf16 MFMA products with fp32 accumulation (csrc/mcpc_gemm6.h).  ONE step with
+    lr = 1 and no noise exposes every contraction of a step -- three forward GEMMs, the read-out and four back-projections, K = 32 ..
+    784 -- in x_new = x - g.  Against an fp64 evaluation of the same step (reference pc_layer.py:266-300 for the errors,
+    pc_trainer.py:862 for dF/dx) every element must sit within 1e-6 of the sum of the ABSOLUTE values of the terms that make it up:
+    what a chain of two fp32 dot products may lose (the core alone: max 2.7e-7 of sum|terms| at K = 4096, the fp32 MFMA 2.1e-7)."""
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    dev = _dev()
+    sizes, n_in, n_out, B = [30, 256, 256], 30, 784, 64
+    g = torch.Generator().manual_seed(41)
+    dims = [n_in] + sizes + [n_out]
+    W = [((torch.rand(dims[j + 1], dims[j], generator=g) * 2 - 1) * (3.0 / dims[j] ** 0.5)).to(dev) for j in range(4)]
+    b = [(torch.rand(dims[j + 1], generator=g) * 2 - 1).to(dev) for j in range(4)]
+    xs = [((torch.rand(B, n, generator=g) * 2 - 1) * 1.5).to(dev) for n in sizes]
+    inputs = (torch.rand(B, n_in, generator=g) * 2 - 1).to(dev)
+    y = (torch.rand(B, n_out, generator=g) * 2 - 1).to(dev)
+    var = 0.8
+    eng = Engine(sizes, [L.ACT_TANH] * 3, n_in, n_out, B, device=dev)
+    eng.bind_params(W, b); eng.bind_inputs(inputs); eng.bind_target(y)
+    eng.load_state(xs)
+    eng.run(1, loss_kind=L.LOSS_GAUSSIAN, loss_var=var, lr=1.0, noise_mode=L.NOISE_NONE)
+    out = [torch.empty_like(x) for x in xs]
+    eng.store_state(out)
+    eng.sync_check()
+    eng.close()
+    Wd, bd, xd = [w.double() for w in W], [v.double() for v in b], [x.double() for x in xs]
+    f = [torch.tanh(x) for x in xd]
+    fp = [1.0 - t * t for t in f]
+    pre = [inputs.double()] + f                                   # input of Linear j
+    mu = [pre[j] @ Wd[j].T + bd[j] for j in range(4)]
+    amu = [pre[j].abs() @ Wd[j].abs().T + bd[j].abs() for j in range(4)]        # sum of |terms| of each prediction
+    e = [xd[l] - mu[l] for l in range(3)] + [(mu[3] - y.double()) / var]
+    ae = [xd[l].abs() + amu[l] for l in range(3)] + [(amu[3] + y.double().abs()) / var]
+    for l in range(3):
+        sign = 1.0 if l == 2 else -1.0
+        back = e[l + 1] @ Wd[l + 1]
+        gl = e[l] + sign * fp[l] * back
+        bound = ae[l] + fp[l].abs() * (ae[l + 1] @ Wd[l + 1].abs())
+        err = (out[l].double() - (xd[l] - gl)).abs()
+        assert float((err / bound).max()) < 1e-6, (l, float((err / bound).max()))
+        assert float((err / bound).max()) > 0                      # (not vacuous: the step did change x)
+        assert float(gl.abs().max()) > 0.1
