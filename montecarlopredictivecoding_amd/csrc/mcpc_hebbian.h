@@ -268,11 +268,9 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb6_kernel(const HebArgs
                 for (int j = 0; j < 4; ++j) {
                     const float a = on ? v[2 * j][u] : 0.f, b = on ? v[2 * j + 1][u] : 0.f;
                     bsum[u] += a + b;
-                    const unsigned h = pk_bf16(a, b);
-                    const float ra = a - bf16lo_f32(h), rb = b - bf16hi_f32(h);
-                    const unsigned mm = pk_bf16(ra, rb);
-                    const float sa = ra - bf16lo_f32(mm), sb = rb - bf16hi_f32(mm);
-                    hi[j] = h; mid[j] = mm; lo[j] = pk_bf16(sa, sb);
+                    unsigned h, mm, ll;
+                    split3_pair_fast(f32x2{a, b}, h, mm, ll);       // (9 instructions per pair instead of 13: mcpc_bf16x6.h)
+                    hi[j] = h; mid[j] = mm; lo[j] = ll;
                 }
                 *reinterpret_cast<u32x4*>(lds6 + 0 * PLANE + loff + u * kHeb6LD) = hi;
                 *reinterpret_cast<u32x4*>(lds6 + 1 * PLANE + loff + u * kHeb6LD) = mid;
