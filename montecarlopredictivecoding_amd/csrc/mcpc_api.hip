@@ -1008,9 +1008,9 @@ int mcpc_store_adam_state(mcpc_engine* e, float* const* m, float* const* v, void
     for (int l = 0; l < e->L; ++l) {
         if (!m[l] || !v[l]) return fail(MCPC_EINVAL, "null Adam state pointer for layer %d", l);
         const size_t total = (size_t)e->d.batch * e->d.sizes[l];
-        hipLaunchKernelGGL(mcpc_unpad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, e->m[l], m[l],
+        hipLaunchKernelGGL(mcpc_unpad_adam_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, e->m[l], m[l],
                            e->d.batch, e->d.sizes[l], e->npad[l]);
-        hipLaunchKernelGGL(mcpc_unpad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, e->v[l], v[l],
+        hipLaunchKernelGGL(mcpc_unpad_adam_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, e->v[l], v[l],
                            e->d.batch, e->d.sizes[l], e->npad[l]);
     }
     HIP_TRY(hipGetLastError());

@@ -177,6 +177,16 @@ __device__ __forceinline__ void mfma_block(f32x4 (&acc)[NTT][CTT], const f32x4 (
         for (int ct = 0; ct < CTT; ++ct) acc[t][ct] = mfma16(a[t].w, b[ct].w, acc[t][ct]);
 }
 
+// Layout of Adam's moments m_l, v_l (only the x update reads and writes them, mcpc_store_adam_state exports them): TILE-MAJOR --
+// the 16 chains x 16 units a wave's float4 access covers are one contiguous KiB, in lane order, instead of sixteen 64-byte pieces of
+// sixteen rows.  A row-major access costs the CU's vector-memory path about 100 cycles per wave instruction, a contiguous one a
+// fraction of that, and that path is what the step kernel is bound by: the MAP warm-up (Adam on x) took 62.4 us
+// per step at cfg-M with row-major moments against 52.0 for SGD with the kick.
+// Float offset of units u0 .. u0+3 (u0 a multiple of 4) of `chain` in an image of npad-wide rows:
+__device__ __forceinline__ size_t adam_state_offset(int chain, int u0, int npad) {
+    return (((size_t)(chain >> 4) * (npad >> 4) + (u0 >> 4)) * 64 + (chain & 15) + 16 * ((u0 >> 2) & 3)) * 4;
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 // streamed once per step (state, targets, spills): nontemporal, so the per-XCD L2 (4 MiB) keeps the
@@ -625,11 +635,12 @@ __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph,
                     xn = x - g * lr;
                 } else {
                     // torch.optim.Adam single-tensor path: lerp_, mul_/addcmul_, sqrt/bias2 + eps, addcdiv_ (adam_x, mcpc_device.h)
-                    f32x4 m = ld4s(Ly.m + row), v = ld4s(Ly.v + row);
+                    const size_t mrow = adam_state_offset(chain, u0, npad);      // (tile-major: see adam_state_offset)
+                    f32x4 m = ld4s(Ly.m + mrow), v = ld4s(Ly.v + mrow);
                     m = m + (g - m) * P.omb1;
                     v = v * P.beta2 + (g * g) * P.omb2;
-                    st4s(Ly.m + row, m);
-                    st4s(Ly.v + row, v);
+                    st4s(Ly.m + mrow, m);
+                    st4s(Ly.v + mrow, v);
                     const float step_size = P.adam_coef[2 * s], inv_bc2 = P.adam_coef[2 * s + 1], eps = P.eps;
                     xn.x = adam_x(x.x, m.x, v.x, step_size, inv_bc2, eps);
                     xn.y = adam_x(x.y, m.y, v.y, step_size, inv_bc2, eps);
@@ -912,6 +923,15 @@ __global__ void mcpc_pad_kernel(const float* __restrict__ src, float* __restrict
         dst[idx] = (src != nullptr && row < B && col < n) ? src[(size_t)row * n + col] : 0.f;
     }
 }
+// export of Adam's moments: the engine keeps them tile-major (adam_state_offset), the caller gets [B][n]
+__global__ void mcpc_unpad_adam_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int n, int npad) {
+    const size_t total = (size_t)B * n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = idx / n, col = idx % n;
+        dst[idx] = src[adam_state_offset(row, col & ~3, npad) + (col & 3)];
+    }
+}
+
 __global__ void mcpc_unpad_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int n, int npad) {
     const size_t total = (size_t)B * n;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {

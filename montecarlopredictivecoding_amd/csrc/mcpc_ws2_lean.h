@@ -268,8 +268,10 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
 #endif
             }
             if constexpr (ADAM) {
-                mv[i][ct] = gld4s(Ly.m, rowb[ct] + tb);
-                vv[i][ct] = gld4s(Ly.v, rowb[ct] + tb);
+                // (moments are kept tile-major: one contiguous KiB per wave access, adam_state_offset in mcpc_kernels.h)
+                const uint32_t mb = (mul24(L.chain[ct] >> 4, (uint32_t)Ly.ntiles) + (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0))) * 1024u + 16u * (uint32_t)(L.c + 16 * L.q);
+                mv[i][ct] = gld4s(Ly.m, mb);
+                vv[i][ct] = gld4s(Ly.v, mb);
             }
 #ifdef MCPC_EXP_NOELOAD
             if (l == 0) ev[i][ct] = (xv[i][ct] - splat(0.25f)) * ecoef;
@@ -328,8 +330,9 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
                 f32x4 m = mv[i][ct], v = vv[i][ct];
                 m = m + (g - m) * P.omb1;
                 v = v * P.beta2 + (g * g) * P.omb2;
-                gst4s(Ly.m, rowb[ct] + tb, m);
-                gst4s(Ly.v, rowb[ct] + tb, v);
+                const uint32_t mb = (mul24(L.chain[ct] >> 4, (uint32_t)Ly.ntiles) + (uint32_t)tile) * 1024u + 16u * (uint32_t)(L.c + 16 * L.q);
+                gst4s(Ly.m, mb, m);
+                gst4s(Ly.v, mb, v);
                 const float step_size = P.adam_coef[2 * s_tab], inv_bc2 = P.adam_coef[2 * s_tab + 1], eps = P.eps;
                 xn.x = adam_x(x.x, m.x, v.x, step_size, inv_bc2, eps);
                 xn.y = adam_x(x.y, m.y, v.y, step_size, inv_bc2, eps);
