@@ -1061,6 +1061,12 @@ HebPlan plan_hebbian(const mcpc_engine* e, int ne, int na, int rows) {
         // ~48 stages of 32 rows per workgroup (0.3 ms at cfg-M): short enough that the step kernel's next segment never
         // waits long for CUs, long enough that the slab traffic stays at a few percent of the spill's
         int want = e->knobs.dw_ksplit > 0 ? e->knobs.dw_ksplit : std::max(1, rows / (48 * kHebKB));
+        // a small flush (the reference's batch of 256: 25 600 rows, 16 splits) would run 16-48 workgroups of 48 stages on an idle chip,
+        // 0.10-0.17 ms per Linear: with at least 8 stages per workgroup, split until the launch has about a workgroup per CU
+        if (e->knobs.dw_ksplit <= 0) {
+            const int cols = std::max(1, (h.n_mt[0] + h.n_mt[1]) * h.n_nt);
+            want = std::max(want, std::min(rows / (8 * kHebKB), (256 + cols - 1) / cols));
+        }
         want = std::min(want, std::max(1, rows / kHebKB));
         h.ksplit_cap = want;
         h.rps = ((rows + want - 1) / want + kHebKB - 1) / kHebKB * kHebKB;
