@@ -53,17 +53,19 @@ def test_plan_mirror_of_known_cases():
     assert _plan(258) == (12, 11) and _plan(3000) == (12, 1)
 
 
-@pytest.mark.parametrize("batch,T,acc0", [(6000, 331, 97), (4800, 140, 33), (4112, 90, 20), (8192, 150, 61), (12000, 70, 30)])
+@pytest.mark.parametrize("batch,T,acc0", [(6000, 331, 97), (4800, 140, 33), (4112, 90, 20), (8192, 150, 61), (12000, 70, 30),
+                                          (4097, 41, 11), (5555, 41, 11), (9999, 41, 11)])
 def test_round_schedule_matches_other_schedules_bitwise(batch, T, acc0):
     """A learning call (inference stretch, then Hebbian segments through the spill ring) on the default plan against the hardware
-    rounds of the 16-chain kernel and against 32-chain workgroups."""
+    rounds of the 16-chain kernel and against 32-chain workgroups.  The last three sizes end in a partly filled workgroup (1, 3 and 15
+    chains of 16) and one that is all padding (4097: Bpad = 4128)."""
     W, b, y, xs = _problem(batch)
     outs = {}
     for key, tuning in (("rounds", None), ("hw", HW_ROUNDS), ("wg32", WG32)):
         eng = _engine(batch, W, b, y, tuning=tuning)
         q = eng.query()
         if key == "rounds":
-            assert q["chains_per_wg"] == 16 and _km(eng) == _plan(q["n_workgroups"]), q
+            assert q["chains_per_wg"] == 16 and q["n_workgroups"] == (batch + 15) // 16 and _km(eng) == _plan(q["n_workgroups"]), q
             m = _km(eng)[1]
         elif key == "hw":
             assert q["chains_per_wg"] == 16 and _km(eng) is None
