@@ -158,6 +158,7 @@ struct mcpc_engine {
     float* e0sum = nullptr;
     float* mu1 = nullptr;
     float* ypad = nullptr;
+    float* ytile = nullptr;         // tile-major copy of ypad (KHead::ytile)
     uint32_t* ybits = nullptr;      // bit-packed copy of a 0/1 target (see mcpc_pack_target_bits_kernel)
     int* y_binary = nullptr;        // device flag: the bound target is exactly 0/1 everywhere
     int ywords = 0;
@@ -259,7 +260,7 @@ int free_all(mcpc_engine* e) {
     if (e->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(e->comm); e->comm = nullptr; e->comm_ranks = 0; }
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int l = 0; l < kMaxLatent; ++l) { F(e->x[l]); F(e->m[l]); F(e->v[l]); F(e->spill_a[l]); F(e->spill_e[l]); }
-    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err); F(e->dummy);
+    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ytile); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err); F(e->dummy);
     for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : e->events_mix) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -847,7 +848,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if ((rc = dmalloc(e->e0sum, (size_t)e->Bpad * e->npad[0])) || (rc = dmalloc(e->mu1, (size_t)e->Bpad * e->npad[0]))) return bail(rc);
     if (hipMemset(e->e0sum, 0, (size_t)e->Bpad * e->npad[0] * 4) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
     if (e->has_head) {
-        if ((rc = dmalloc(e->ypad, (size_t)e->Bpad * e->out_pad))) return bail(rc);
+        if ((rc = dmalloc(e->ypad, (size_t)e->Bpad * e->out_pad)) || (rc = dmalloc(e->ytile, (size_t)e->Bpad * e->out_pad))) return bail(rc);
         if (hipMemset(e->ypad, 0, (size_t)e->Bpad * e->out_pad * 4) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
         e->ywords = (e->out_pad + 31) / 32;
         if ((rc = dmalloc(e->ybits, (size_t)e->Bpad * e->ywords)) || (rc = dmalloc(e->y_binary, 2))) return bail(rc);
@@ -967,6 +968,7 @@ int mcpc_bind_target(mcpc_engine* e, const float* target, void* stream_) {
     const size_t total = (size_t)e->Bpad * e->out_pad;
     hipLaunchKernelGGL(mcpc_pad_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream_, target, e->ypad,
                        e->d.batch, e->d.n_out, e->Bpad, e->out_pad);
+    hipLaunchKernelGGL(mcpc_tile_major_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream_, e->ypad, e->ytile, e->Bpad, e->out_pad);
     // a 0/1 target (the Bernoulli read-out's usual one) is also kept bit-packed; the flag tells the step kernel which to read
     HIP_TRY(hipMemsetAsync(e->y_binary, 0xff, sizeof(int), (hipStream_t)stream_));
     hipLaunchKernelGGL(mcpc_pack_target_bits_kernel, dim3(grid_for((size_t)e->Bpad * e->ywords)), dim3(256), 0, (hipStream_t)stream_,
@@ -1384,7 +1386,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         const Lin& ln = e->lin[e->L];
         H.Wf = (const f32x4*)ln.Wf; H.Wb = (const f32x4*)ln.Wb; H.bias = ln.bias_pad;
         H.ybits = e->ybits; H.y_binary = e->knobs.no_ybits ? e->y_binary + 1 : e->y_binary; H.ywords = e->ywords;
-        H.y = e->ypad; H.rec_out = r->rec_count > 0 ? r->rec_out : nullptr; H.spill_e = e->spill_eo;
+        H.y = e->ypad; H.ytile = e->ytile; H.rec_out = r->rec_count > 0 ? r->rec_out : nullptr; H.spill_e = e->spill_eo;
         H.n = e->d.n_out; H.npad = e->out_pad; H.ntiles = e->out_pad / 16;
         H.loss_kind = r->loss_kind;
         H.inv_var = r->loss_kind == MCPC_LOSS_GAUSSIAN ? (float)(1.0 / (double)r->loss_var) : 1.0f;

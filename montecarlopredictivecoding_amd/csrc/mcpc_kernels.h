@@ -53,6 +53,7 @@ struct KHead {
     const f32x4* Wb;       // [ntiles(L-1)][ntiles][64]
     const float* bias;     // [npad]
     const float* y;        // padded target [Bpad][npad]
+    const float* ytile;    // the same image tile-major (tile_major_offset): what the lean read-out epilogue reads of an fp32 target
     const uint32_t* ybits; // the same bit-packed, [Bpad][ywords] (bit u & 31 of word u >> 5 = y[chain][u]); valid iff *y_binary
     const int* y_binary;   // device flag set by mcpc_bind_target: every target value is exactly 0.0f or 1.0f
     int ywords;            // words per chain = ceil(npad / 32)
@@ -177,13 +178,13 @@ __device__ __forceinline__ void mfma_block(f32x4 (&acc)[NTT][CTT], const f32x4 (
         for (int ct = 0; ct < CTT; ++ct) acc[t][ct] = mfma16(a[t].w, b[ct].w, acc[t][ct]);
 }
 
-// Layout of Adam's moments m_l, v_l (only the x update reads and writes them, mcpc_store_adam_state exports them): TILE-MAJOR --
+// Layout of images only the epilogues read or write -- Adam's moments m_l, v_l, the tile-major copy of an fp32 target: TILE-MAJOR --
 // the 16 chains x 16 units a wave's float4 access covers are one contiguous KiB, in lane order, instead of sixteen 64-byte pieces of
 // sixteen rows.  A row-major access costs the CU's vector-memory path about 100 cycles per wave instruction, a contiguous one a
 // fraction of that, and that path is what the step kernel is bound by: the MAP warm-up (Adam on x) took 62.4 us
 // per step at cfg-M with row-major moments against 52.0 for SGD with the kick.
 // Float offset of units u0 .. u0+3 (u0 a multiple of 4) of `chain` in an image of npad-wide rows:
-__device__ __forceinline__ size_t adam_state_offset(int chain, int u0, int npad) {
+__device__ __forceinline__ size_t tile_major_offset(int chain, int u0, int npad) {
     return (((size_t)(chain >> 4) * (npad >> 4) + (u0 >> 4)) * 64 + (chain & 15) + 16 * ((u0 >> 2) & 3)) * 4;
 }
 
@@ -635,7 +636,7 @@ __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph,
                     xn = x - g * lr;
                 } else {
                     // torch.optim.Adam single-tensor path: lerp_, mul_/addcmul_, sqrt/bias2 + eps, addcdiv_ (adam_x, mcpc_device.h)
-                    const size_t mrow = adam_state_offset(chain, u0, npad);      // (tile-major: see adam_state_offset)
+                    const size_t mrow = tile_major_offset(chain, u0, npad);      // (tile-major: see tile_major_offset)
                     f32x4 m = ld4s(Ly.m + mrow), v = ld4s(Ly.v + mrow);
                     m = m + (g - m) * P.omb1;
                     v = v * P.beta2 + (g * g) * P.omb2;
@@ -915,6 +916,15 @@ __global__ void mcpc_pack_target_bits_kernel(const float* __restrict__ ypad, uin
     }
 }
 
+// tile-major copy of a padded image [Bpad][npad] (tile_major_offset: the 16 chains x 16 units of a wave access contiguous)
+__global__ void mcpc_tile_major_kernel(const float* __restrict__ src, float* __restrict__ dst, int Bpad, int npad) {
+    const size_t total = (size_t)Bpad * npad / 4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int row = idx / (npad / 4), u0 = 4 * (int)(idx % (npad / 4));
+        *reinterpret_cast<f32x4*>(dst + tile_major_offset(row, u0, npad)) = *reinterpret_cast<const f32x4*>(src + (size_t)row * npad + u0);
+    }
+}
+
 // dst[Bpad][npad] <- src[B][n] (zero padded)      /     dst[B][n] <- src[Bpad][npad]
 __global__ void mcpc_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int n, int Bpad, int npad) {
     const size_t total = (size_t)Bpad * npad;
@@ -923,12 +933,12 @@ __global__ void mcpc_pad_kernel(const float* __restrict__ src, float* __restrict
         dst[idx] = (src != nullptr && row < B && col < n) ? src[(size_t)row * n + col] : 0.f;
     }
 }
-// export of Adam's moments: the engine keeps them tile-major (adam_state_offset), the caller gets [B][n]
+// export of Adam's moments: the engine keeps them tile-major (tile_major_offset), the caller gets [B][n]
 __global__ void mcpc_unpad_adam_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int n, int npad) {
     const size_t total = (size_t)B * n;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int row = idx / n, col = idx % n;
-        dst[idx] = src[adam_state_offset(row, col & ~3, npad) + (col & 3)];
+        dst[idx] = src[tile_major_offset(row, col & ~3, npad) + (col & 3)];
     }
 }
 

@@ -268,7 +268,7 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
 #endif
             }
             if constexpr (ADAM) {
-                // (moments are kept tile-major: one contiguous KiB per wave access, adam_state_offset in mcpc_kernels.h)
+                // (moments are kept tile-major: one contiguous KiB per wave access, tile_major_offset in mcpc_kernels.h)
                 const uint32_t mb = (mul24(L.chain[ct] >> 4, (uint32_t)Ly.ntiles) + (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0))) * 1024u + 16u * (uint32_t)(L.c + 16 * L.q);
                 mv[i][ct] = gld4s(Ly.m, mb);
                 vv[i][ct] = gld4s(Ly.v, mb);
@@ -401,8 +401,10 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                 yv[i][ct] = splat(0.f);
                 yw[i][ct] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds + H.lds_yw) + mul24(L.lrow[ct], wrow4) + 4u * (uint32_t)(tile >> 1));
             } else if constexpr (XL) {
+                // (an fp32 target is read from its tile-major image: one contiguous KiB per wave access, like Adam's moments)
                 const bool has_y = kind != MCPC_LOSS_NONE;
-                yv[i][ct] = gld4s(has_y ? H.y : H.bias, has_y ? rowb[ct] + tb : 16u * L.q + tb);
+                yv[i][ct] = gld4s(has_y ? H.ytile : H.bias,
+                                  has_y ? (mul24(L.chain[ct] >> 4, (uint32_t)H.ntiles) + (uint32_t)tile) * 1024u + 16u * (uint32_t)(L.c + 16 * L.q) : 16u * L.q + tb);
                 yw[i][ct] = 0u;
             } else {
             // Branch-free on purpose (a load under an `if` makes hipcc join the paths behind `s_waitcnt vmcnt(0)`, which here
