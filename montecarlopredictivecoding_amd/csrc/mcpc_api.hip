@@ -287,6 +287,10 @@ int dmalloc(T*& p, size_t count) {
     void* q = nullptr;
     hipError_t err = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
     if (err != hipSuccess) return fail(MCPC_ENOMEM, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(err));
+#ifdef MCPC_POISON_ALLOC      // diagnostic build: every fresh device allocation is filled with 0xFF bytes (NaN as fp32 / fp64, -1 as int), so that a
+                              // read of memory nobody initialised shows on every box, not only on one whose fresh pages are not zero
+    if (hipMemset(q, 0xFF, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return fail(MCPC_EHIP, "hipMemset (poison) failed");
+#endif
     p = (T*)q;
     return 0;
 }

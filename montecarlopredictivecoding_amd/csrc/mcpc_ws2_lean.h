@@ -10,8 +10,8 @@
 //     a row offset per chain tile computed once per entry (v_mul_u32_u24), one v_add per tile;
 //   * per-element `live` / padding / mask predicates -> padded units and partial loss masks are handled by a wave-uniform branch on
 //     the one tile that has them; padding CHAINS (the last workgroup of a batch that is not a multiple of 16) cost one per-lane mask:
-//     they evolve like any chain, and their energy terms are multiplied by 0, their spills ANDed with 0, their records skipped
-//     (LeanLane::livef / livem) -- until round 3 such a workgroup took the generic epilogues and every launch waited for it (+17 %
+//     they evolve like any chain, and their energy terms are dropped by a select, their spills ANDed with 0, their records skipped
+//     (LeanLane::livem) -- until round 3 such a workgroup took the generic epilogues and every launch waited for it (+17 %
 //     per step at 7000 chains);
 //   * three loads per slot whatever the entry type   -> each entry type requests exactly its operands.
 // The arithmetic per element is the generic epilogue's, operation for operation: trajectories stay bitwise those of the
@@ -71,7 +71,6 @@ struct LeanLane {
     int c, q;
     uint32_t chain[CTT];       // global row (chain) of this lane in chain tile ct
     uint32_t lrow[CTT];        // 16 ct + c: row inside the workgroup's LDS images
-    float livef[CTT];          // 1.0f for a chain of the batch, 0.0f for a padding chain
     uint32_t livem[CTT];       // ~0u / 0u
 };
 __device__ __forceinline__ f32x4 mask4(f32x4 v, uint32_t m) {
@@ -182,7 +181,7 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
             }
             if (rec != nullptr && L.livem[ct]) st_unpadded(rec, (int)L.chain[ct], Ly.n, 16 * tile + 4 * L.q, x);
             const f32x4 dd = d * d;
-            esum += L.livef[ct] * (0.5f * ecoef * (dd.x + dd.y + dd.z + dd.w));
+            esum += L.livem[ct] ? 0.5f * ecoef * (dd.x + dd.y + dd.z + dd.w) : 0.f;          // (a select, not a product: whatever a padding chain holds)
         }
     }
     return esum;
@@ -459,7 +458,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                         const bool on = inside || ((u0 + r) >= mask_start && (u0 + r) < n);
                         const float dlt = ov[r] - yy[r];
                         ev[r] = on ? inv_var * dlt : 0.f;
-                        lsum += on ? L.livef[ct] * (0.5f * inv_var * dlt * dlt) : 0.f;
+                        lsum += (on && L.livem[ct]) ? 0.5f * inv_var * dlt * dlt : 0.f;
                     }
                 } else if (do_energy) {
                     if (inside) {
@@ -468,7 +467,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                             float sg, bc;
                             sigmoid_bce_f(ov[r], yy[r], sg, bc);
                             ev[r] = sg - yy[r];
-                            lsum += L.livef[ct] * bc;
+                            lsum += L.livem[ct] ? bc : 0.f;
                         }
                     } else {
 #pragma unroll
@@ -477,7 +476,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                             float sg, bc;
                             sigmoid_bce_f(ov[r], yy[r], sg, bc);
                             ev[r] = on ? sg - yy[r] : 0.f;
-                            lsum += on ? L.livef[ct] * bc : 0.f;
+                            lsum += (on && L.livem[ct]) ? bc : 0.f;
                         }
                     }
                 } else {

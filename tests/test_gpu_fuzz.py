@@ -114,12 +114,13 @@ def test_wide_networks_against_oracle(sizes, n_out):
                       acc_begin=1, acc_end=T, energy_mode=L.ENERGY_ALL)
         eng.store_state(xs)
         eng.sync_check()
-        np.testing.assert_allclose(res.energies.cpu().numpy()[:, -1], ref.overall, rtol=1e-4)
+        en = res.energies.cpu().numpy()
+        np.testing.assert_allclose(en[:, -1], ref.overall, rtol=1e-4, err_msg=f"tuning {tuning}: energies\n{en}")
         for l in range(len(sizes)):
-            np.testing.assert_allclose(xs[l].cpu().numpy(), ref.xs[l], rtol=0, atol=5e-4 * max(1.0, float(np.abs(ref.xs[l]).max())))
+            np.testing.assert_allclose(xs[l].cpu().numpy(), ref.xs[l], rtol=0, atol=5e-4 * max(1.0, float(np.abs(ref.xs[l]).max())), err_msg=f"tuning {tuning}")
         flat = eng.read_param_grads_flat().cpu().numpy()
         want = np.concatenate([np.concatenate([gw.reshape(-1), gb.reshape(-1)]) for gw, gb in zip(ref.gW, ref.gb)])
-        np.testing.assert_allclose(flat, want, rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(want).max())))
+        np.testing.assert_allclose(flat, want, rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(want).max())), err_msg=f"tuning {tuning}")
         eng.close()
     assert len(seen) >= 2
 
