@@ -379,6 +379,13 @@ int plan_lds_ws2(mcpc_engine* e, bool allow_xl = true) {
         if (CT == 16 && L >= 2 && fits_apart(hc, nb) && !e->knobs.overlay16) { e->ws2_overlay = false; e->lds_eo = off + e_sum; }
     }
     off += e->ws2_overlay ? std::max(ring_floats, e_sum) : ring_floats + e_sum;
+#ifdef MCPC_GEMM_BF16X6
+    // The bf16x6 core reads the LDS operand in whole 32-deep k-blocks: up to 12 floats beyond a row whose width is not a multiple of
+    // 32 (zero weights there, so the values only have to be FINITE).  Inside the plan that is the next row or the next region, which
+    // the kernel zero-fills at launch; the last row of the last operand region (E_{L-1} when it ends the shared region) would reach
+    // past the plan into LDS another kernel left behind: 16 floats of slack keep it inside.
+    off += 16;
+#endif
     // with room to spare (16-chain plans: 45 KB at cfg-M) the lean epilogues keep what they read every step in LDS: the state rows
     // X_l (layout of FX_l), the bias rows, the mu_1 rows (layout of FX_0), the read-out bias and the bit-packed target rows
     e->xl = false;
