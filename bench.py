@@ -19,7 +19,9 @@ One bench "step" = ONE CALL of the hot path in BASELINE.json's configuration (cf
 
 Everything in the timed region goes through the C ABI (libmcpc.so); inputs are resident in HBM before the clock starts.
 `roofline` is computed from HIP events the library records on its launch stream (mcpc_set_profiling) during the timed
-calls.  `cpu_baseline` (rank 0, N = 1 only) times oracle/torch_port.py -- a torch-autograd port with the reference's op
+calls; its `peak` is the ceiling of the pipe the kernel computes on (fp32 products as six bf16 MFMA products: dense bf16 peak / 6),
+the fp32 MFMA peak SURVEY 8(d) names is carried beside it; `traffic` comes from the tracked PMC summary of the same command
+(profiles/, separate --pmc passes: counters cannot be read inside this run) with its source named.  `cpu_baseline` (rank 0, N = 1 only) times oracle/torch_port.py -- a torch-autograd port with the reference's op
 mix -- on the host cores for a bounded sample.
 """
 import argparse
@@ -48,8 +50,37 @@ FRAG_BYTES_PER_WG_STEP = 2 * 6 * (32 * 256 + 256 * 256 + 256 * 784)
 # peak -- the dense MFMA peak of the dtype the path computes in -- and the line carries this second ceiling beside it.
 PEAK_BF16X6_TFLOPS = 2516.0 / 6.0
 # What binds a 16-chain workgroup of the step kernel with this core: the packed weights it streams out of L2 once per step through its
-# CU's vector-memory return path, 64 B per clock (MI355X_MICROARCH.md) at the 2.4 GHz peak shader clock.
-PEAK_L1_FILL_GBS_PER_CU = 64 * 2.4
+# CU's vector-memory return path, 64 B per clock (MI355X_MICROARCH.md) -- at the shader clock the chip holds under THIS load, which the
+# library measures during the timed launches (mcpc_last_shader_clock_ghz: 1.8-2.0 GHz; the 2.4 GHz peak only as a fallback).
+L1_FILL_BYTES_PER_CLK = 64
+PEAK_SHADER_GHZ = 2.4
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+
+
+def pmc_traffic(mode, kernel_name):
+    """HBM bytes per launch of the step kernel from the tracked PMC summary (scripts/pmc_round.sh + scripts/reduce_pmc.py: separate
+    --pmc passes of this command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads), or None."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            summ = json.load(f)
+        sect = summ.get(mode) or {}
+        key = next((k for k in sect if k.startswith("mcpc_steps_ws2_kernel") or k in kernel_name), None)
+        if key is None:
+            return None
+        ent = sect[key]
+        n, d, c = ent["dispatches"], ent["derived"], ent["counters"]
+        out = {"hbm_read_bytes_per_launch": d["hbm_read_bytes"] / n, "hbm_write_bytes_per_launch": d["hbm_write_bytes"] / n,
+               "launches": n, "kernel": key,
+               "source": "profiles/r04_pmc_summary.json, section '%s' (rocprofv3 --pmc passes of `bench.py %s`, builder-run; "
+                         "FETCH_SIZE x 2, WRITE_SIZE as read)" % (mode, "--no-secondary" if mode == "learning" else "--only-inference")}
+        if "TCC_REQ_sum" in c:
+            # the fragment stream out of L2: requests of 128 B (the call the passes profiled: summ['meta'])
+            out["l2_request_bytes_per_launch"] = c["TCC_REQ_sum"] * 128.0 / n
+        if "meta" in summ:
+            out["meta"] = summ["meta"]
+        return out
+    except (OSError, KeyError, ValueError, StopIteration):
+        return None
 
 
 def make_problem(batch, seed, device):
@@ -106,9 +137,9 @@ def main():
     ap.add_argument("--batch", type=int, default=6000, help="chains per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the inference-only calls (clean PMC passes of the learning call)")
-    ap.add_argument("--only-inference", action="store_true", help="time inference-only calls only (clean PMC passes of the mixed schedule)")
+    ap.add_argument("--only-inference", action="store_true", help="time inference-only calls only (clean PMC passes of the inference call)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--no-self-check", action="store_true", help="skip the replay of one call on the serial / plain schedule (PMC passes)")
+    ap.add_argument("--no-self-check", action="store_true", help="skip the replay of one call on the serial schedule of the barrier kernel (PMC passes)")
     ap.add_argument("--force-dist", action="store_true",
                     help="developer check: take the multi-rank code path (RCCL group, barriers, all-reduces) with whatever world size the "
                          "environment gives, 1 included -- the 1-GPU rehearsal of what the driver launches with torch.distributed.run")
@@ -183,26 +214,25 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         eng.sync_check()          # raises if a kernel reported a device-side fault during the timed calls
-        plain = eng.last_step_kernel_ms()
-        mixed = eng.last_mixed_cycles_ms()
+        plain = eng.last_step_kernel_ms() + (eng.last_shader_clock_ghz(),)
         eng.set_profiling(False)
         if dist is not None:
             tt = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, res, plain, mixed
+        return dt, res, plain
 
     for _ in range(Wm):
         if not args.only_inference:
             one_call(True)
         if not args.no_secondary:
             one_call(False)
-    dt_learn = res = plain_l = mixed_l = None
+    dt_learn = res = plain_l = None
     if not args.only_inference:
-        dt_learn, res, plain_l, mixed_l = timed(True, K)
-    dt_inf = plain_i = mixed_i = None
+        dt_learn, res, plain_l = timed(True, K)
+    dt_inf = plain_i = None
     if not args.no_secondary or args.only_inference:
-        dt_inf, res_i, plain_i, mixed_i = timed(False, K)
+        dt_inf, res_i, plain_i = timed(False, K)
         res = res if res is not None else res_i
     primary_learning = dt_learn is not None
     dt = dt_learn if primary_learning else dt_inf
@@ -211,9 +241,9 @@ def main():
     finite = all(abs(v) < 1e30 for v in en)
 
     # ---- self-check (outside the timed region): ONE call of the timed kind from the initial state, on the tuning that was
-    # timed and on the serial / plain one (32-chain workgroups, one launch per segment, one spill-ring part flushed on the
-    # caller's stream: another workgroup form and schedule, nothing overlaps, nothing can race).  Per chain both run the same arithmetic in the same order, so the final state and the
-    # records must agree BITWISE, the gradient bucket up to nothing (same 64-step Hebbian segments) and the energies up to
+    # timed and on the serial one (the BARRIER kernel -- another program: four waves per workgroup, s_barrier hand-overs, generic
+    # epilogues -- one launch per segment, one spill-ring part flushed on the caller's stream: nothing overlaps, nothing can race).  Per chain both run the same arithmetic in the same order, so the final state and the
+    # records must agree BITWISE, the gradient bucket up to nothing (same 128-step Hebbian segments) and the energies up to
     # the grouping of fp32 partial sums.  What the reference defines for these: pc_trainer.py:853-862 (dF/dtheta summed over
     # accumulate_p_at), :904-914 (normalisation).
     self_check = None
@@ -230,16 +260,17 @@ def main():
             engine.sync_check()
             return r_, st, fl
         ra, sa, fa = replay(eng)
-        serial = "rr=0,no_mix=1,no_overlap=1,slot_cap=128"
+        serial = "ws=0,no_overlap=1,slot_cap=128"
         eng_s = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=device, tuning=serial)
         eng_s.bind_params(W, b)
         eng_s.bind_inputs(None)
         eng_s.bind_target(y)
+        eng_s_name = eng_s.query()["step_kernel"]
         rb, sb, fb = replay(eng_s)
         eng_s.close()
         ea, eb = ra.energies, rb.energies
         self_check = {
-            "reference": "the same call (initial state, seed, Philox step base 0) on tuning '%s'" % serial,
+            "reference": "the same call (initial state, seed, Philox step base 0) on tuning '%s': %s" % (serial, eng_s_name),
             "mode": "learning call" if primary_learning else "inference-only call",
             "bitwise_state": all(torch.equal(p_, q_) for p_, q_ in zip(sa, sb)),
             "bitwise_records": all(torch.equal(p_, q_) for p_, q_ in zip(ra.rec_x, rb.rec_x)),
@@ -262,56 +293,64 @@ def main():
         flops_heb = 2.0 * S_MACS * B     # + the Hebbian sums e^T f(x) on accumulating steps
         bytes_per_step = 7472.0 * B
 
-        def kernel_line(kernel, ms_n_steps, flops_per_step, note, n_wg, wg_per_launch=None):
-            ms, n, steps = ms_n_steps
+        def kernel_line(kernel, prof, flops_per_step, note, n_wg, wg_per_launch, mode):
+            ms, n, steps, ghz = prof
             if not n or not steps:
                 return None
             avg_s = ms * 1e-3 / n
             spl = steps / n
             tf = flops_per_step * spl / avg_s / 1e12
-            return {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / PEAK_FP32_TFLOPS, "traffic": None, "brackets": n, "steps_per_bracket": spl,
+            clk = ghz if ghz and ghz > 0.5 else PEAK_SHADER_GHZ
+            l1_peak = L1_FILL_BYTES_PER_CLK * clk
+            l1_ach = FRAG_BYTES_PER_WG_STEP * spl * n_wg / wg_per_launch / avg_s / 1e9
+            pmc = pmc_traffic(mode, kernel)
+            line = {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16X6_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / PEAK_BF16X6_TFLOPS,
+                    "peak_is": "the ceiling of the pipe this kernel computes on: every fp32 product is six v_mfma_f32_16x16x32_bf16 products "
+                               "(fp32 accumulate), so dense bf16 peak 2516 / 6; the kernel issues no fp32 MFMA (SQ_INSTS_VALU_MFMA_F32 = 0)",
+                    "fp32_mfma": {"peak": PEAK_FP32_TFLOPS, "frac": tf / PEAK_FP32_TFLOPS,
+                                  "note": "the fp32 MFMA peak SURVEY 8(d) prescribes for dtype f32; not a ceiling of this kernel"},
+                    # HBM bytes per launch from the PMC counters (separate passes of the same command, tracked summary)
+                    "traffic": None if pmc is None else pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"],
+                    "traffic_detail": pmc,
+                    "algorithmic_flop_per_launch": flops_per_step * spl,
+                    "brackets": n, "steps_per_bracket": spl,
                     "avg_bracket_ms": avg_s * 1e3, "us_per_step": avg_s / spl * 1e6,
                     "flop_per_chain_step": 4 * S_MACS,
-                    "bf16x6_pipe": {"peak": PEAK_BF16X6_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_BF16X6_TFLOPS,
-                                    "note": "fp32 products as 6 bf16 MFMA products, fp32 accumulate: dense bf16 peak / 6"},
+                    "shader_clock_ghz": ghz,
                     # the same launches against the HBM roofline (north_star asks for both): algorithmic streaming bytes, SURVEY 8(d)
                     "hbm_side": {"achieved": bytes_per_step * spl / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": bytes_per_step * spl / avg_s / 1e9 / PEAK_HBM_GBS, "bytes_per_chain_step": 7472},
-                    # every workgroup streams the packed weights (Wf + Wb, 2.19 MB) out of its XCD's L2 once per step
+                    # every workgroup streams the packed weights (Wf + Wb as three bf16 planes, 3.29 MB) out of its XCD's L2 once per step
                     "l2_fragment_stream": {"achieved": n_wg * FRAG_BYTES_PER_WG_STEP * spl / avg_s / 1e9, "peak": PEAK_L2_GBS,
                                            "unit": "GB/s", "frac": n_wg * FRAG_BYTES_PER_WG_STEP * spl / avg_s / 1e9 / PEAK_L2_GBS,
                                            "workgroups": n_wg, "bytes_per_workgroup_step": FRAG_BYTES_PER_WG_STEP},
                     # the same stream per CU: a workgroup of a launch does spl * n_wg / wg_per_launch steps in it
-                    "l1_fill_per_cu": {"achieved": FRAG_BYTES_PER_WG_STEP * spl * n_wg / (wg_per_launch or n_wg) / avg_s / 1e9,
-                                       "peak": PEAK_L1_FILL_GBS_PER_CU, "unit": "GB/s",
-                                       "frac": FRAG_BYTES_PER_WG_STEP * spl * n_wg / (wg_per_launch or n_wg) / avg_s / 1e9 / PEAK_L1_FILL_GBS_PER_CU,
-                                       "workgroups_per_launch": wg_per_launch or n_wg,
-                                       "note": "the resource that binds the bf16x6 step kernel at 16 chains per workgroup (DESIGN section 4): "
+                    "l1_fill_per_cu": {"achieved": l1_ach, "peak": l1_peak, "unit": "GB/s", "frac": l1_ach / l1_peak,
+                                       "peak_is": "64 B per clock x the shader clock measured during these launches (%s)"
+                                                  % ("%.3f GHz" % ghz if ghz and ghz > 0.5 else "not measured: 2.4 GHz peak"),
+                                       "workgroups_per_launch": wg_per_launch,
+                                       "note": "the resource that binds the step kernel at 16 chains per workgroup (DESIGN section 4): "
                                                "six MFMAs of 16 cycles per 3 KiB of fragments, four GEMM waves per CU on one 64 B/clk return path"},
                     "note": note}
+            return line
 
-        # the dominant kernel of the timed call: the step kernel's launches of the plain schedule (in a learning call: the
-        # 4000 Hebbian steps, one launch per half of the spill ring); algorithmic FLOPs of the STEP kernel = 4 S per chain-step
-        # (the Hebbian GEMMs are a different kernel).  `traffic` (PMC) cannot be measured inside this run: the per-launch
-        # figure of the same command lives in profiles/ (README there) and is deliberately not copied into this line.
+        # the dominant kernel of the timed call: every launch of the step kernel; algorithmic FLOPs of the STEP kernel = 4 S per
+        # chain-step (the Hebbian GEMMs are a different kernel)
         km = re.search(r"round schedule: k=(\d+) .* m=(\d+)", q["step_kernel"])
         wg_per_launch = q["n_workgroups"] if km is None else round(q["n_workgroups"] * int(km.group(2)) / int(km.group(1)))
-        roof = kernel_line("mcpc::mcpc_steps_ws2_kernel<2, false>" if q["chains_per_wg"] == 32 else q["step_kernel"],
-                           plain_l if primary_learning else plain_i, flops_inf,
+        roof = kernel_line(q["step_kernel"], plain_l if primary_learning else plain_i, flops_inf,
                            "HIP events around every launch of the step kernel during the timed "
                            + ("learning calls (mixing and Hebbian stretches alike; the Hebbian GEMMs of a segment run between and beside "
                               "the launches of the next); a launch of the round schedule advances its workgroups' share of the shard, "
                               "steps_per_bracket counts whole-shard steps" if primary_learning else "inference calls"),
-                           q["n_workgroups"], wg_per_launch)
-        mixed_line = kernel_line("mcpc::mcpc_steps_ws2_mixed_kernel (mixed schedule: 32-chain and 16-chain workgroups in one launch per segment)",
-                                 mixed_i if mixed_i is not None else mixed_l, flops_inf,
-                                 "HIP events around whole cycles of the mixed schedule during the timed "
-                                 + ("inference-only calls" if mixed_i is not None else "learning calls (mixing steps)"),
-                                 # one workgroup per CU: nwg pairs as 32-chain workgroups minus the split ones, which count twice
-                                 256 if q["n_workgroups"] < 256 else q["n_workgroups"])
-        if roof is None:
-            roof = mixed_line
+                           q["n_workgroups"], wg_per_launch, "learning" if primary_learning else "inference")
+        if roof is not None and primary_learning and plain_i is not None:
+            inf_line = kernel_line(q["step_kernel"], plain_i, flops_inf, "the same kernel's launches during the timed inference-only calls",
+                                   q["n_workgroups"], wg_per_launch, "inference")
+            if inf_line is not None:
+                roof["inference_only_launches"] = {k_: inf_line[k_] for k_ in ("achieved", "frac", "fp32_mfma", "traffic", "avg_bracket_ms",
+                                                                               "us_per_step", "shader_clock_ghz", "l1_fill_per_cu")}
         value = world * K * T / dt
         out = {
             "metric": "Langevin inference steps/sec (whole node), MNIST MCPC 784-256-256-30, batch 6000",
@@ -345,20 +384,20 @@ def main():
                     "steps_per_s": world * K * T / dt_inf, "us_per_langevin_step": dt_inf / (K * T) * 1e6, "calls": K,
                     "achieved_tflops": flops_inf * K * T / dt_inf / 1e12,
                     "frac_of_fp32_peak": flops_inf * K * T / dt_inf / 1e12 / PEAK_FP32_TFLOPS,
+                    "frac_of_bf16x6_pipe": flops_inf * K * T / dt_inf / 1e12 / PEAK_BF16X6_TFLOPS,
                     # the packed weights every workgroup streams out of L2 once per step (wall clock of the calls)
                     "l2_fragment_stream_gbs": q["n_workgroups"] * FRAG_BYTES_PER_WG_STEP * K * T / dt_inf / 1e9,
                     "l2_fragment_stream_frac_of_peak": q["n_workgroups"] * FRAG_BYTES_PER_WG_STEP * K * T / dt_inf / 1e9 / PEAK_L2_GBS},
                 "learning_call_flops": None if not primary_learning else {
                     "achieved_tflops": (flops_inf * T + flops_heb * (T - mixing)) * K / dt / 1e12,
                     "frac_of_fp32_peak": (flops_inf * T + flops_heb * (T - mixing)) * K / dt / 1e12 / PEAK_FP32_TFLOPS,
+                    "frac_of_bf16x6_pipe": (flops_inf * T + flops_heb * (T - mixing)) * K / dt / 1e12 / PEAK_BF16X6_TFLOPS,
                     "note": "whole call, wall clock: 4S per chain-step + 2S on the accumulating steps"},
                 "lds_bytes_per_wg": q["lds_bytes"], "chains_per_wg": q["chains_per_wg"],
                 "workgroups": q["n_workgroups"], "spill_slots": q["spill_slots"],
             },
             "roofline": roof,
         }
-        if mixed_line is not None and mixed_line is not roof:
-            out["roofline"]["mixed_schedule"] = mixed_line
         if self_check is not None:
             out["self_check"] = self_check
         if world == 1 and not args.no_cpu_baseline:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MCPC_ABI_VERSION 2
+#define MCPC_ABI_VERSION 3
 #define MCPC_MAX_LATENT 6
 
 /* status codes */
@@ -86,13 +86,15 @@ typedef struct mcpc_net_desc {
     int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default: room for 384 steps in three parts (17 GB at 6000
                                           * chains of cfg-M's net), at least 6 GiB, at most a quarter of the device's memory */
     const char* tuning;                  /* NULL, or developer overrides of the schedule heuristics as "key=value,key=value"
-                                          * (parsed once by mcpc_create, not kept): ws=0|2 step kernel (barrier / in-place),
-                                          * ct=16|32 chains per workgroup, nw=4|8, no_mix=1, no_overlap=1, slot_cap=N,
-                                          * spill_gb=N, ring_parts=N, flush_tail=N, flush_streams=1|2, mix_slack=N, mix_ratio=N, mix_pmax=N, dw_ksplit=N, ws_prio=0|1|2, stagger=N, no_lean=1, no_ybits=1, overlay16=1, heb_fp32=1 (the Hebbian GEMM on the fp32 MFMA instead of its bf16x6 form),
-                                          * rr=0 (shards of more 16-chain units than CUs as 32-chain workgroups + the mixed schedule instead of the round
-                                          * schedule), rr_qmax=N (most steps per launch of the round schedule), no_xl=1 (state and per-step constants of a
-                                          * workgroup's chains in global memory instead of LDS).  Unknown keys are
-                                          * an error.  Used by A/B runs and by the tests that pin every kernel variant. */
+                                          * (parsed once by mcpc_create, not kept): ws=0|2 step kernel (0: the barrier kernel, the
+                                          * fallback and the independent form parity checks replay the default against; 2: the in-place
+                                          * wave-specialised kernel, the default), no_overlap=1, slot_cap=N, spill_gb=N, ring_parts=N,
+                                          * flush_tail=N, flush_streams=1|2, cu_slack=N, dw_ksplit=N, ws_prio=0|1|2, stagger=N, no_lean=1,
+                                          * no_ybits=1, overlay16=1, heb_fp32=1 (the Hebbian GEMM on the fp32 MFMA instead of its bf16x6
+                                          * form), rr=0 (shards of more 16-chain units than CUs as ONE launch in hardware rounds instead of
+                                          * the round schedule), rr_qmax=N (most steps per launch of the round schedule), no_xl=1 (state and
+                                          * per-step constants of a workgroup's chains in global memory instead of LDS).  Unknown keys are
+                                          * an error.  Used by A/B runs and by the tests that pin the kernel forms against each other. */
 } mcpc_net_desc;
 
 /* One train_on_batch call (or a slice of it).  Steps are numbered 0..T-1 inside the call. */
@@ -209,16 +211,23 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
 const char* mcpc_step_kernel_name(const mcpc_engine* e);
 
 /* Timing hooks.  While profiling is enabled (mcpc_set_profiling(e, 1); every call of it resets the tallies), mcpc_run
- * brackets with HIP events on its stream
- *   - every step-kernel launch of the plain schedule and of the round schedule (a launch of the round schedule advances only the
- *     workgroups it holds: it counts as steps x workgroups / all workgroups whole-shard steps), and
- *   - every whole CYCLE of the mixed 32-/16-chain schedule (tuning rr=0: inference stretches of a shard that leaves CUs idle; a
- *     segment of a cycle is ONE launch of mcpc_steps_ws2_mixed_kernel, a cycle is up to a few hundred of them back to back).
- * The two getters synchronise on the recorded events and return the summed time, the number of brackets and the
- * whole-shard steps they cover (rounded down), accumulated over all runs since profiling was enabled (at most 65 536 brackets per set). */
+ * brackets every step-kernel launch with HIP events on its stream (a launch of the round schedule advances only the workgroups it
+ * holds: it counts as steps x workgroups / all workgroups whole-shard steps).  The getter synchronises on the recorded events and
+ * returns the summed time, the number of launches and the whole-shard steps they cover (rounded), accumulated over all runs since
+ * profiling was enabled (at most 65 536 launches). */
 int mcpc_set_profiling(mcpc_engine* e, int enable);
 int mcpc_last_step_kernel_ms(mcpc_engine* e, float* ms, int32_t* n_launches, int64_t* n_steps);
-int mcpc_last_mixed_cycles_ms(mcpc_engine* e, float* ms, int32_t* n_cycles, int64_t* n_steps);
+/* The shader clock the chip held DURING the step-kernel launches bracketed since profiling was enabled: one wave of workgroup 0 of
+ * every launch of the in-place kernel reads s_memtime (shader cycles) and s_memrealtime (100 MHz) at both ends of the launch; the
+ * quotient of the sums is the clock under that load (MI355X lowers it under MFMA-dense work: 1.8-2.0 GHz against the 2.4 GHz peak).
+ * 0 when no such launch has run.  Waits for the device. */
+int mcpc_last_shader_clock_ghz(mcpc_engine* e, float* ghz);
+
+/* Diagnostic (tests only; nothing of the product path calls it): fill the 160 KiB of LDS of EVERY compute unit of `device` with the
+ * 32-bit pattern `word` (e.g. 0x7fa00000, a signalling NaN), then return once the fill has completed.  LDS is not cleared between
+ * kernels on gfx950, so the next launch on each CU finds the pattern in whatever LDS it does not write itself.  Used by
+ * tests/test_gpu_lds_poison.py to show that no result depends on LDS content the step kernels did not produce. */
+int mcpc_debug_poison_lds(int device, uint32_t word, void* stream);
 
 #ifdef __cplusplus
 }

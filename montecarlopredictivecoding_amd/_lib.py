@@ -10,7 +10,7 @@ import os
 MAX_LATENT = 6
 COMM_ID_BYTES = 128
 ENERGY_COLS = MAX_LATENT + 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT_IDENTITY, ACT_RELU, ACT_TANH = 0, 1, 2
 LOSS_NONE, LOSS_GAUSSIAN, LOSS_BERNOULLI = 0, 1, 2
@@ -101,8 +101,8 @@ SYMBOLS = {
     "mcpc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "mcpc_last_step_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                            C.POINTER(C.c_int64)]),
-    "mcpc_last_mixed_cycles_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32),
-                                            C.POINTER(C.c_int64)]),
+    "mcpc_last_shader_clock_ghz": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "mcpc_debug_poison_lds": (C.c_int, [C.c_int, C.c_uint32, C.c_void_p]),
 }
 
 _lib = None

@@ -61,39 +61,24 @@ struct Lin {
 constexpr int kMaxRingParts = 8;
 struct Knobs {
     int ws = -1;              // -1: automatic; 0: barrier kernel; 2: in-place wave-specialised kernel
-    int ct = 0;               // 0: automatic; 16 / 32 chains per workgroup
-    int nw = 0;               // 0: automatic; 4 / 8 waves per workgroup of the barrier kernel
-    int no_mix = 0;           // 1: never use the mixed 32-/16-chain schedule
     int no_overlap = 0;       // 1: Hebbian flushes run serially on the caller's stream (one ring segment = the whole ring)
     int slot_cap = 384;       // spill-ring slots at most (3 parts of 128 steps)
     int spill_gb = 0;         // > 0: spill budget in GiB (overrides mcpc_net_desc::spill_budget_bytes)
-    int mix_slack = 0;        // CUs the mixed schedule leaves free
+    int cu_slack = 0;         // CUs the round schedule leaves free (launches of at most n_cu - cu_slack workgroups)
     int flush_streams = 2;    // low-priority streams the GEMMs of an overlapped flush are spread over (1 or 2)
     int flush_tail = 0;       // > 0: the last accumulating segment of a stretch is cut to this many steps (its flush is the one nothing overlaps)
     int ring_parts = 3;       // parts of the spill ring: one is filled by the step kernel, one is being flushed, one is slack -- with two
                               // halves the step kernel waited at every boundary for a flush that takes as long as its own segment
                               // (96.8 -> 95.2 us per step of the learning call; parts of 64 steps beat 48, 96 and 128)
-    int mix_pmax = 80;        // longest segment of the mixed schedule, in steps of a paired unit (10 / 20 / 40 / 80: 76.4 / 75.4 / 75.2 / 75.0 us
-                              // per step inside the cycles: every segment boundary joins two streams)
-#ifndef MCPC_GEMM_BF16X6
-    int mix_ratio = 17;       // steps of a split unit per 10 steps of a paired one (the rate ratio of the two workgroup forms)
-#else
-    int mix_ratio = 19;       // ... with the bf16x6 GEMM core the 16-chain form gained more than the 32-chain one: 1.7 / 1.8 / 1.9 / 2.0 / 2.1
-                              // give 67.5 / 66.7 / 65.9 / 66.9 / 68.0 us per step of an inference call at cfg-M
-#endif
     int dw_ksplit = 0;        // > 0: K-splits per workgroup tile of the Hebbian GEMM (0: one wave of workgroups over the chip)
-#ifndef MCPC_GEMM_BF16X6
-    int ws_prio = 1;          // 1: epilogue waves at raised priority, 2: GEMM waves, 0: neither
-#else
-    int ws_prio = 0;          // ... the bf16x6 GEMM waves need most of the issue port themselves (48 MFMAs + ~110 VALU per 768 MFMA cycles): with
-                              // the epilogue waves at raised priority the plain schedule takes 94.2 us per step at cfg-M, without 87.7
-#endif
+    int ws_prio = 0;          // 1: epilogue waves at raised priority, 2: GEMM waves, 0: neither (the bf16x6 GEMM waves need most of the issue port
+                              // themselves: with the epilogue waves at raised priority a step of cfg-M took 94.2 us against 87.7, round 3)
     int stagger = 0;          // barrier kernel: start cycles of the second workgroup of a CU
     int no_lean = 0;          // 1: the in-place kernel's E waves use the generic epilogues everywhere (A/B, parity tests)
     int no_ybits = 0;         // 1: 0/1 targets are read as fp32 like any other target (A/B, parity tests)
     int overlay16 = 0;        // 1: 16-chain plans share the LDS of the ring and the E_l like 32-chain plans do (A/B, parity tests)
     int no_xl = 0;            // 1: 16-chain plans keep the state and the per-step constants in global memory even when the LDS has the room (A/B, parity tests)
-    int rr = 1;               // 0: shards of more 16-chain units than CUs run as 32-chain workgroups (+ the mixed schedule) instead of the round schedule (setup_rounds)
+    int rr = 1;               // 0: shards of more 16-chain units than CUs run as one launch in hardware rounds instead of the round schedule (setup_rounds)
     int rr_qmax = 100;        // round schedule: most steps per launch in stretches without Hebbian accumulation
     int heb_fp32 = 0;         // 1: the tiled Hebbian GEMM runs on the fp32 MFMA (mcpc_heb_kernel) instead of the bf16x6 form (A/B, parity tests)
 };
@@ -114,8 +99,8 @@ int parse_tuning(const char* str, Knobs& k) {
         const std::string key = item.substr(0, eq);
         const int val = eq == std::string::npos ? 1 : atoi(item.c_str() + eq + 1);
         struct { const char* name; int* dst; } table[] = {
-            {"ws", &k.ws}, {"ct", &k.ct}, {"nw", &k.nw}, {"no_mix", &k.no_mix}, {"no_overlap", &k.no_overlap},
-            {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"mix_slack", &k.mix_slack}, {"mix_ratio", &k.mix_ratio}, {"mix_pmax", &k.mix_pmax}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
+            {"ws", &k.ws}, {"no_overlap", &k.no_overlap},
+            {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"cu_slack", &k.cu_slack}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
             {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}, {"heb_fp32", &k.heb_fp32}, {"rr", &k.rr}, {"rr_qmax", &k.rr_qmax}, {"no_xl", &k.no_xl}};
         bool found = false;
         for (auto& t : table)
@@ -123,12 +108,9 @@ int parse_tuning(const char* str, Knobs& k) {
         if (!found) return fail(MCPC_EINVAL, "unknown tuning key '%s' in mcpc_net_desc::tuning", key.c_str());
     }
     if (k.ws != -1 && k.ws != 0 && k.ws != 2) return fail(MCPC_EINVAL, "tuning ws=%d: 0 (barrier kernel) or 2 (in-place kernel)", k.ws);
-    if (k.ct != 0 && k.ct != 16 && k.ct != 32) return fail(MCPC_EINVAL, "tuning ct=%d: 16 or 32", k.ct);
-    if (k.nw != 0 && k.nw != 4 && k.nw != 8) return fail(MCPC_EINVAL, "tuning nw=%d: 4 or 8", k.nw);
     if (k.slot_cap < 2) k.slot_cap = 2;
-    if (k.mix_slack < 0) k.mix_slack = 0;
+    if (k.cu_slack < 0) k.cu_slack = 0;
     if (k.ring_parts < 2 || k.ring_parts > kMaxRingParts) return fail(MCPC_EINVAL, "tuning ring_parts=%d: 2..%d", k.ring_parts, kMaxRingParts);
-    if (k.mix_ratio < 10 || k.mix_ratio > 30) return fail(MCPC_EINVAL, "tuning mix_ratio=%d: 10..30 (tenths)", k.mix_ratio);
     return 0;
 }
 
@@ -142,12 +124,12 @@ struct mcpc_engine {
     int L = 0, Bpad = 0, nwg = 0, has_head = 0;
     int nwg_live = 0;               // 16-chain in-place plans: workgroups that hold at least one chain of the batch (Bpad is a multiple of 32, so
                                     // the last 16-chain unit may be all padding: it is never launched -- its spill rows and energy slots stay zero)
-    int ct = kCT;                   // chains per workgroup: 16 (two workgroups per CU) or 32
-    int nw = kWaves;                // waves per workgroup: 4, or 8 with 32 chains (two waves per SIMD, one workgroup per CU)
-    int ws = 0;                     // 1: wave-specialised kernel with staging slots; 2: in-place variant (4 GEMM + 4 epilogue waves, 32 chains)
+    static constexpr int ct = 16;   // chains per workgroup: one MFMA column tile (the 32-chain forms of rounds 1-3 left the tree in round 4)
+    int nw = kWaves;                // waves per workgroup: 4 (barrier kernel) or 8 (in-place kernel: 4 GEMM + 4 epilogue waves)
+    int ws = 0;                     // 0: barrier kernel (the fallback, two workgroups per CU); 2: in-place wave-specialised kernel
     int ws2_chunk = 0, ws2_ring = 0; // in-place variant: read-out tiles per chunk, chunks in the LDS ring
-    bool ws2_overlay = true;        // the ring of read-out error chunks shares LDS with E_1 .. E_{L-1} (32-chain plans); 16-chain plans that fit
-                                    // keep them apart, which frees the order of the forward entries (build_phases_ws2)
+    bool ws2_overlay = true;        // the ring of read-out error chunks shares LDS with E_1 .. E_{L-1}; plans that fit keep them apart,
+                                    // which frees the order of the forward entries (build_phases_ws2)
     int lds_ws_sync = 0;
     int npad[kMaxLatent]{};
     int out_pad = 0;
@@ -198,25 +180,19 @@ struct mcpc_engine {
     KPhase* phases = nullptr;
     int n_phases = 0;
     int* err = nullptr;             // device error word written by the kernels
+    unsigned long long* clk = nullptr;   // profiling: {shader cycles, 100 MHz ticks} of one wave per launch (KParams::clk)
     float* dummy = nullptr;         // 4 KiB of zeros (KParams::dummy)
-    // Mixed schedule of the in-place kernel (inference stretches of a shard that leaves CUs idle): most pairs of chain tiles
-    // run as 32-chain workgroups, `mix_ns` pairs per segment are split into two 16-chain workgroups on the spare CUs; the
-    // split set rotates, and after `mix_lc` segments every pair has done the same number of steps.
-    bool mix = false;
-    int mix_ns = 0, mix_np = 0, mix_lc = 0, mix_a = 0;    // pairs split / paired per segment, segments per cycle, splits per pair per cycle
-    int* mix_tab = nullptr;          // device: per segment [np pair ids][np rel][2 ns tile ids][2 ns rel]
     // Round schedule (setup_rounds): a shard of more 16-chain units than CUs as `rr_k` launches per cycle, each unit in `rr_m` of them
     bool rr = false;
     int rr_k = 0, rr_m = 0;
     std::string rr_name;                 // mcpc_step_kernel_name of an engine on the round schedule
     std::vector<int> rr_count, rr_off;   // per launch of a cycle: workgroups, offset of its [ids][rel] rows in rr_tab
     int* rr_tab = nullptr;
-    struct Alt { int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_ws_sync = 0, lds_bytes = 0, n_phases = 0; KPhase* phases = nullptr; } alt16;
     // profiling
     bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events, events_mix;   // plain-schedule launches / whole mixed cycles
-    size_t events_used = 0, events_mix_used = 0;
-    double prof_steps = 0, prof_steps_mix = 0;      // whole-shard steps covered by the bracketed launches / cycles
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;   // HIP events around every launch of the step kernel
+    size_t events_used = 0;
+    double prof_steps = 0;          // whole-shard steps covered by the bracketed launches
 #ifdef MCPC_STAMPS
     unsigned long long* dbg = nullptr;
 #endif
@@ -260,18 +236,16 @@ int free_all(mcpc_engine* e) {
     if (e->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(e->comm); e->comm = nullptr; e->comm_ranks = 0; }
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int l = 0; l < kMaxLatent; ++l) { F(e->x[l]); F(e->m[l]); F(e->v[l]); F(e->spill_a[l]); F(e->spill_e[l]); }
-    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ytile); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err); F(e->dummy);
+    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ytile); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err); F(e->clk); F(e->dummy);
     for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    for (auto& ev : e->events_mix) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    e->events_mix.clear();
     for (int h = 0; h < kMaxRingParts; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
     if (e->aux) { (void)hipStreamDestroy(e->aux); e->aux = nullptr; }
     if (e->aux3) { (void)hipStreamDestroy(e->aux3); e->aux3 = nullptr; }
     if (e->spacer) { (void)hipStreamDestroy(e->spacer); e->spacer = nullptr; }
     if (e->ev_fork) { (void)hipEventDestroy(e->ev_fork); e->ev_fork = nullptr; }
     if (e->ev_join) { (void)hipEventDestroy(e->ev_join); e->ev_join = nullptr; }
-    F(e->mix_tab); F(e->alt16.phases);
+    F(e->rr_tab);
     for (auto& q : e->retired) { (void)hipFree(q.p); if (q.ev) (void)hipEventDestroy(q.ev); }
     e->retired.clear();
     for (int i = 0; i < 2; ++i) {
@@ -362,10 +336,12 @@ int plan_lds_ws2(mcpc_engine* e, bool allow_xl = true) {
     if (e->has_head) {
         // fewest chunks of at most 16 tiles whose ring of two still fits; chunks equalised; ring of three if that fits too
         const int ht = std::max(e->out_pad / 16, 1);
-        const int span = kWs2Pairs * (CT == 16 ? ws2_nt<1>() : ws2_nt<2>());     // tiles a table entry hands out
+        const int span = kWs2Pairs * ws2_nt<1>();     // tiles a table entry hands out
         auto ring_of = [&](int hc, int nb) { return nb * CT * (hc * 16 + kLdPad); };
-        auto fits = [&](int hc, int nb) { return (off + std::max(ring_of(hc, nb), e_sum)) * (int)sizeof(float) <= 160 * 1024; };
-        auto fits_apart = [&](int hc, int nb) { return (off + ring_of(hc, nb) + e_sum) * (int)sizeof(float) <= 160 * 1024; };
+        // (+16: the slack added behind the operand regions below -- a plan within 64 B of the limit takes a smaller chunk or ring here
+        // instead of failing the final size check)
+        auto fits = [&](int hc, int nb) { return (off + 16 + std::max(ring_of(hc, nb), e_sum)) * (int)sizeof(float) <= 160 * 1024; };
+        auto fits_apart = [&](int hc, int nb) { return (off + 16 + ring_of(hc, nb) + e_sum) * (int)sizeof(float) <= 160 * 1024; };
         // (chunks are whole k-blocks of the back-projection GEMM: tq tiles)
         const int tq = kKB / 16, hb = (ht + tq - 1) / tq;
         int hcb_fit = 0;
@@ -376,20 +352,17 @@ int plan_lds_ws2(mcpc_engine* e, bool allow_xl = true) {
         const int hc = tq * ((hb + nch - 1) / nch);          // equalised: the widest chunk of the split (tiles)
         const int nb = (nch >= 3 && fits(hc, 3)) ? 3 : 2;
         e->ws2_chunk = hc; e->ws2_ring = nb; ring_floats = ring_of(hc, nb);
-        if (CT == 16 && L >= 2 && fits_apart(hc, nb) && !e->knobs.overlay16) { e->ws2_overlay = false; e->lds_eo = off + e_sum; }
+        if (L >= 2 && fits_apart(hc, nb) && !e->knobs.overlay16) { e->ws2_overlay = false; e->lds_eo = off + e_sum; }
     }
     off += e->ws2_overlay ? std::max(ring_floats, e_sum) : ring_floats + e_sum;
-#ifdef MCPC_GEMM_BF16X6
     // The bf16x6 core reads the LDS operand in whole 32-deep k-blocks: up to 12 floats beyond a row whose width is not a multiple of
-    // 32 (zero weights there, so the values only have to be FINITE).  Inside the plan that is the next row or the next region, which
-    // the kernel zero-fills at launch; the last row of the last operand region (E_{L-1} when it ends the shared region) would reach
-    // past the plan into LDS another kernel left behind: 16 floats of slack keep it inside.
+    // 32.  Those lanes are zeroed in registers (mcpc_gemm6.h: tail_keep), so what lies there is irrelevant; 16 floats of slack keep
+    // even the read itself inside the workgroup's allocation.
     off += 16;
-#endif
     // with room to spare (16-chain plans: 45 KB at cfg-M) the lean epilogues keep what they read every step in LDS: the state rows
     // X_l (layout of FX_l), the bias rows, the mu_1 rows (layout of FX_0), the read-out bias and the bit-packed target rows
     e->xl = false;
-    if (CT == 16 && allow_xl && !e->knobs.no_xl) {
+    if (allow_xl && !e->knobs.no_xl) {
         int extra = 0;
         for (int l = 0; l < L; ++l) extra += CT * (e->npad[l] + kLdPad) + (l >= 1 ? e->npad[l] : CT * (e->npad[0] + kLdPad));
         const int ywords = (e->out_pad + 31) / 32;
@@ -431,7 +404,7 @@ int plan_lds_ws2(mcpc_engine* e, bool allow_xl = true) {
 // the previous step's readers of E_l: dep_g <- last back-projection GEMM, dep_se <- last BWD entry.
 int build_phases_ws2(mcpc_engine* e) {
     const int L = e->L;
-    const int span = kWs2Pairs * (e->ct == 16 ? ws2_nt<1>() : ws2_nt<2>());     // tiles per table entry: 16 (32-chain workgroups) or 32 (16-chain)
+    const int span = kWs2Pairs * ws2_nt<1>();     // tiles per table entry
     auto tiles = [&](int l) { return e->npad[l] / 16; };
     auto blank = [&]() { KPhase k{}; k.dep_e = -1; k.dep_g = -1; k.dep_se = -1; return k; };
     enum { REF_LAST_BWD = -1000, REF_LAST_FWD = -2000, REF_LAST_HB = -3000, REF_LAST_BWD_GEMM = -4000, REF_LAST_BWD_ANY = -5000 };   // symbolic deps
@@ -442,7 +415,7 @@ int build_phases_ws2(mcpc_engine* e) {
             if (l == 0) {
                 k.flags = PHF_MU1 | PHF_WS_EPI;
             } else {
-                k.A = e->lin[l].Wf; k.nkb = kblocks(16 * tiles(l - 1)); k.a_tile_stride = k.nkb * kFragBlock;
+                k.A = e->lin[l].Wf; k.kw = 16 * tiles(l - 1); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
                 k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
                 k.out_lds = e->lds_e[l]; k.out_ld = e->npad[l] + kLdPad;
                 k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_BWD - (l - 1);
@@ -485,7 +458,7 @@ int build_phases_ws2(mcpc_engine* e) {
         auto add_f = [&](int c) {
             KPhase f = blank();
             f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c_start[c]; f.ntiles = c_start[c + 1] - c_start[c]; f.rot = c & (kWs2Pairs - 1);
-            f.A = e->lin[L].Wf; f.nkb = kblocks(16 * tiles(L - 1)); f.a_tile_stride = f.nkb * kFragBlock;
+            f.A = e->lin[L].Wf; f.kw = 16 * tiles(L - 1); f.nkb = kblocks(f.kw); f.a_tile_stride = f.nkb * kFragBlock;
             f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad;
             f.out_lds = e->lds_eo + (c % R) * chunk_floats; f.out_ld = hc * 16 + kLdPad;
             f.flags = PHF_WS_GEMM | PHF_WS_EPI; f.dep_e = REF_LAST_BWD - (L - 1);
@@ -497,7 +470,7 @@ int build_phases_ws2(mcpc_engine* e) {
             KPhase b = blank();
             b.type = PH_HEADB; b.layer = L - 1; b.tile0 = 0; b.ntiles = tiles(L - 1);
             b.A = e->lin[L].Wb; b.a_tile_stride = kblocks(e->out_pad) * kFragBlock; b.a_off0 = (c_start[c] / tq) * kFragBlock;
-            b.nkb = (c_start[c + 1] - c_start[c] + tq - 1) / tq;
+            b.kw = 16 * (c_start[c + 1] - c_start[c]); b.nkb = (c_start[c + 1] - c_start[c] + tq - 1) / tq;
             b.b_lds = e->lds_eo + (c % R) * chunk_floats; b.ldb = hc * 16 + kLdPad;
             b.flags = PHF_WS_GEMM; b.dep_e = idx_f[c];
             idx_b[c] = (int)ph.size(); ph.push_back(b);
@@ -526,7 +499,7 @@ int build_phases_ws2(mcpc_engine* e) {
         for (int base = 0; base < tiles(l - 1); base += span) {
             KPhase k = blank();
             k.type = PH_BWD; k.layer = l - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(l - 1) - base);
-            k.A = e->lin[l].Wb; k.nkb = kblocks(16 * tiles(l)); k.a_tile_stride = k.nkb * kFragBlock;
+            k.A = e->lin[l].Wb; k.kw = 16 * tiles(l); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
             k.b_lds = e->lds_e[l]; k.ldb = e->npad[l] + kLdPad; k.sign = -1.0f;
             k.out_lds = e->lds_a[l - 1]; k.out_ld = e->npad[l - 1] + kLdPad;
             k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_FWD - l;
@@ -576,7 +549,7 @@ int build_phases(mcpc_engine* e) {
         for (int base = 0; base < tiles(l); base += span) {
             KPhase k{};
             k.type = PH_FWD; k.layer = l; k.tile0 = base; k.ntiles = std::min(span, tiles(l) - base);
-            k.A = e->lin[l].Wf; k.nkb = kblocks(16 * tiles(l - 1)); k.a_tile_stride = k.nkb * kFragBlock;
+            k.A = e->lin[l].Wf; k.kw = 16 * tiles(l - 1); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
             k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
             k.flags = base + span >= tiles(l) ? PHF_SYNC : 0;
             ph.push_back(k);
@@ -587,14 +560,14 @@ int build_phases(mcpc_engine* e) {
             const int ntc = std::min(kChunkTiles, ht - c0);
             KPhase f{};
             f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c0; f.ntiles = ntc;
-            f.A = e->lin[L].Wf; f.nkb = kblocks(16 * tiles(L - 1)); f.a_tile_stride = f.nkb * kFragBlock;
+            f.A = e->lin[L].Wf; f.kw = 16 * tiles(L - 1); f.nkb = kblocks(f.kw); f.a_tile_stride = f.nkb * kFragBlock;
             f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad; f.flags = PHF_SYNC;
             f.out_lds = e->lds_eo; f.out_ld = kChunkTiles * 16 + kLdPad; f.dep_e = f.dep_g = -1;
             ph.push_back(f);
             KPhase b{};
             b.type = PH_HEADB; b.layer = L - 1; b.tile0 = 0; b.ntiles = tiles(L - 1);
             b.A = e->lin[L].Wb; b.a_tile_stride = kblocks(e->out_pad) * kFragBlock; b.a_off0 = (c0 * 16 / kKB) * kFragBlock;
-            b.nkb = (ntc * 16 + kKB - 1) / kKB;
+            b.kw = ntc * 16; b.nkb = (ntc * 16 + kKB - 1) / kKB;
             b.b_lds = e->lds_eo; b.ldb = kChunkTiles * 16 + kLdPad;
             b.flags = PHF_ACC_FROM_B | PHF_ACC_TO_B | PHF_SYNC;
             ph.push_back(b);
@@ -613,7 +586,7 @@ int build_phases(mcpc_engine* e) {
         for (int base = 0; base < tiles(l - 1); base += span) {
             KPhase k{};
             k.type = PH_BWD; k.layer = l - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(l - 1) - base);
-            k.A = e->lin[l].Wb; k.nkb = kblocks(16 * tiles(l)); k.a_tile_stride = k.nkb * kFragBlock;
+            k.A = e->lin[l].Wb; k.kw = 16 * tiles(l); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
             k.b_lds = e->lds_e[l]; k.ldb = e->npad[l] + kLdPad; k.sign = -1.0f;
             ph.push_back(k);
         }
@@ -629,86 +602,6 @@ int build_phases(mcpc_engine* e) {
 
 namespace {
 
-// Mixed schedule (see mcpc_engine::mix): a second LDS plan and phase table for 16-chain workgroups and the rotation tables.
-// A shard of `nwg` 32-chain workgroups leaves n_cu - nwg CUs idle; per segment that many pairs of chain
-// tiles are split into two 16-chain workgroups each, which advance ~1.7x as many steps in the same time.  Rotating the
-// split set cyclically over the pairs, every pair has been split equally often after nwg / gcd(nwg, ns) segments.
-// Per-chain results do not depend on the form a step is computed in (the two kernels run the same arithmetic in the same
-// order per chain), so trajectories are bitwise those of the plain schedule; only the grouping of the energy partials moves.
-int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
-    const int npairs = e->nwg;
-    // MCPC_MIX_SLACK CUs are left free (default 0): with every CU taken, a workgroup that finds its CU still draining has
-    // to wait for another workgroup of its XCD to finish, which doubles that segment
-    const int slack = e->knobs.mix_slack;
-    int ns = std::min(n_cu - slack - npairs, npairs);           // npairs + ns workgroups (np pairs + 2 ns singles) <= CUs
-    // The rotation repeats after npairs / gcd(npairs, ns) segments.  When that is long (> 64 segments), a few splits fewer are a
-    // good price for a cycle that fits into shorter stretches (7500 chains: 21 of 235 pairs rotate in 235 segments, 20 in 47).
-    {
-        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
-        int best = ns;
-        if (npairs / gcd(npairs, ns) > 64)
-            for (int c = ns - 1; c >= 1 && c >= ns - ns / 8; --c)
-                if (gcd(npairs, c) > gcd(npairs, best)) best = c;
-        ns = best;
-    }
-    // (One launch per segment: its workgroups go round-robin over the 8 XCDs as one sequence, at most one per CU.  With the
-    // two halves as two launches each started at XCD 0 and an XCD could receive one workgroup more than it has CUs -- 7500
-    // chains: 27 + 6 on XCD 0 -- which then waited for a whole segment.)
-    // A split pair advances 34 steps where a paired one advances 20: the schedule does 1 + 0.7 ns / npairs times the plain
-    // schedule's work per unit of time, minus what its short launches cost.  Below 4 % expected it does not pay (8000 chains:
-    // 4 of 250 pairs split, +1.1 % expected, -5 % measured).
-    if (ns < 1 || (0.1 * e->knobs.mix_ratio - 1.0) * ns < 0.04 * npairs) return 0;
-    // second plan: swap the primary one out, plan for 16 chains, swap back
-    mcpc_engine::Alt keep;
-    std::copy(e->lds_a, e->lds_a + kMaxLatent, keep.lds_a); std::copy(e->lds_e, e->lds_e + kMaxLatent, keep.lds_e);
-    keep.lds_eo = e->lds_eo; keep.lds_red = e->lds_red; keep.lds_ws_sync = e->lds_ws_sync; keep.lds_bytes = e->lds_bytes;
-    keep.n_phases = e->n_phases; keep.phases = e->phases;
-    const int k_chunk = e->ws2_chunk, k_ring = e->ws2_ring;
-    const bool k_overlay = e->ws2_overlay;
-    e->ct = 16; e->phases = nullptr;
-    int rc = plan_lds_ws2(e, false);
-    if (!rc) rc = build_phases_ws2(e);
-    mcpc_engine::Alt& a = e->alt16;
-    if (!rc) {
-        std::copy(e->lds_a, e->lds_a + kMaxLatent, a.lds_a); std::copy(e->lds_e, e->lds_e + kMaxLatent, a.lds_e);
-        a.lds_eo = e->lds_eo; a.lds_red = e->lds_red; a.lds_ws_sync = e->lds_ws_sync; a.lds_bytes = e->lds_bytes;
-        a.n_phases = e->n_phases; a.phases = e->phases;
-    }
-    e->ct = 32;
-    std::copy(keep.lds_a, keep.lds_a + kMaxLatent, e->lds_a); std::copy(keep.lds_e, keep.lds_e + kMaxLatent, e->lds_e);
-    e->lds_eo = keep.lds_eo; e->lds_red = keep.lds_red; e->lds_ws_sync = keep.lds_ws_sync; e->lds_bytes = keep.lds_bytes;
-    e->n_phases = keep.n_phases; e->phases = keep.phases;
-    e->ws2_chunk = k_chunk; e->ws2_ring = k_ring; e->ws2_overlay = k_overlay;
-    if (rc) { g_err.clear(); return 0; }                     // no 16-chain plan: plain schedule only
-    if (hipFuncSetAttribute((const void*)mcpc_steps_ws2_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(e->lds_bytes, a.lds_bytes)) != hipSuccess)
-        return fail(MCPC_EHIP, "hipFuncSetAttribute failed for the mixed schedule");
-    // rotation tables
-    int g = npairs, h = ns;
-    while (h) { const int t = g % h; g = h; h = t; }
-    const int lc = npairs / g, np = npairs - ns;
-    std::vector<int> cnt_a(npairs, 0), cnt_b(npairs, 0), tab((size_t)lc * (2 * np + 4 * ns));
-    for (int seg = 0; seg < lc; ++seg) {
-        int* row = tab.data() + (size_t)seg * (2 * np + 4 * ns);
-        int* p_id = row, *p_rel = row + np, *s_id = row + 2 * np, *s_rel = row + 2 * np + 2 * ns;
-        std::vector<char> split(npairs, 0);
-        for (int i = 0; i < ns; ++i) split[((size_t)seg * ns + i) % npairs] = 1;
-        int ip = 0, is = 0;
-        for (int j = 0; j < npairs; ++j) {
-            const int rel = cnt_a[j] | (cnt_b[j] << 16);
-            if (split[j]) { s_id[is] = 2 * j; s_rel[is++] = rel; s_id[is] = 2 * j + 1; s_rel[is++] = rel; ++cnt_a[j]; }
-            else { p_id[ip] = j; p_rel[ip++] = rel; ++cnt_b[j]; }
-        }
-    }
-    for (int j = 1; j < npairs; ++j)
-        if (cnt_a[j] != cnt_a[0] || cnt_b[j] != cnt_b[0]) return fail(MCPC_EINVAL, "mixed schedule: rotation is not balanced");
-    if ((rc = dmalloc(e->mix_tab, tab.size()))) return rc;
-    if (hipMemcpy(e->mix_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
-        return fail(MCPC_EHIP, "hipMemcpy of the mixed-schedule tables failed");
-    e->mix_ns = ns; e->mix_np = np; e->mix_lc = lc; e->mix_a = cnt_a[0];
-    e->mix = true;
-    return 0;
-}
-
 // Round schedule of the in-place kernel for a shard of U 16-chain units on C < U CUs.  One unit per CU is what the kernel is built
 // for (a step is a chain of dependent hand-overs inside ONE workgroup: a second workgroup per CU does not fit the LDS, a launch of
 // U > C workgroups runs as ceil(U / C) hardware rounds, the last one mostly empty).  Instead the units are dealt into k groups and a
@@ -719,7 +612,7 @@ int setup_mixed_schedule(mcpc_engine* e, int n_cu) {
 // of any other schedule, bitwise; in a Hebbian segment (m q <= slots of a ring part) every unit fills its own rows of all m q slots
 // before the flush, which therefore sees what the plain schedule would have written.
 int setup_rounds(mcpc_engine* e, int n_cu) {
-    const int U = e->nwg_live, C = n_cu - e->knobs.mix_slack;
+    const int U = e->nwg_live, C = n_cu - e->knobs.cu_slack;
     if (U <= C || C < 1) return 0;
     auto gsize = [&](int k, int g) { return (int)((int64_t)(g + 1) * U / k - (int64_t)g * U / k); };
     // best m for every k <= 16, then the SMALLEST k within 3 % of the best k / m: short cycles mean long launches (a Hebbian segment is
@@ -796,59 +689,33 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     { const int rc = parse_tuning(d->tuning, e->knobs); if (rc) { delete e; return rc; } }
     e->d.tuning = nullptr;                   // the caller's string is not kept
     const Knobs& kn = e->knobs;
-    // Default schedule: the in-place wave-specialised kernel (4 GEMM + 4 epilogue waves), with 16 chains per workgroup while
-    // that still gives every workgroup a CU of its own (B <= 16 x CUs: 55 us per step at B = 4096 on cfg-M's net, against 72
-    // for the barrier kernel and 93 for 32-chain workgroups) and 32 chains per workgroup beyond (93 us at B = 6000, against
-    // 109 for two 16-chain workgroups per CU).  The barrier kernel (16 chains per workgroup: two workgroups share a CU, one's
-    // MFMA phases cover the other's epilogues) remains the fallback when the in-place LDS plan does not fit.  Tuning keys
-    // force a variant for A/B runs and for the tests that pin every variant against the same fixtures: ws=0 the barrier
-    // kernel (ct / nw choose its forms), ws=2 [ct=16|32] the in-place kernel.
-    e->ct = 16; e->nw = 4;
-    if (kn.ct) e->ct = kn.ct;
-    if (kn.nw == 4 || (kn.nw == 8 && e->ct == 32)) e->nw = kn.nw;
+    // Default schedule: the in-place wave-specialised kernel (4 GEMM + 4 epilogue waves, 16 chains, one workgroup per CU; shards of
+    // more units than CUs on the round schedule, setup_rounds).  The barrier kernel (16 chains, 4 waves, two workgroups per CU, generic
+    // epilogues) is the fallback when the in-place LDS plan does not fit, and the independent form the parity checks replay the default
+    // against (bench.py self_check, tests): tuning ws=0 forces it, ws=2 insists on the in-place kernel.
     int n_cu = 256;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, d->device) != hipSuccess || n_cu <= 0) n_cu = 256;
-    int want_ws = (!kn.ct && !kn.nw) ? 2 : 0;
-    bool ct16 = (d->batch + 15) / 16 <= n_cu;
-    if (!ct16) {
-        // Shards of more than one round of workgroups: a round of 16-chain workgroups takes 1 / 1.65 of a round of 32-chain ones
-        // (54 against 88.5 us per step at cfg-M with every CU taken), so the form with the cheaper sum of rounds wins -- 12 000
-        // chains: 3 x 54 against 2 x 88.5 us.  (One round of 32-chain workgroups with CUs to spare is the mixed schedule's case.)
-        const int r32 = ((d->batch + 31) / 32 + n_cu - 1) / n_cu, r16 = ((d->batch + 15) / 16 + n_cu - 1) / n_cu;
-        if (r32 >= 2 && r16 < 1.65 * r32 - 0.05) ct16 = true;
-    }
-    if (kn.rr && want_ws) ct16 = true;                   // the round schedule: 16-chain units whatever the shard size
-    if (kn.ws != -1) {
-        want_ws = kn.ws;
-        ct16 = kn.ct == 16;
-    }
-    if (want_ws) { e->ws = 2; e->ct = ct16 ? 16 : 32; e->nw = 2 * kWs2Pairs; }
+    e->ws = kn.ws == 0 ? 0 : 2;
+    e->nw = e->ws == 2 ? 2 * kWs2Pairs : kWaves;
     e->nwg = e->Bpad / e->ct;
     for (int l = 0; l < e->L; ++l) e->npad[l] = pad16(d->sizes[l]);
     e->out_pad = pad16(d->n_out);
     // The back-projection of the read-out error is accumulated in registers over the whole read-out: 16 tiles per workgroup
-    // (a last latent layer of up to 256 units) for 32-chain workgroups and for the barrier kernel, 32 tiles (512 units) for
-    // the 16-chain in-place kernel, which a wider last layer therefore selects whatever the shard size.
+    // (a last latent layer of up to 256 units) for the barrier kernel, 32 tiles (512 units) for the in-place kernel.
     const int last_tiles = e->has_head ? e->npad[e->L - 1] / 16 : 0;
-    const int cap32 = kWs2Pairs * ws2_nt<2>(), cap16 = kWs2Pairs * ws2_nt<1>();
-    if (last_tiles > std::max(cap16, kNT * kWaves) || (last_tiles > kNT * kWaves && e->ws != 2)) {
+    const int cap_ws2 = kWs2Pairs * ws2_nt<1>(), cap_bar = kNT * kWaves;
+    if (last_tiles > std::max(cap_ws2, cap_bar) || (last_tiles > cap_bar && e->ws != 2)) {
         delete e;
-        return fail(MCPC_ENOMEM, "last latent layer wider than %d units is not supported by the fused read-out (its back-projection is held in register tiles)", std::max(cap16, kNT * kWaves) * 16);
+        return fail(MCPC_ENOMEM, "last latent layer wider than %d units is not supported by the fused read-out (its back-projection is held in register tiles)", (e->ws == 2 ? std::max(cap_ws2, cap_bar) : cap_bar) * 16);
     }
-    if (e->ws == 2 && e->ct == 32 && last_tiles > cap32) { e->ct = 16; e->nwg = e->Bpad / e->ct; }
     int rc = e->ws == 2 ? plan_lds_ws2(e) : plan_lds(e);
-    if (rc && e->ws == 2 && e->ct == 32) {   // the 32-chain in-place plan does not fit the LDS: the 16-chain one may
+    if (rc && e->ws == 2 && kn.ws == -1 && last_tiles <= cap_bar) {   // no in-place plan fits: the barrier schedule
         g_err.clear();
-        e->ct = 16; e->nwg = e->Bpad / e->ct;
-        rc = plan_lds_ws2(e);
-    }
-    if (rc && e->ws && last_tiles <= kNT * kWaves) {   // no in-place plan fits: classic 16-chain barrier schedule
-        g_err.clear();
-        e->ws = 0; e->ct = 16; e->nw = 4; e->nwg = e->Bpad / e->ct;
+        e->ws = 0; e->nw = kWaves;
         rc = plan_lds(e);
     }
     if (rc) { delete e; return rc; }
-    e->nwg_live = (e->ws == 2 && e->ct == 16) ? (d->batch + 15) / 16 : e->nwg;
+    e->nwg_live = e->ws == 2 ? (d->batch + 15) / 16 : e->nwg;
 
     auto bail = [&](int code) { free_all(e); delete e; return code; };
     for (int l = 0; l < e->L; ++l) {
@@ -910,17 +777,14 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if ((rc = e->ws == 2 ? build_phases_ws2(e) : build_phases(e))) return bail(rc);
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
     if (hipMemset(e->err, 0, sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
+    if ((rc = dmalloc(e->clk, 2))) return bail(rc);
+    if (hipMemset(e->clk, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
     if ((rc = dmalloc(e->dummy, 1024))) return bail(rc);
     if (hipMemset(e->dummy, 0, 4096) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
-    const void* kfn = e->ws == 2 ? (e->ct == 16 ? (const void*)mcpc_steps_ws2_kernel<1> : (const void*)mcpc_steps_ws2_kernel<2>)
-                      : e->ct == 16 ? (const void*)mcpc_steps_kernel<1, 4>
-                      : (e->nw == 8 ? (const void*)mcpc_steps_kernel<2, 8> : (const void*)mcpc_steps_kernel<2, 4>);
+    const void* kfn = e->ws == 2 ? (const void*)mcpc_steps_ws2_kernel<1> : (const void*)mcpc_steps_kernel<1, 4>;
     hipError_t herr = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes);
     if (herr != hipSuccess) return bail(fail(MCPC_EHIP, "hipFuncSetAttribute(%d bytes LDS) failed: %s", e->lds_bytes, hipGetErrorString(herr)));
-    if (e->ws == 2 && e->ct == 32 && e->nwg < n_cu && !kn.no_mix) {
-        if ((rc = setup_mixed_schedule(e, n_cu))) return bail(rc);
-    }
-    if (e->ws == 2 && e->ct == 16 && e->nwg_live > n_cu && kn.rr) {
+    if (e->ws == 2 && e->nwg_live > n_cu && kn.rr) {
         if ((rc = setup_rounds(e, n_cu))) return bail(rc);
     }
     *out = e;
@@ -1157,7 +1021,7 @@ int ensure_spill(mcpc_engine* e) {
     }
     if (e->has_head && !e->spill_eo && (rc = dmalloc(e->spill_eo, (size_t)e->slots * e->Bpad * e->out_pad))) return rc;
     // rows of a 16-chain unit that is all padding (never launched) read as zero in every slot: the Hebbian GEMMs sum over all Bpad rows
-    if (e->nwg_live * e->ct < e->Bpad && e->ws == 2 && e->ct == 16) {
+    if (e->nwg_live * e->ct < e->Bpad && e->ws == 2) {
         const size_t live = (size_t)e->nwg_live * 16, dead = (size_t)e->Bpad - live;
         auto zero_tail = [&](float* base, int npad) {
             return hipMemset2D(base + live * npad, (size_t)e->Bpad * npad * sizeof(float), 0, dead * npad * sizeof(float), (size_t)e->slots) == hipSuccess;
@@ -1427,6 +1291,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         P.lean_ok = e->Bpad < (1 << 24) && (uint64_t)e->Bpad * (uint64_t)widest * 4u < (1ull << 32) && !e->knobs.no_lean;
     }
     P.err = e->err; P.dummy = e->dummy; P.lds_floats = e->lds_bytes / 4;
+    P.clk = e->profiling ? e->clk : nullptr;
     P.xl = e->xl ? 1 : 0;
     {
         // bytes of Hebbian spill per step: beyond 8 MB (a quarter of the eight 4 MB L2s) the stores go out at system scope
@@ -1446,64 +1311,26 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     const bool overlap = e->aux != nullptr;
     int half = 0;                                         // part of the ring the next accumulating segment spills into
     const int n_parts = std::max(1, e->slots / std::max(1, e->half_slots));
-    // mixed schedule for stretches without Hebbian accumulation (fused x updates only: the gradients-only mode hands dF/dx to
-    // the caller after every single step)
-    bool mix_ok = e->mix && r->update_x;
-#ifdef MCPC_STAMPS
-    mix_ok = false;
-#endif
-    // HIP events around the launches of the plain schedule (set 0) and around whole cycles of the mixed schedule (set 1)
-    // (at most kMaxProfBrackets per set since profiling was switched on: a caller that leaves it on forever stops collecting,
-    // it does not accumulate HIP events without bound)
+    // HIP events around every launch of the step kernel (at most kMaxProfBrackets since profiling was switched on: a caller that
+    // leaves it on forever stops collecting, it does not accumulate HIP events without bound)
     constexpr size_t kMaxProfBrackets = 1 << 16;
     bool bracket_open = false;
-    auto prof_begin = [&](bool mixed = false) -> int {
+    auto prof_begin = [&]() -> int {
         bracket_open = false;
         if (!e->profiling) return 0;
-        auto& ev = mixed ? e->events_mix : e->events;
-        size_t& used = mixed ? e->events_mix_used : e->events_used;
-        if (used >= kMaxProfBrackets) return 0;
+        if (e->events_used >= kMaxProfBrackets) return 0;
         bracket_open = true;
-        if (used == ev.size()) {
+        if (e->events_used == e->events.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(MCPC_EHIP, "hipEventCreate failed");
-            ev.emplace_back(a, b);
+            e->events.emplace_back(a, b);
         }
-        return hipEventRecord(ev[used].first, stream) == hipSuccess ? 0 : fail(MCPC_EHIP, "hipEventRecord failed");
+        return hipEventRecord(e->events[e->events_used].first, stream) == hipSuccess ? 0 : fail(MCPC_EHIP, "hipEventRecord failed");
     };
-    auto prof_end = [&](double steps, bool mixed = false) -> int {
+    auto prof_end = [&](double steps) -> int {
         if (!e->profiling || !bracket_open) return 0;
-        auto& ev = mixed ? e->events_mix : e->events;
-        size_t& used = mixed ? e->events_mix_used : e->events_used;
-        if (hipEventRecord(ev[used].second, stream) != hipSuccess) return fail(MCPC_EHIP, "hipEventRecord failed");
-        ++used; (mixed ? e->prof_steps_mix : e->prof_steps) += steps;
-        return 0;
-    };
-    // one cycle of the mixed schedule: mix_lc segments, in each of them the paired units do `mp` steps as 32-chain workgroups
-    // while the split ones do `ms` steps as 16-chain workgroups -- one launch per segment; afterwards every unit is at t0 + cyc
-    auto run_mixed_cycle = [&](int t0, int mp, int ms) -> int {
-        KParams P2 = P, P1 = P;
-        for (int l = 0; l < e->L; ++l) { P1.layer[l].lds_a = e->alt16.lds_a[l]; P1.layer[l].lds_e = e->alt16.lds_e[l]; }
-        P1.head.lds_eo = e->alt16.lds_eo; P1.lds_red = e->alt16.lds_red; P1.lds_ws_sync = e->alt16.lds_ws_sync;
-        P1.phases = e->alt16.phases; P1.n_phases = e->alt16.n_phases; P1.lds_floats = e->alt16.lds_bytes / 4;
-        P2.t0 = P1.t0 = t0; P2.spill_t0 = P1.spill_t0 = t0;
-        P2.xl = P1.xl = 0;
-        // per-step tables start at the cycle's first step; a unit indexes them with its own step minus t0
-        const int s0 = t0 - r->t_begin;
-        P2.adam_coef = P1.adam_coef = r->xopt_kind == MCPC_XOPT_ADAM ? e->adam_coef + 2 * (size_t)s0 : nullptr;
-        if (r->noise_mode == MCPC_NOISE_EXTERNAL)
-            for (int l = 0; l < e->L; ++l) P2.layer[l].ext_noise = P1.layer[l].ext_noise = r->ext_noise[l] + (size_t)s0 * e->d.batch * e->d.sizes[l];
-        P2.n_steps = mp; P1.n_steps = ms;
-        P2.mix_mp = P1.mix_mp = mp; P2.mix_ms = P1.mix_ms = ms;
-        const int np = e->mix_np, ns = e->mix_ns;
-        for (int seg = 0; seg < e->mix_lc; ++seg) {
-            const int* row = e->mix_tab + (size_t)seg * (2 * np + 4 * ns);
-            P2.wg_list = row; P2.wg_rel = row + np;
-            P1.wg_list = row + 2 * np; P1.wg_rel = row + 2 * np + 2 * ns;
-            // (no timing events inside a cycle: mcpc_last_step_kernel_ms covers the launches of the plain schedule only)
-            hipLaunchKernelGGL(mcpc_steps_ws2_mixed_kernel, dim3(np + 2 * ns), dim3(kWs2Threads), std::max(e->lds_bytes, e->alt16.lds_bytes), stream, P2, P1, np);
-        }
-        HIP_TRY(hipGetLastError());
+        if (hipEventRecord(e->events[e->events_used].second, stream) != hipSuccess) return fail(MCPC_EHIP, "hipEventRecord failed");
+        ++e->events_used; e->prof_steps += steps;
         return 0;
     };
     // one cycle of the round schedule (setup_rounds): rr_k launches of q steps, every unit in rr_m of them; afterwards every
@@ -1514,7 +1341,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
 #endif
     auto run_round_cycle = [&](const KParams& base, int t0, int q) -> int {
         KParams Q = base;
-        Q.t0 = t0; Q.spill_t0 = t0; Q.n_steps = q; Q.mix_ms = q; Q.mix_mp = 0;
+        Q.t0 = t0; Q.spill_t0 = t0; Q.n_steps = q; Q.rr_q = q;
         const int s0 = t0 - r->t_begin;
         Q.adam_coef = r->xopt_kind == MCPC_XOPT_ADAM ? e->adam_coef + 2 * (size_t)s0 : nullptr;
         if (r->noise_mode == MCPC_NOISE_EXTERNAL)
@@ -1539,24 +1366,6 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             if (overlap && tail > 0 && rem <= e->half_slots && rem >= 2 * tail && std::min(end, acc_e) == acc_e) n = rem - tail;
         }
         else n = (t < acc_b ? std::min(end, acc_b) : end) - t;
-        if (!in_acc && mix_ok) {
-            // As many whole cycles as fit, longest segments first; what is left runs on the plain schedule below.  A cycle with p
-            // steps per segment for the paired units and s(p) = round(1.7 p) for the split ones (the 1 : 1.7 rate ratio of the two
-            // workgroup forms: 20 / 34, 10 / 17, 3 / 5) advances every unit by a s + (lc - a) p steps; segments shorter than 3
-            // steps do not pay for their launches.
-            for (int p = std::max(3, std::min(e->knobs.mix_pmax, 300)); p >= 3;) {
-                const int sp = (e->knobs.mix_ratio * p + 5) / 10;
-                const int cyc = e->mix_a * sp + (e->mix_lc - e->mix_a) * p;
-                if (cyc > n) { --p; continue; }
-                // (events around whole cycles)
-                { const int rc = prof_begin(true); if (rc) return rc; }
-                const int rc = run_mixed_cycle(t, p, sp);
-                if (rc) return rc;
-                { const int rc2 = prof_end((double)cyc, true); if (rc2) return rc2; }
-                t += cyc; n -= cyc;
-            }
-            if (n == 0) continue;
-        }
         int rr_q = 0;
         if (rr_ok && in_acc) {
             rr_q = n / e->rr_m;                               // a Hebbian segment is one cycle (fewer steps than rr_m left: plain launch)
@@ -1592,11 +1401,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             if (rc) return rc;
         } else {
         { const int rc = prof_begin(); if (rc) return rc; }
-        if (e->ws == 2 && e->ct == 16) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1>), dim3(e->nwg_live), dim3(kWs2Threads), e->lds_bytes, stream, P);
-        else if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<2>), dim3(e->nwg), dim3(kWs2Threads), e->lds_bytes, stream, P);
-        else if (e->ct == 16) hipLaunchKernelGGL((mcpc_steps_kernel<1, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
-        else if (e->nw == 8) hipLaunchKernelGGL((mcpc_steps_kernel<2, 8>), dim3(e->nwg), dim3(512), e->lds_bytes, stream, P);
-        else hipLaunchKernelGGL((mcpc_steps_kernel<2, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
+        if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1>), dim3(e->nwg_live), dim3(kWs2Threads), e->lds_bytes, stream, P);
+        else hipLaunchKernelGGL((mcpc_steps_kernel<1, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
         { const int rc = prof_end((double)n); if (rc) return rc; }
         }
         HIP_TRY(hipGetLastError());
@@ -1801,10 +1607,8 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
 const char* mcpc_step_kernel_name(const mcpc_engine* e) {
     if (!e) return "";
     if (e->rr) return e->rr_name.c_str();
-    if (e->ws == 2 && e->mix) return "mcpc::mcpc_steps_ws2_kernel<2, false> (Hebbian stretches) / mcpc_steps_ws2_mixed_kernel (mixed schedule of inference stretches)";
-    if (e->ws == 2) return e->ct == 16 ? "mcpc::mcpc_steps_ws2_kernel<1, false>" : "mcpc::mcpc_steps_ws2_kernel<2, false>";
-    if (e->ct == 16) return "mcpc::mcpc_steps_kernel<1, 4>";
-    return e->nw == 8 ? "mcpc::mcpc_steps_kernel<2, 8>" : "mcpc::mcpc_steps_kernel<2, 4>";
+    if (e->ws == 2) return "mcpc::mcpc_steps_ws2_kernel<1, false>";
+    return "mcpc::mcpc_steps_kernel<1, 4>";
 }
 
 int mcpc_sync_check(mcpc_engine* e, void* stream_) {
@@ -1820,11 +1624,81 @@ int mcpc_sync_check(mcpc_engine* e, void* stream_) {
     return MCPC_OK;
 }
 
+int mcpc_last_shader_clock_ghz(mcpc_engine* e, float* ghz) {
+    if (!e || !ghz) return fail(MCPC_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(e->d.device));
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, e->clk, sizeof h, hipMemcpyDeviceToHost));              // (waits for the device)
+    *ghz = h[1] ? (float)((double)h[0] / (double)h[1] * 0.1) : 0.f;
+    return MCPC_OK;
+}
+
+// ---- diagnostic: poison the LDS of every CU (include/mcpc.h: mcpc_debug_poison_lds) -------------------------------------------
+}  // extern "C"
+namespace {
+// One workgroup per CU at a time (it takes the whole 160 KiB of LDS): fills it with `word`, then holds its CU for ~20 us so that
+// the dispatcher has to place the other workgroups of the launch on the other CUs.  `seen[xcc * 64 + cu]` counts the visits.
+__global__ __launch_bounds__(256) void mcpc_poison_lds_kernel(uint32_t word, int* seen) {
+    extern __shared__ uint32_t poison_lds[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) poison_lds[i] = word;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        // HW_ID: cu_id bits 11:8, sh_id bit 12, se_id bits 15:13 (gfx9)
+        const int cu = (int)((hw >> 8) & 0xff);
+        atomicAdd(&seen[(xcc & 7) * 256 + cu], 1);
+        const unsigned long long t_end = wall_clock64() + 2000;          // 100 MHz ticks: 20 us
+        while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(32);
+    }
+    __syncthreads();
+    // keep the stores observable: a read the compiler cannot drop
+    if (poison_lds[(threadIdx.x * 97) % (160 * 1024 / 4)] != word) atomicAdd(&seen[8 * 256], 1);
+}
+}  // namespace
+extern "C" {
+
+int mcpc_debug_poison_lds(int device, uint32_t word, void* stream_) {
+    HIP_TRY(hipSetDevice(device));
+    int n_cu = 256;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n_cu <= 0) n_cu = 256;
+    static bool attr_set[16] = {false};
+    if (device >= 0 && device < 16 && !attr_set[device]) {
+        HIP_TRY(hipFuncSetAttribute((const void*)mcpc_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set[device] = true;
+    }
+    int* seen = nullptr;
+    HIP_TRY(hipMalloc((void**)&seen, (8 * 256 + 1) * sizeof(int)));
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = MCPC_OK;
+    // two passes of four workgroups per CU: a CU that was still draining another kernel during the first is caught by the second
+    for (int pass = 0; pass < 2 && rc == MCPC_OK; ++pass) {
+        if (hipMemsetAsync(seen, 0, (8 * 256 + 1) * sizeof(int), stream) != hipSuccess) { rc = fail(MCPC_EHIP, "hipMemsetAsync failed"); break; }
+        hipLaunchKernelGGL(mcpc_poison_lds_kernel, dim3(4 * n_cu), dim3(256), 160 * 1024, stream, word, seen);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) rc = fail(MCPC_EHIP, "the LDS poison kernel failed");
+    }
+    if (rc == MCPC_OK) {
+        std::vector<int> h(8 * 256 + 1);
+        if (hipMemcpy(h.data(), seen, h.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(MCPC_EHIP, "hipMemcpy failed");
+        else {
+            int visited = 0;
+            for (int i = 0; i < 8 * 256; ++i) visited += h[i] > 0;
+            if (visited < n_cu) rc = fail(MCPC_ESTATE, "LDS poison reached %d of %d compute units", visited, n_cu);
+            else if (h[8 * 256] != 0) rc = fail(MCPC_ESTATE, "LDS poison read-back mismatch");
+        }
+    }
+    (void)hipFree(seen);
+    return rc;
+}
+
 int mcpc_set_profiling(mcpc_engine* e, int enable) {
     if (!e) return fail(MCPC_EINVAL, "null engine");
+    HIP_TRY(hipSetDevice(e->d.device));
     e->profiling = enable != 0;
-    e->events_used = e->events_mix_used = 0;
-    e->prof_steps = e->prof_steps_mix = 0;
+    e->events_used = 0;
+    e->prof_steps = 0;
+    if (enable) HIP_TRY(hipMemset(e->clk, 0, 2 * sizeof(unsigned long long)));      // (synchronises with the device: a diagnostic call)
     return MCPC_OK;
 }
 
@@ -1848,16 +1722,6 @@ int mcpc_last_step_kernel_ms(mcpc_engine* e, float* ms, int32_t* n_launches, int
     if (rc) return rc;
     if (n_launches) *n_launches = (int32_t)e->events_used;
     if (n_steps) *n_steps = (int64_t)std::llround(e->prof_steps);
-    return MCPC_OK;
-}
-
-int mcpc_last_mixed_cycles_ms(mcpc_engine* e, float* ms, int32_t* n_cycles, int64_t* n_steps) {
-    if (!e || !ms) return fail(MCPC_EINVAL, "null argument");
-    HIP_TRY(hipSetDevice(e->d.device));
-    const int rc = sum_events(e->events_mix, e->events_mix_used, ms);
-    if (rc) return rc;
-    if (n_cycles) *n_cycles = (int32_t)e->events_mix_used;
-    if (n_steps) *n_steps = (int64_t)std::llround(e->prof_steps_mix);
     return MCPC_OK;
 }
 

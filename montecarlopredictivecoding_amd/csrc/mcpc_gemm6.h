@@ -1,5 +1,4 @@
-// GEMM core of the step kernels, "bf16x6" form: fp32 products on the bf16 matrix pipe (mcpc_bf16x6.h).  The default;
-// -DMCPC_GEMM_FP32 selects the v_mfma_f32_16x16x4_f32 core in mcpc_kernels.h instead.
+// GEMM core of the step kernels, "bf16x6" form: fp32 products on the bf16 matrix pipe (mcpc_bf16x6.h).
 //
 // Every contraction of a Langevin step is out^T[unit][chain] = W[unit][k] . act^T[k][chain] in fp32.  On gfx950 the fp32 MFMA
 // (v_mfma_f32_16x16x4_f32) runs at the vector rate, 157 TFLOP/s; the bf16 MFMA (v_mfma_f32_16x16x32_bf16, fp32 accumulate) at 16
@@ -20,8 +19,11 @@
 //   C: the fp32 accumulator tile of the 16x16 MFMAs, same layout as before (lane (c, q): units 4q..4q+3 of chain c).
 // Fragments of a k-block travel ONE block ahead of their MFMAs in two register sets (P, Q) of 12 VGPRs per tile; the sets double as
 // the cross-entry prefetch (blocks 0 and 1 of the next table entry are requested into them while the current block is handed over).
-// k ranges that are not a multiple of 32 are covered by zero weights; what the B side reads beyond them is finite LDS content (the
-// step kernels clear their LDS once per launch), so the excess products are exact zeros.
+// k ranges that are not a multiple of 32 (kw % 32 == 16): the weights beyond kw are zeros AND the B lanes beyond kw are zeroed in
+// registers (MCPC_LOAD_B, the last block only), so the excess products are exact zeros WHATEVER the LDS holds behind the row -- the
+// next chain's row, another region of the plan, or bytes another kernel left behind.  (Round 3 relied on "finite neighbours"; a
+// non-finite neighbour -- 0 x NaN -- was the intermittent NaN of tests/test_gpu_fuzz.py::test_wide_networks_against_oracle, DESIGN
+// section 8, reproduced by scripts/nan_repro.py and pinned by tests/test_gpu_lds_poison.py.)
 #pragma once
 
 namespace mcpc {
@@ -46,6 +48,13 @@ __device__ __forceinline__ frag_t split8(f32x4 x0, f32x4 x1) {
     frag_t f;
     f.h = u32x4{h[0], h[1], h[2], h[3]}; f.m = u32x4{m[0], m[1], m[2], m[3]}; f.l = u32x4{l[0], l[1], l[2], l[3]};
     return f;
+}
+
+__device__ __forceinline__ f32x4 and4(f32x4 v, uint32_t m) {
+    f32x4 r;
+    r.x = __uint_as_float(__float_as_uint(v.x) & m); r.y = __uint_as_float(__float_as_uint(v.y) & m);
+    r.z = __uint_as_float(__float_as_uint(v.z) & m); r.w = __uint_as_float(__float_as_uint(v.w) & m);
+    return r;
 }
 
 // the six products of one k-block for NT tiles x CTT chain tiles, small terms first; consecutive MFMAs go to different
@@ -80,10 +89,13 @@ __device__ __forceinline__ void mfma6_block(f32x4 (&acc)[NTT][CTT], const frag_t
 // block and the read-out's back-projection), the fp32 B rows, their three planes and the split's temporaries that is what
 // keeps a 32-chain GEMM wave inside its 256 registers.  Static register names need the rotation unrolled over three k-blocks.
 template <int NT, int NTT, int CTT, int NW>
-__device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nkb,
+__device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nkb, int kw,
                                            const float* B, int ldb, int lane, frag_t (&pre)[NTT]) {
+    static_assert(CTT == 1, "one chain tile per workgroup (the 32-chain forms left the tree in round 4)");
     constexpr int N0 = NT < 2 ? NT : 2, N1 = NT - N0;            // tiles of group 0 / group 1
     const int c = lane & 15, g = lane >> 4;
+    // lanes whose eight k values of the LAST block lie beyond kw (g >= 2 when kw % 32 == 16) read as zeros
+    const uint32_t tail_keep = (uint32_t)(kKB * (nkb - 1) + 8 * g) < (uint32_t)kw ? ~0u : 0u;
     const float* bp = B + c * ldb + 8 * g;
     // wave-uniform base + a 32-bit per-lane byte offset that never changes during the GEMM (no VALU address arithmetic per load)
     uint32_t voff[NT];
@@ -97,9 +109,10 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
 #define MCPC_LOAD_B(k_)                                                                             \
     do {                                                                                            \
         const int kc_ = (k_) < last ? (k_) : last;          /* clamped, never conditional */        \
+        const uint32_t keep_ = (k_) < last ? ~0u : tail_keep;                                       \
         _Pragma("unroll") for (int ct = 0; ct < CTT; ++ct) {                                        \
-            bC[ct][0] = *reinterpret_cast<const f32x4*>(bp + ct * 16 * ldb + kc_ * kKB);            \
-            bC[ct][1] = *reinterpret_cast<const f32x4*>(bp + ct * 16 * ldb + kc_ * kKB + 4);        \
+            bC[ct][0] = and4(*reinterpret_cast<const f32x4*>(bp + ct * 16 * ldb + kc_ * kKB), keep_);     \
+            bC[ct][1] = and4(*reinterpret_cast<const f32x4*>(bp + ct * 16 * ldb + kc_ * kKB + 4), keep_); \
         }                                                                                           \
     } while (0)
     // fragments of group G_ (0 / 1) of block k_ (clamped) into half-set s_
@@ -122,30 +135,8 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
     do { MCPC_M6(s_, G_, ct_, m, m); MCPC_M6(s_, G_, ct_, l, h); MCPC_M6(s_, G_, ct_, h, l);         \
          MCPC_M6(s_, G_, ct_, m, h); MCPC_M6(s_, G_, ct_, h, m); MCPC_M6(s_, G_, ct_, h, h); } while (0)
 #define MCPC_SPLIT1(ct_) bs[ct_] = split8(bC[ct_][0], bC[ct_][1])
-    // One k-block, CTT == 2: four sub-steps (G0,ct0) (G0,ct1) (G1,ct0) (G1,ct1).  The planes of chain tile 0 are last read in the
-    // third, those of chain tile 1 in the fourth, so the split of the NEXT block's rows runs beside MFMAs that do not need its
-    // destination: ct0 of block k + 1 beside (G1,ct1) of block k, ct1 of block k + 1 beside (G0,ct0) of block k + 1 -- no second copy
-    // of the planes, and the ~45 VALU instructions of a split sit between twelve MFMAs instead of in front of forty-eight.
-    // The B rows (ONE fp32 buffer) are re-read when both of its halves have been split, the half-sets as before.
-#define MCPC_BLOCK2(sa_, sb_, sc_, k_)   /* sa_: set of (k, G0); sb_: set of (k, G1); sc_: free */    \
-    do {                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-        MCPC_LOAD_HALF(sc_, 0, (k_) + 1);                                                           \
-        MCPC_SPLIT1(CTT - 1);                      /* (k, ct1): its rows are still in bC[1] */      \
-        MCPC_SUB(sa_, 0, 0);                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-        MCPC_LOAD_B((k_) + 1);                                                                      \
-        MCPC_SUB(sa_, 0, CTT - 1);                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-        MCPC_LOAD_HALF(sa_, 1, (k_) + 1);                                                           \
-        MCPC_SUB(sb_, 1, 0);                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-        MCPC_SPLIT1(0);                            /* (k + 1, ct0) */                               \
-        MCPC_SUB(sb_, 1, CTT - 1);                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-    } while (0)
-    // CTT == 1: one chain tile, its planes are read by both sub-steps: the next block's split goes into a second copy beside
-    // (k, G1) and is moved over at the end of the block (12 v_mov; a 16-chain wave has the registers)
+    // One k-block: the chain tile's planes are read by both sub-steps, so the next block's split goes into a second copy beside
+    // (k, G1) and is moved over at the end of the block (12 v_mov)
 #define MCPC_BLOCK1(sa_, sb_, sc_, k_)                                                              \
     do {                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -159,15 +150,15 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
         MCPC_LOAD_B((k_) + 2);                                                                      \
         bs[0] = bsn_;                                                                               \
     } while (0)
-#define MCPC_BLOCK(sa_, sb_, sc_, k_) do { if constexpr (CTT == 2) MCPC_BLOCK2(sa_, sb_, sc_, k_); else MCPC_BLOCK1(sa_, sb_, sc_, k_); } while (0)
+#define MCPC_BLOCK(sa_, sb_, sc_, k_) MCPC_BLOCK1(sa_, sb_, sc_, k_)
     // block 0 arrives in `pre`: tiles 0, 1 -> set 0, tiles 2, 3 -> set 1
 #pragma unroll
     for (int i = 0; i < N0; ++i) s0[i] = pre[i];
 #pragma unroll
     for (int i = 0; i < N1; ++i) s1[i] = pre[2 + i];
     MCPC_LOAD_B(0);
-    MCPC_SPLIT1(0);                                     // (0, ct0); CTT == 2: (0, ct1) follows in the first block
-    if constexpr (CTT == 1) MCPC_LOAD_B(1);
+    MCPC_SPLIT1(0);
+    MCPC_LOAD_B(1);
     int k = 0;
     // steady state: three k-blocks per round (the rotation's period); every request is for an existing block or clamped to the last
     for (; k + 3 <= nkb; k += 3) {
@@ -184,7 +175,6 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
     }
 #undef MCPC_BLOCK
 #undef MCPC_BLOCK1
-#undef MCPC_BLOCK2
 #undef MCPC_SPLIT1
 #undef MCPC_SUB
 #undef MCPC_M6
@@ -194,25 +184,26 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
 
 // nt (wave-uniform, 1..NTT) selects a straight-line instantiation: no per-tile branches in the loop
 template <int N, int NTT, int CTT, int NW>
-__device__ __forceinline__ void gemm_dispatch(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nt, int nkb,
+__device__ __forceinline__ void gemm_dispatch(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nt, int nkb, int kw,
                                               const float* B, int ldb, int lane, frag_t (&pre0)[NTT]) {
     if constexpr (N >= NTT) {
-        gemm_fixed<NTT, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0);
+        gemm_fixed<NTT, NTT, CTT, NW>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0);
     } else {
-        if (nt == N) gemm_fixed<N, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0);
-        else gemm_dispatch<N + 1, NTT, CTT, NW>(acc, A, aoff, nt, nkb, B, ldb, lane, pre0);
+        if (nt == N) gemm_fixed<N, NTT, CTT, NW>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0);
+        else gemm_dispatch<N + 1, NTT, CTT, NW>(acc, A, aoff, nt, nkb, kw, B, ldb, lane, pre0);
     }
 }
+// kw: valid k width of the B rows (a multiple of 16, 32 (nkb - 1) < kw <= 32 nkb)
 template <int NTT, int CTT, int NW>
-__device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const void* A, const int (&aoff)[NTT], int nt, int nkb,
-                                           const float* B, int ldb, int lane, frag_t (&pre0)[NTT], frag_t (&)[NTT]) {
-    gemm_dispatch<1, NTT, CTT, NW>(acc, (const gu32x4*)A, aoff, nt, nkb, B, ldb, lane, pre0);     // (pre1: the fp32 core's second prefetched block)
+__device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const void* A, const int (&aoff)[NTT], int nt, int nkb, int kw,
+                                           const float* B, int ldb, int lane, frag_t (&pre0)[NTT]) {
+    gemm_dispatch<1, NTT, CTT, NW>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0);
 }
 
 // request the fragments of k-block 0 of a phase's GEMM (issued one phase early: weights do not depend on any barrier)
 template <int NW, int NTW>
 __device__ __forceinline__ void prefetch_first_blocks(const KPhase& ph, int wave, int lane, int& nt, int (&aoff)[NTW],
-                                                      frag_t (&pre0)[NTW], frag_t (&pre1)[NTW]) {
+                                                      frag_t (&pre0)[NTW]) {
     nt = (ph.ntiles - wave + NW - 1) / NW;
     nt = nt < 0 ? 0 : (nt > NTW ? NTW : nt);
     if (ph.type == PH_ENERGY) nt = 0;

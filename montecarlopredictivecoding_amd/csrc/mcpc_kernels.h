@@ -8,9 +8,6 @@
 //                         activation) rows, split-K with deterministic slab reduction.
 //                         replaces the parameter part of overall.backward(), pc_trainer.py:862.
 #pragma once
-#if !defined(MCPC_GEMM_FP32) && !defined(MCPC_GEMM_BF16X6)
-#define MCPC_GEMM_BF16X6 1
-#endif
 #include "mcpc_device.h"
 #include "mcpc_bf16x6.h"
 #include "../../include/mcpc.h"
@@ -81,6 +78,7 @@ struct KPhase {
     int a_tile_stride;     // 16-byte units between the fragments of consecutive output tiles
     int a_off0;            // 16-byte offset of the first k-block of the k-window
     int nkb;               // k-blocks of kKB (0: no GEMM -- top-layer pass, update without back-projection)
+    int kw;                // valid k width of the B rows (a multiple of 16 in (32 (nkb - 1), 32 nkb]): B lanes beyond it read as zeros
     int b_lds, ldb;        // B operand: LDS float offset and row stride
     int flags;             // PHF_*
     float sign;            // BWD: g = e + sign * f'(x) * back
@@ -128,11 +126,11 @@ struct KParams {
     int lds_ws_sync;                 // wave-specialised kernel: float offset of the progress counters
     int ws_prio;                     // 1: epilogue waves run at raised static priority
     int* err;                        // device error word (bit 0/1: a progress-counter wait ran out)
-    // in-place kernel, mixed schedule (32- and 16-chain workgroups side by side, see run_mixed in mcpc_api.hip): workgroup ->
-    // unit (pair of chain tiles or single tile) and the steps that unit has already done since the cycle began
+    // in-place kernel, round schedule (setup_rounds / run_round_cycle in mcpc_api.hip): workgroup -> 16-chain unit and the launches of
+    // the cycle that unit has already taken part in
     const int* wg_list;              // [gridDim.x] unit index, or null: unit = blockIdx.x
-    const int* wg_rel;               // [gridDim.x] (segments of the cycle spent split) | (segments spent paired) << 16, or null
-    int mix_ms, mix_mp;              // steps per segment of a split / a paired unit
+    const int* wg_rel;               // [gridDim.x] launches of this cycle the unit has already run, or null
+    int rr_q;                        // steps per launch of the cycle
     int epart_slots;                 // in-place kernel: energy partials are indexed by 16-chain tile, this many per row
     int lean_ok;                     // in-place kernel: every [Bpad][npad] image is < 4 GiB and Bpad < 2^24 (32-bit lane offsets)
     const void* dummy;               // 4 KiB of valid device memory: what the branch-free fragment prefetch reads for entries without a GEMM
@@ -140,43 +138,12 @@ struct KParams {
                                      // target of the workgroup's chains live in LDS for the whole launch (mcpc_ws2_lean.h: XL)
     int spill_sys;                   // Hebbian spill stores at system scope (write-through): shards whose spill per step is far beyond the L2s
     int lds_floats;                  // floats of dynamic LDS of this plan (cleared once per launch: see mcpc_gemm6.h, k ranges)
+    unsigned long long* clk;         // profiling only (else null): [0] += shader cycles (s_memtime), [1] += 100 MHz wall ticks (s_memrealtime)
+                                     // of one wave of workgroup 0 over the launch -- their ratio is the shader clock under THIS load
 #ifdef MCPC_STAMPS
     unsigned long long* dbg;   // diagnostic build only: [nwg][kWaves][16] cycle sums per phase
 #endif
 };
-
-// ------------------------------------------------------------------------------------------------
-// Tile GEMM: acc[t][ct] (16 units x 16 chains, C layout: lane (c=lane&15, q=lane>>4) holds units
-// 4q..4q+3 of chain c) += A_t * B, K = 16*nkb.
-//   A: packed global fragments, one coalesced 1 KiB load per (tile, k-block): lane (m,q) holds
-//      W[u0+m][k0+4q+r] (forward) or W[k0+4q+r][i0+m] (backward), r = 0..3
-//   B: LDS rows [chain][k]: lane (c,q) reads 16 B at [c][k0+4q] -> the same k set per MFMA.
-// MFMA r pairs A.r with B.r: k-set {k0+4q+r : q=0..3}; four MFMAs cover the 16-deep block.
-// The fragment loads of k-block kb+1 are issued before the MFMAs of k-block kb (two named register
-// sets, loop unrolled by two) so that an L2 round trip hides behind 8*NT MFMAs.
-template <int NT, int NTT, int CTT, int NA>
-__device__ __forceinline__ void mfma_block(f32x4 (&acc)[NTT][CTT], const f32x4 (&a)[NA], const f32x4 (&b)[CTT]) {
-    static_assert(NA >= NT, "fragment set smaller than the tile count");
-    // round-robin over every accumulator of the wave: a given accumulator is touched again only after
-    // NT*CTT other MFMAs (the dependent-accumulate latency of v_mfma_f32_16x16x4_f32 is not hidden by
-    // alternating just two accumulators)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int ct = 0; ct < CTT; ++ct) acc[t][ct] = mfma16(a[t].x, b[ct].x, acc[t][ct]);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int ct = 0; ct < CTT; ++ct) acc[t][ct] = mfma16(a[t].y, b[ct].y, acc[t][ct]);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int ct = 0; ct < CTT; ++ct) acc[t][ct] = mfma16(a[t].z, b[ct].z, acc[t][ct]);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int ct = 0; ct < CTT; ++ct) acc[t][ct] = mfma16(a[t].w, b[ct].w, acc[t][ct]);
-}
 
 // Layout of images only the epilogues read or write -- Adam's moments m_l, v_l, the tile-major copy of an fp32 target: TILE-MAJOR --
 // the 16 chains x 16 units a wave's float4 access covers are one contiguous KiB, in lane order, instead of sixteen 64-byte pieces of
@@ -236,187 +203,12 @@ __device__ __forceinline__ void issue_epilogue_loads(const KParams& P, const KPh
 }
 
 // ---- GEMM core ------------------------------------------------------------------------------------------------------------
-// Default: fp32 products emulated in-class on the bf16 matrix pipe (mcpc_gemm6.h, mcpc_bf16x6.h).  -DMCPC_GEMM_FP32 builds the round-1/2
-// core on v_mfma_f32_16x16x4_f32 instead (A/B runs: `make variant VARNAME=fp32 VARFLAGS=-DMCPC_GEMM_FP32`).  Both expose
-//   frag_t, kKB (k-depth of a fragment block), kFragBlock (16-byte units per tile and block), frag_zero, load_frag,
-//   gemm_tiles, prefetch_first_blocks
-// and read the B operand from the same fp32 LDS rows.
-#ifdef MCPC_GEMM_BF16X6
+// fp32 products emulated in-class on the bf16 matrix pipe (mcpc_gemm6.h, mcpc_bf16x6.h): frag_t, kKB (k-depth of a fragment block),
+// kFragBlock (16-byte units per tile and block), frag_zero, load_frag, gemm_tiles, prefetch_first_blocks.  The B operand is read from
+// fp32 LDS rows.  (Rounds 1-2 ran v_mfma_f32_16x16x4_f32 here; that core left the tree in round 4 -- git history)
 }  // namespace mcpc
 #include "mcpc_gemm6.h"
 namespace mcpc {
-#else
-typedef f32x4 frag_t;                   // one 16-deep k-block of one tile: lane (m, q) holds W[16ut+m][16kb+4q+r], r = 0..3
-constexpr int kKB = 16;
-constexpr int kFragBlock = 64;
-__device__ __forceinline__ frag_t frag_zero() { return splat(0.f); }
-__device__ __forceinline__ frag_t load_frag(const gf32x4* A, int off, int lane) { return A[off + lane]; }
-#ifdef MCPC_EXP_NOLOAD   // timing experiment only (wrong results): every fragment load re-reads k-block 0 -> L1 hits
-#define MCPC_KSEL(k_) 0
-#else
-#define MCPC_KSEL(k_) (k_)
-#endif
-template <int NT, int NTT, int CTT, int NW>
-__device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gf32x4* __restrict__ A,
-                                           const int (&aoff)[NTT], int nkb,
-                                           const float* B, int ldb, int lane,
-                                           const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT]) {
-    // Three named register sets, fragment loads issued TWO k-blocks ahead of their MFMAs: with one
-    // wave per SIMD (or two) the loads in flight per CU, not the issue rate, bound the L2 stream.
-    // The fragments of k-blocks 0 and 1 were requested by the caller during the previous phase.
-    // (Four sets / three blocks ahead: 35.7 -> 33.3 cycles per MFMA in the isolated loop, scripts/mfma_stream_ubench.hip,
-    // but no gain inside the step kernel, where the GEMMs are 12-16 k-blocks long -- measured and dropped.)
-    const int c = lane & 15, q = lane >> 4;
-    const float* bp = B + c * ldb + 4 * q;
-    f32x4 aP[NT], aQ[NT], aR[NT], bP[CTT], bQ[CTT], bR[CTT];
-    // Fragment addresses = wave-uniform base (SGPR pair, advanced by the scalar ALU) + a 32-bit per-lane byte offset that
-    // never changes during the GEMM: `global_load_dwordx4 v, v_off, s[base]` needs no VALU address arithmetic at all (with
-    // a 64-bit per-lane pointer every load cost a v_add, a v_ashr and a v_lshl_add_u64 between the MFMA blocks).
-    uint32_t voff[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) voff[t] = (uint32_t)(aoff[t] + lane) * 16u;
-    const char __attribute__((address_space(1)))* const Ab = (const char __attribute__((address_space(1)))*)A;
-#define MCPC_LOAD_B(b_, k_)                                                                         \
-    do {                                                                                            \
-        _Pragma("unroll") for (int ct = 0; ct < CTT; ++ct)                                          \
-            b_[ct] = *reinterpret_cast<const f32x4*>(bp + ct * 16 * ldb + (k_) * 16);               \
-    } while (0)
-#define MCPC_LOAD_SET(a_, b_, k_)                                                                   \
-    do {                                                                                            \
-        const char __attribute__((address_space(1)))* const Ak_ = Ab + (size_t)MCPC_KSEL(k_) * 1024u; \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) a_[t] = *(const gf32x4*)(Ak_ + voff[t]);     \
-        MCPC_LOAD_B(b_, k_);                                                                        \
-    } while (0)
-    // One pipeline stage = "request set k+2, compute set k".  The requests are spread over the MFMA block (one memory
-    // instruction behind every few MFMAs, where the issue port idles anyway while the matrix pipe works) instead of
-    // sitting in a clump between two blocks, during which the pipe drained: 36-37 -> 33 cycles per MFMA.
-#define MCPC_STAGE_SCHED()                                                                          \
-    do {                                                                                            \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                            \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   /* 2 MFMA */                       \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   /* 1 VMEM read */                  \
-        }                                                                                           \
-        _Pragma("unroll") for (int ct = 0; ct < CTT; ++ct) {                                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                      \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   /* 1 DS read */                    \
-        }                                                                                           \
-        if constexpr (4 * NT * CTT - 2 * NT - 2 * CTT > 0)                                          \
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * CTT - 2 * NT - 2 * CTT, 0);        \
-    } while (0)
-    MCPC_LOAD_B(bP, 0);
-    if (nkb > 1) MCPC_LOAD_B(bQ, 1);
-    int kb = 0;
-    if (nkb >= 5) {
-        // first round peeled: the prefetched fragments are consumed where they are (copying them into sets P and Q
-        // cost 8*NT v_mov behind an `s_waitcnt vmcnt(0)` at the head of every GEMM)
-        __builtin_amdgcn_sched_barrier(0);
-        MCPC_LOAD_SET(aR, bR, 2);
-        mfma_block<NT, NTT, CTT>(acc, pre0, bP);
-        MCPC_STAGE_SCHED();
-        __builtin_amdgcn_sched_barrier(0);
-        MCPC_LOAD_SET(aP, bP, 3);
-        mfma_block<NT, NTT, CTT>(acc, pre1, bQ);
-        MCPC_STAGE_SCHED();
-        __builtin_amdgcn_sched_barrier(0);
-        MCPC_LOAD_SET(aQ, bQ, 4);
-        mfma_block<NT, NTT, CTT>(acc, aR, bR);
-        MCPC_STAGE_SCHED();
-        __builtin_amdgcn_sched_barrier(0);
-        kb = 3;
-    } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { aP[t] = pre0[t]; aQ[t] = pre1[t]; }
-    }
-    // Steady state: NO conditional loads inside the loop.  hipcc counts vmcnt exactly only across
-    // straight-line code; a branch around a load makes it fall back to draining every outstanding
-    // load before the next MFMA block (guide section 5, "Three .s-level traps" (c)).
-    for (; kb + 5 <= nkb; kb += 3) {
-        // sched_barrier pins the stage boundaries: left alone, the machine scheduler sinks the loads next to their
-        // consumers and the two-block prefetch distance is lost
-        __builtin_amdgcn_sched_barrier(0);
-        MCPC_LOAD_SET(aR, bR, kb + 2);
-        mfma_block<NT, NTT, CTT>(acc, aP, bP);
-        MCPC_STAGE_SCHED();
-        __builtin_amdgcn_sched_barrier(0);
-        MCPC_LOAD_SET(aP, bP, kb + 3);
-        mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
-        MCPC_STAGE_SCHED();
-        __builtin_amdgcn_sched_barrier(0);
-        MCPC_LOAD_SET(aQ, bQ, kb + 4);
-        mfma_block<NT, NTT, CTT>(acc, aR, bR);
-        MCPC_STAGE_SCHED();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // tail: 0..4 k-blocks left, sets P (kb) and Q (kb+1) are loaded when they exist
-    const int rem = nkb - kb;
-    if (rem == 4) {
-        // pinned like the steady state: unpinned, hipcc moved the last request behind set R's MFMAs (re-using R's
-        // registers) and waited for it at once -- one exposed L2 round trip per GEMM with 16 k-blocks
-        MCPC_LOAD_SET(aR, bR, kb + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block<NT, NTT, CTT>(acc, aP, bP);
-        __builtin_amdgcn_sched_barrier(0);
-        MCPC_LOAD_SET(aP, bP, kb + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
-        mfma_block<NT, NTT, CTT>(acc, aR, bR);
-        mfma_block<NT, NTT, CTT>(acc, aP, bP);
-    } else if (rem == 3) {
-        MCPC_LOAD_SET(aR, bR, kb + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_block<NT, NTT, CTT>(acc, aP, bP);
-        mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
-        mfma_block<NT, NTT, CTT>(acc, aR, bR);
-    } else if (rem == 2) {
-        mfma_block<NT, NTT, CTT>(acc, aP, bP);
-        mfma_block<NT, NTT, CTT>(acc, aQ, bQ);
-    } else {
-        if (rem == 1) mfma_block<NT, NTT, CTT>(acc, aP, bP);
-    }
-#undef MCPC_STAGE_SCHED
-#undef MCPC_LOAD_SET
-#undef MCPC_LOAD_B
-}
-
-// nt (wave-uniform, 1..NTT) selects a straight-line instantiation: no per-tile branches in the loop
-template <int N, int NTT, int CTT, int NW>
-__device__ __forceinline__ void gemm_dispatch(f32x4 (&acc)[NTT][CTT], const gf32x4* __restrict__ A, const int (&aoff)[NTT], int nt, int nkb,
-                                              const float* B, int ldb, int lane, const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT]) {
-    if constexpr (N >= NTT) {
-        gemm_fixed<NTT, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1);
-    } else {
-        if (nt == N) gemm_fixed<N, NTT, CTT, NW>(acc, A, aoff, nkb, B, ldb, lane, pre0, pre1);
-        else gemm_dispatch<N + 1, NTT, CTT, NW>(acc, A, aoff, nt, nkb, B, ldb, lane, pre0, pre1);
-    }
-}
-template <int NTT, int CTT, int NW>
-__device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const void* A,
-                                           const int (&aoff)[NTT], int nt, int nkb,
-                                           const float* B, int ldb, int lane,
-                                           const f32x4 (&pre0)[NTT], const f32x4 (&pre1)[NTT]) {
-    gemm_dispatch<1, NTT, CTT, NW>(acc, (const gf32x4*)A, aoff, nt, nkb, B, ldb, lane, pre0, pre1);
-}
-
-// request the fragments of k-blocks 0 and 1 of a phase's GEMM (issued one phase early: weights do not
-// depend on any barrier, so their L2 round trip hides behind the previous epilogue)
-template <int NW, int NTW>
-__device__ __forceinline__ void prefetch_first_blocks(const KPhase& ph, int wave, int lane, int& nt, int (&aoff)[NTW],
-                                                      f32x4 (&pre0)[NTW], f32x4 (&pre1)[NTW]) {
-    nt = (ph.ntiles - wave + NW - 1) / NW;
-    nt = nt < 0 ? 0 : (nt > NTW ? NTW : nt);
-    if (ph.type == PH_ENERGY) nt = 0;
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        aoff[i] = (ph.tile0 + wave + NW * i) * ph.a_tile_stride + ph.a_off0;
-        if (i < nt && ph.nkb > 0) {
-            const gf32x4* A = (const gf32x4*)ph.A;      // weights live in global memory: global_load, not flat_load
-            pre0[i] = A[aoff[i] + lane];
-            if (ph.nkb > 1) pre1[i] = A[aoff[i] + 64 + lane];
-        }
-    }
-}
-
-#endif   // MCPC_GEMM_BF16X6
 
 // guarded scalar store of a C-layout quad into an unpadded [B][n] tensor row
 __device__ __forceinline__ void st_unpadded(float* base, int chain, int n, int u0, f32x4 v) {
@@ -682,8 +474,11 @@ __device__ __forceinline__ void bwd_epilogue_mode(const KParams& P, const KPhase
     else bwd_epilogue<CTT, NW, NTW, ACT, 0, FXOUT>(P, ph, nt, wave, lane, chain0, acc, pa, pb, s, t, lds);
 }
 
+#ifndef MCPC_BARRIER_WAVES_PER_EU
+#define MCPC_BARRIER_WAVES_PER_EU 2      // two workgroups per CU (one's GEMMs cover the other's epilogues); 1: no spilled VGPRs, one workgroup per CU
+#endif
 template <int CTT, int NW>
-__global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_steps_kernel(const KParams P) {
+__global__ __launch_bounds__(NW * 64, MCPC_BARRIER_WAVES_PER_EU) void mcpc_steps_kernel(const KParams P) {
     constexpr int NTW = 16 / NW;     // unit tiles per wave per phase (a phase hands out 16 tiles)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
@@ -694,11 +489,9 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
     // fused fast paths of the x update (wave-uniform, fixed for the launch)
     const int upd_mode = (P.update_x && P.xopt == MCPC_XOPT_SGD)
                              ? (P.noise_mode == MCPC_NOISE_PHILOX ? 2 : (P.noise_mode == MCPC_NOISE_NONE ? 1 : 0)) : 0;
-#ifdef MCPC_GEMM_BF16X6
-    // the GEMM core may read B rows a little beyond a k range (zero weights there): every float of the plan is finite from here on
+    // every float of the plan starts a launch as zero (row tails and padding columns are never written afterwards)
     for (int i = tid; i < P.lds_floats / 4; i += NW * 64) st4(lds + 4 * i, splat(0.f));
     __syncthreads();
-#endif
     if (P.stagger_cycles > 0 && blockIdx.x >= 256) {
         // two workgroups share a CU: start the second one out of phase so that its GEMMs overlap the
         // first one's epilogues / barriers instead of competing for the matrix pipe in lockstep
@@ -709,10 +502,10 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
     // software pipeline over phases: descriptor + first two weight k-blocks of the upcoming phase
     KPhase ph_next = load_phase(P.phases, 0);
     int nt_next, aoff_next[NTW];
-    frag_t pre0_next[NTW], pre1_next[NTW];
+    frag_t pre0_next[NTW];
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) { pre0_next[i] = frag_zero(); pre1_next[i] = frag_zero(); }
-    prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
+    for (int i = 0; i < NTW; ++i) pre0_next[i] = frag_zero();
+    prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next);
 
     for (int s = 0; s < P.n_steps; ++s) {
         const int t = P.t0 + s;
@@ -740,9 +533,9 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
             const KPhase ph = ph_next;
             const int nt = nt_next;
             int aoff[NTW];
-            frag_t pre0[NTW], pre1[NTW];
+            frag_t pre0[NTW];
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) { aoff[i] = aoff_next[i]; pre0[i] = pre0_next[i]; pre1[i] = pre1_next[i]; }
+            for (int i = 0; i < NTW; ++i) { aoff[i] = aoff_next[i]; pre0[i] = pre0_next[i]; }
             // descriptor of the phase after this one (wraps into the next step)
             const bool has_next = (p + 1 < P.n_phases) || (s + 1 < P.n_steps);
             if (has_next) ph_next = load_phase(P.phases, p + 1 < P.n_phases ? p + 1 : 0);
@@ -760,7 +553,7 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
                         P.epart[((size_t)erow * gridDim.x + blockIdx.x) * (kMaxLatent + 1) + tid] = v;
                     }
                 }
-                if (has_next) prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
+                if (has_next) prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next);
                 STAMP(12);
                 continue;
             }
@@ -781,9 +574,9 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
             // (Requesting them after the GEMM's last fragment load was measured slower on MI355X.)
             if (ph.type != PH_HEADB) issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
             if (nt > 0 && ph.nkb > 0)
-                gemm_tiles<NTW, CTT, NW>(acc, ph.A, aoff, nt, ph.nkb, lds + ph.b_lds, ph.ldb, lane, pre0, pre1);
+                gemm_tiles<NTW, CTT, NW>(acc, ph.A, aoff, nt, ph.nkb, ph.kw, lds + ph.b_lds, ph.ldb, lane, pre0);
             // the next phase's first weight fragments travel while this phase's epilogue runs
-            if (has_next) prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next, pre1_next);
+            if (has_next) prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next);
             if (ph.flags & PHF_ACC_TO_B) {
 #pragma unroll
                 for (int i = 0; i < NTW; ++i)
@@ -822,33 +615,6 @@ __global__ __launch_bounds__(NW * 64, (CTT == 1 || NW == 8) ? 2 : 1) void mcpc_s
 
 // ------------------------------------------------------------------------------------------------
 // Weight packing into MFMA fragment order (run once per parameter change).
-#ifndef MCPC_GEMM_BF16X6
-//   forward : Wf[ut][kb][lane][r] = W[16ut + (lane&15)][16kb + 4(lane>>4) + r]
-//   backward: Wb[it][ub][lane][r] = W[16ub + 4(lane>>4) + r][16it + (lane&15)]
-__global__ void mcpc_pack_kernel(const float* __restrict__ W, const float* __restrict__ bias,
-                                 float* __restrict__ Wf, float* __restrict__ Wb, float* __restrict__ bias_pad,
-                                 int n_out, int n_in, int out_tiles, int in_tiles) {
-    const size_t total = (size_t)out_tiles * in_tiles * 256;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int r = idx & 3, lane = (idx >> 2) & 63;
-        const size_t blk = idx >> 8;
-        {   // forward: blk = ut*in_tiles + kb
-            const int ut = blk / in_tiles, kb = blk % in_tiles;
-            const int u = 16 * ut + (lane & 15), k = 16 * kb + 4 * (lane >> 4) + r;
-            Wf[idx] = (u < n_out && k < n_in) ? W[(size_t)u * n_in + k] : 0.f;
-        }
-        {   // backward: blk = it*out_tiles + ub
-            const int it = blk / out_tiles, ub = blk % out_tiles;
-            const int u = 16 * ub + 4 * (lane >> 4) + r, i = 16 * it + (lane & 15);
-            Wb[idx] = (u < n_out && i < n_in) ? W[(size_t)u * n_in + i] : 0.f;
-        }
-    }
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < out_tiles * 16) bias_pad[gid] = (bias != nullptr && gid < n_out) ? bias[gid] : 0.f;
-}
-
-#else
 // bf16x6 core (mcpc_gemm6.h): every weight is split into three bf16 pieces, stored as three planes per (tile, 32-deep block):
 //   forward : Wf[ut][kb][plane][lane] (16 B) = W[16ut + (lane&15)][32kb + 8(lane>>4) + j], j = 0..7
 //   backward: Wb[it][ub][plane][lane] (16 B) = W[32ub + 8(lane>>4) + j][16it + (lane&15)], j = 0..7
@@ -892,7 +658,6 @@ __global__ void mcpc_pack_kernel(const float* __restrict__ W, const float* __res
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < out_tiles * 16) bias_pad[gid] = (bias != nullptr && gid < n_out) ? bias[gid] : 0.f;
 }
-#endif
 
 // Bit-pack a padded target image [Bpad][npad] whose values are all exactly 0.0f / 1.0f (binarised MNIST, the Bernoulli
 // read-out's usual target): 98 B per chain instead of 3 136 B re-read from HBM in every step.  *flag is cleared by the first

@@ -119,30 +119,20 @@ __device__ __forceinline__ int ws2_need(int base, int n_ent, int p, int dep) {
 // branch behind `s_waitcnt vmcnt(0)`: four serial L2 round trips (~1 k cycles) per table entry.
 template <int NT>
 __device__ __forceinline__ void ws2_prefetch(const KPhase& ph, int k, int lane, const void* dummy, int& nt_out, int (&aoff)[NT],
-                                             frag_t (&pre0)[NT], frag_t (&pre1)[NT]) {
+                                             frag_t (&pre0)[NT]) {
     const int kk = (k + ph.rot) & (kWs2Pairs - 1);
     int nt = (ph.ntiles - kk + kWs2Pairs - 1) / kWs2Pairs;
     nt = nt < 0 ? 0 : (nt > NT ? NT : nt);
     if (!(ph.flags & PHF_WS_GEMM) || ph.nkb <= 0) nt = 0;
     nt_out = nt;
     const bool valid = nt > 0;
-#ifndef MCPC_GEMM_BF16X6
-    const gf32x4* const A = valid ? (const gf32x4*)ph.A : (const gf32x4*)dummy;
-#else
     const gu32x4* const A = valid ? (const gu32x4*)ph.A : (const gu32x4*)dummy;      // (dummy: any 6 KiB of valid global memory)
-#endif
-#ifndef MCPC_GEMM_BF16X6
-    const int second = (valid && ph.nkb > 1) ? kFragBlock : 0;
-#endif
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int ii = i < nt ? i : 0;
         const int off = valid ? (ph.tile0 + kk + kWs2Pairs * ii) * ph.a_tile_stride + ph.a_off0 : 0;
         aoff[i] = off;
         pre0[i] = load_frag(A, off, lane);
-#ifndef MCPC_GEMM_BF16X6
-        pre1[i] = load_frag(A, off + second, lane);
-#endif
     }
 }
 
@@ -269,35 +259,6 @@ __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps
 #include "mcpc_steps_ws2_body.inc"
 #undef WS2_BLOCK
 #undef WS2_NBLOCKS
-}
-
-// One segment of the mixed schedule as ONE launch: workgroups [0, np) are 32-chain workgroups running P2 (their units and step
-// offsets from P2.wg_list / wg_rel), the others 16-chain workgroups running P1.  (Two launches on two streams were concurrent only
-// while the streams had hardware queues of their own: the HIP runtime lets streams share queues -- GPU_MAX_HW_QUEUES = 4 per
-// priority class -- and in a process that also held RCCL communicators the two halves of every segment ran one after the
-// other.  One launch needs no second stream, no cross-stream events, and its workgroups go round-robin over the XCDs as ONE
-// sequence, so that no XCD receives more workgroups than it has CUs as long as the launch has at most one per CU.)
-__global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps_ws2_mixed_kernel(const KParams P2, const KParams P1, const int np) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    if ((int)blockIdx.x < np) {
-        constexpr int CTT = 2;
-        constexpr bool MIX = true;
-        const KParams& P = P2;
-#define WS2_BLOCK blockIdx.x
-#define WS2_NBLOCKS np
-#include "mcpc_steps_ws2_body.inc"
-#undef WS2_BLOCK
-#undef WS2_NBLOCKS
-    } else {
-        constexpr int CTT = 1;
-        constexpr bool MIX = true;
-        const KParams& P = P1;
-#define WS2_BLOCK (blockIdx.x - np)
-#define WS2_NBLOCKS (gridDim.x - np)
-#include "mcpc_steps_ws2_body.inc"
-#undef WS2_BLOCK
-#undef WS2_NBLOCKS
-    }
 }
 
 }  // namespace mcpc

@@ -64,7 +64,7 @@ class Engine:
         d.n_latent, d.n_in, d.n_out, d.batch = self.L, self.n_in, self.n_out, self.batch
         d.device = self.device.index
         d.spill_budget_bytes = int(spill_budget_bytes)
-        # developer overrides of the schedule heuristics ("ws=2,ct=32", see include/mcpc.h).  The library reads no
+        # developer overrides of the schedule heuristics ("ws=0,no_overlap=1", see include/mcpc.h).  The library reads no
         # environment; this harness-side variable lets the test-suite pin every kernel variant through the facade too.
         self.tuning = tuning if tuning is not None else os.environ.get("MCPC_TUNING")
         d.tuning = self.tuning.encode() if self.tuning else None
@@ -272,10 +272,18 @@ class Engine:
         L.check(self._lib.mcpc_last_step_kernel_ms(self._h, C.byref(ms), C.byref(n), C.byref(s)))
         return ms.value, n.value, s.value
 
-    def last_mixed_cycles_ms(self):
-        ms, n, s = C.c_float(), C.c_int32(), C.c_int64()
-        L.check(self._lib.mcpc_last_mixed_cycles_ms(self._h, C.byref(ms), C.byref(n), C.byref(s)))
-        return ms.value, n.value, s.value
+    def last_shader_clock_ghz(self):
+        g = C.c_float()
+        L.check(self._lib.mcpc_last_shader_clock_ghz(self._h, C.byref(g)))
+        return g.value
+
+
+def debug_poison_lds(device, word=0x7FA00000):
+    """Diagnostic (tests only): fill the LDS of every compute unit of `device` with a 32-bit pattern (default: a signalling NaN)."""
+    lib = L.load()
+    device = torch.device(device)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    L.check(lib.mcpc_debug_poison_lds(device.index or 0, word, stream))
 
 
 def philox_normals(seed, step, layer, chain_base, batch, n_units, device, raw=False) -> torch.Tensor:

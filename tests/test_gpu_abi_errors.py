@@ -33,7 +33,7 @@ def test_create_rejects_bad_descriptions():
     for kw, code, word in ((dict(abi=1), EINVAL, "ABI version"), (dict(n_latent=0), EINVAL, "n_latent"), (dict(n_latent=7), EINVAL, "n_latent"),
                            (dict(batch=0), EINVAL, "batch"), (dict(act=3), EINVAL, "acts"), (dict(ecoef=0.0), EINVAL, "ecoef"),
                            (dict(device=99), EINVAL, "device"), (dict(tuning=b"bogus=1"), EINVAL, "unknown tuning key"),
-                           (dict(tuning=b"ct=24"), EINVAL, "ct=24")):
+                           (dict(tuning=b"ws=1"), EINVAL, "ws=1")):
         d = _desc(L, **kw)
         assert lib.mcpc_create(C.byref(d), C.byref(h)) == code, kw
         assert word in _err(lib), (kw, _err(lib))

@@ -106,22 +106,17 @@ def check_against_golden(g, ci, call, res, eng, xs_final, sched, x_atol=3e-4, e_
             np.testing.assert_allclose(np.abs(dW.astype(np.float64)).sum(), g.get(ci, f"gW{j}_abs"), rtol=2e-4)
 
 
-@pytest.mark.parametrize("kernel", ["default", "inplace", "barrier"])
+@pytest.mark.parametrize("kernel", ["default", "barrier"])
 @pytest.mark.parametrize("name", fixture_names(exclude=("g9_",)))
 def test_engine_matches_reference_golden(name, kernel, monkeypatch):
-    """Every golden fixture on the kernel a small shard gets by default (in-place wave-specialised, 16 chains per workgroup),
-    on the 32-chain form large shards get (forced with tuning ws=2: the kernel the benchmark runs) AND on the barrier kernel
-    that remains the fallback (tuning ws=0): every loss / optimizer / noise / schedule variant the reference's fixtures hold is
-    pinned on all three."""
-    if kernel == "inplace":
-        monkeypatch.setenv("MCPC_TUNING", "ws=2")
-    elif kernel == "barrier":
+    """Every golden fixture on the default kernel (in-place wave-specialised: the kernel the benchmark runs) AND on the barrier
+    kernel that remains the fallback and the parity checks' independent form (tuning ws=0): every loss / optimizer / noise / schedule
+    variant the reference's fixtures hold is pinned on both."""
+    if kernel == "barrier":
         monkeypatch.setenv("MCPC_TUNING", "ws=0")
     g = Golden(name)
     eng = make_engine(g)
-    if kernel == "inplace" and eng.query()["chains_per_wg"] != 32:
-        eng.close()
-        pytest.skip("in-place plan does not fit this net: the engine fell back to 16-chain workgroups")
+    assert ("mcpc_steps_kernel<1, 4>" in eng.query()["step_kernel"]) == (kernel == "barrier")
     W, b = g.W, g.b
     keep = bind(eng, g)
     dev = _dev()

@@ -21,14 +21,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(params=["default", "inplace", "barrier"], autouse=True)
+@pytest.fixture(params=["default", "barrier"], autouse=True)
 def step_kernel(request, monkeypatch):
-    """Run every facade test on the kernel a small shard gets by default (in-place, 16 chains per workgroup), on the 32-chain
-    form large shards get (tuning ws=2) and on the barrier kernel kept as fallback (ws=0); MCPC_TUNING is read by engine.py when an
-    engine is created, and a plan that does not fit falls back by itself."""
-    if request.param == "inplace":
-        monkeypatch.setenv("MCPC_TUNING", "ws=2")
-    elif request.param == "barrier":
+    """Run every facade test on the default kernel (in-place, wave-specialised) and on the barrier kernel kept as fallback (ws=0);
+    MCPC_TUNING is read by engine.py when an engine is created, and a plan that does not fit falls back by itself."""
+    if request.param == "barrier":
         monkeypatch.setenv("MCPC_TUNING", "ws=0")
     return request.param
 

@@ -23,11 +23,6 @@ def _problem(batch=B, seed=30):
     return make_problem(batch, seed, DEV)
 
 
-# The mixed schedule belongs to the 32-chain workgroup form, which default plans no longer choose (shards of more units than CUs run
-# the round schedule of 16-chain workgroups): its tests select it explicitly, with the rate ratio their mirror of the plan assumes.
-MIXED_TUNING = "ws=2,ct=32,mix_ratio=17"
-
-
 def _engine(batch, W, b, y, **kw):
     from montecarlopredictivecoding_amd import _lib as L
     from montecarlopredictivecoding_amd.engine import Engine
@@ -158,108 +153,6 @@ def test_sharding_and_launch_slicing_do_not_change_trajectories():
     np.testing.assert_allclose(flat_sum, flat_whole, rtol=1e-4, atol=1e-6 * np.abs(flat_whole).max())
 
 
-def _mixed_plan(batch, T, n_cu=256):
-    """Mirror of setup_mixed_schedule / mcpc_run (mcpc_api.hip): (cycles, steps on the mixed schedule, segment sizes used) of an
-    inference stretch of T steps of a shard of `batch` chains on a GPU of n_cu CUs in 8 XCDs."""
-    from math import gcd
-    npairs = (batch + 31) // 32
-    ns = min(n_cu - npairs, npairs)
-    best = ns
-    if npairs // gcd(npairs, ns) > 64:
-        for c in range(ns - 1, max(0, ns - ns // 8 - 1), -1):
-            if c >= 1 and gcd(npairs, c) > gcd(npairs, best):
-                best = c
-    ns = best
-    if ns < 1 or 0.7 * ns < 0.04 * npairs:
-        return 0, 0, []
-    lc = npairs // gcd(npairs, ns)
-    a = ns * lc // npairs
-    cycles, steps, used, n, p = 0, 0, [], T, 80
-    while p >= 3:
-        sp = (17 * p + 5) // 10
-        cyc = a * sp + (lc - a) * p
-        if cyc > n:
-            p -= 1
-            continue
-        cycles += 1; steps += cyc; n -= cyc; used.append(p)
-    return cycles, steps, used
-
-
-def test_mixed_schedule_matches_plain_schedule(monkeypatch):
-    """Inference stretches of a shard that leaves CUs idle run on the mixed schedule (most chain-tile pairs as 32-chain
-    workgroups, a rotating subset split into 16-chain workgroups on the spare CUs).  Per chain the arithmetic is the same, so
-    trajectories and records must be BITWISE those of the plain schedule; energies regroup fp32 partial sums."""
-    W, b, y, xs = _problem()
-    T = 420                                    # 400 inference steps (one cycle of (6, 10) steps per segment: 350, then plain), then 20 Hebbian steps
-    outs = []
-    for no_mix in (False, True):
-        monkeypatch.setenv("MCPC_TUNING", MIXED_TUNING + (",no_mix=1" if no_mix else ""))
-        eng = _engine(B, W, b, y)
-        res, out = _run(eng, xs, T, acc_begin=400, acc_end=T, rec_begin=0, rec_stride=60, rec_count=7, rec_x=True)
-        outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x],
-                     eng.read_param_grads_flat().cpu().numpy()))
-        eng.close()
-    for a, c in zip(outs[0][1], outs[1][1]):
-        assert np.array_equal(a, c)
-    for a, c in zip(outs[0][2], outs[1][2]):
-        assert np.array_equal(a, c)
-    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-6)
-    assert np.all(np.isfinite(outs[0][0]))
-    assert np.array_equal(outs[0][3], outs[1][3])            # the Hebbian steps run on the plain schedule either way
-
-
-def test_mixed_schedule_all_segment_sizes_match_plain_schedule(monkeypatch):
-    """A call runs whole cycles of the mixed schedule, longest segments first: up to (80, 136) steps per segment (4712 steps per cycle
-    at B = 6000), then the longest that still fits, down to (3, 5) (175 steps), before the plain schedule takes what is left.
-    T = 6100 runs one cycle with (80, 136) steps per segment, one with (23, 39) (1353 steps) and 35 plain steps; the shortest form, (3, 5),
-    is what test_mixed_schedule_with_per_step_tables runs, (6, 10) what test_mixed_schedule_matches_plain_schedule runs: final state and
-    every record must be BITWISE those of the plain schedule."""
-    W, b, y, xs = _problem()
-    T = 4712 + 1353 + 35
-    assert _mixed_plan(B, T) == (2, 4712 + 1353, [80, 23])
-    outs = []
-    for no_mix in (False, True):
-        monkeypatch.setenv("MCPC_TUNING", MIXED_TUNING + (",no_mix=1" if no_mix else ""))
-        eng = _engine(B, W, b, y)
-        eng.set_profiling(True)
-        res, out = _run(eng, xs, T, rec_begin=0, rec_stride=277, rec_count=23, rec_x=True)
-        ms, n_cycles, n_steps = eng.last_mixed_cycles_ms()
-        assert (n_cycles, n_steps) == ((0, 0) if no_mix else (2, 4712 + 1353))
-        outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x]))
-        eng.close()
-    for a, c in zip(outs[0][1], outs[1][1]):
-        assert np.array_equal(a, c)
-    for a, c in zip(outs[0][2], outs[1][2]):
-        assert np.array_equal(a, c)
-    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-6)
-    assert np.all(np.isfinite(outs[0][0]))
-
-
-@pytest.mark.parametrize("batch,T", [(7500, 700), (5000, 700), (4200, 420), (8000, 300)])
-def test_mixed_schedule_other_shard_sizes(batch, T, monkeypatch):
-    """The pair / single counts of the mixed schedule and the length of its rotation depend on the shard size: 7500 chains =
-    215 pairs + 40 singles (20 splits rotate in 47 segments; the 21 the CUs allow would take 235), 5000 chains = 58 + 198,
-    rotation of 157 (157 pairs: prime), 4200 chains = 8 + 248; 8000 chains would split 6 pairs of 250, which does not pay:
-    plain schedule.  Trajectories and records must be BITWISE those of the plain schedule for every one of them."""
-    W, b, y, xs = _problem(batch)
-    cycles, steps, used = _mixed_plan(batch, T)
-    assert (cycles > 0) == (batch != 8000) and steps <= T
-    outs = []
-    for no_mix in (False, True):
-        monkeypatch.setenv("MCPC_TUNING", MIXED_TUNING + (",no_mix=1" if no_mix else ""))
-        eng = _engine(batch, W, b, y)
-        eng.set_profiling(True)
-        res, out = _run(eng, xs, T, rec_begin=0, rec_stride=97, rec_count=(T + 96) // 97, rec_x=True)
-        ms, n_cycles, n_steps = eng.last_mixed_cycles_ms()
-        assert (n_cycles, n_steps) == ((0, 0) if no_mix else (cycles, steps))
-        outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], [r.cpu().numpy() for r in res.rec_x]))
-        eng.close()
-    for a, c in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
-        assert np.array_equal(a, c)
-    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-6)
-    assert np.all(np.isfinite(outs[0][0]))
-
-
 def test_hebbian_ring_wraps_full_size():
     """B = 6000, Hebbian sums over 400 steps (pc_trainer.py:853-862: autograd adds dF/dtheta of every accumulating step).
     A ring of 192 slots (three parts of 64, overlapped flush; the default is 384 in parts of 128) wraps twice.  Checked against
@@ -324,32 +217,6 @@ def test_hebbian_ring_wraps_full_size():
             off += n
 
 
-@pytest.mark.parametrize("mode", ["adam", "external_noise"])
-def test_mixed_schedule_with_per_step_tables(mode, monkeypatch):
-    """Adam's bias-correction table and injected noise are indexed by the step, which differs between the units of a mixed
-    launch: the MAP warm-up (Adam on x, no noise) and an SGD run with external normals must still be bitwise those of the
-    plain schedule."""
-    from montecarlopredictivecoding_amd import _lib as L
-    W, b, y, xs = _problem()
-    xs_small = [x * 0.1 for x in xs]
-    T = 200                                    # one short cycle ((3, 5) steps per segment: 175 steps) + 25 plain steps
-    kw = dict(noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.05)
-    if mode == "external_noise":
-        g = torch.Generator().manual_seed(3)
-        ext = [torch.randn(T, B, n, generator=g).to(DEV) for n in SIZES]
-        kw = dict(noise_mode=L.NOISE_EXTERNAL, ext_noise=ext, noise_var=2.0, lr=0.03)
-    outs = []
-    for no_mix in (False, True):
-        monkeypatch.setenv("MCPC_TUNING", MIXED_TUNING + (",no_mix=1" if no_mix else ""))
-        eng = _engine(B, W, b, y)
-        res, out = _run(eng, xs_small, T, **kw)
-        outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out]))
-        eng.close()
-    for a, c in zip(outs[0][1], outs[1][1]):
-        assert np.array_equal(a, c)
-    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-6)
-
-
 def test_lean_epilogues_and_bitpacked_targets_change_nothing():
     """The E waves' lean epilogues (32-bit lane offsets, uniform fast paths) and the bit-packed copy of a 0/1 target are
     different code for the same arithmetic: states, records, energies and Hebbian sums are BITWISE those of the generic
@@ -375,16 +242,16 @@ def test_lean_epilogues_and_bitpacked_targets_change_nothing():
 
 def test_lean_adam_epilogue_matches_generic_epilogue():
     """The MAP warm-up (Adam on x, no noise) takes the lean x update, which requests the moments in front of the wait for the
-    partner's block: states, energies and the moments themselves are bitwise those of the generic epilogue, on the mixed
-    schedule (200 steps = one short cycle + 25 plain steps) and on the plain one."""
+    partner's block: states, energies and the moments themselves are bitwise those of the generic epilogue, on the round schedule
+    (6000 chains) and on a single launch (4000 chains)."""
     from montecarlopredictivecoding_amd import _lib as L
-    W, b, y, xs = _problem()
-    xs_small = [x * 0.1 for x in xs]
-    for base in ("", "no_mix=1,"):
+    for batch in (B, 4000):
+        W, b, y, xs = _problem(batch)
+        xs_small = [x * 0.1 for x in xs]
         outs = []
-        for tuning in (base.rstrip(",") or None, base + "no_lean=1"):
-            eng = _engine(B, W, b, y, tuning=tuning)
-            res, out = _run(eng, xs_small, 200 if not base else 40, noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.05)
+        for tuning in (None, "no_lean=1"):
+            eng = _engine(batch, W, b, y, tuning=tuning)
+            res, out = _run(eng, xs_small, 40, noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.05)
             m = [torch.empty_like(x) for x in xs]; v = [torch.empty_like(x) for x in xs]
             eng.store_adam_state(m, v)
             eng.sync_check()
@@ -422,13 +289,14 @@ def test_pc_path_is_bitwise_reproducible_and_descends():
 
 
 def test_workgroup_variants_agree():
-    """16-chain / 32-chain workgroups and the wave-specialised kernel (tuning keys ct, nw, ws = 2: in-place wave-specialised, 32 or 16 chains) are different
-    schedules of the same arithmetic."""
+    """The in-place wave-specialised kernel (the default) and the barrier kernel (tuning ws=0: four waves per workgroup, generic
+    epilogues, two workgroups per CU -- the fallback, and the form bench.py's self_check replays the headline call on) are different
+    programs for the same arithmetic: states bitwise equal, energies up to the grouping of the partial sums."""
     W, b, y, xs = _problem(640)
     outs = []
-    for ct, nw, ws in (("16", "4", "0"), ("32", "8", "0"), ("32", "4", "0"), ("32", "8", "2"), ("16", "8", "2")):
-        eng = _engine(640, W, b, y, tuning=f"ct={ct},nw={nw},ws={ws}")
-        assert eng.query()["chains_per_wg"] == int(ct)
+    for tuning, name in ((None, "ws2"), ("ws=0", "mcpc_steps_kernel<1, 4>"), ("ws=2,no_xl=1", "ws2"), ("ws=2,no_lean=1", "ws2")):
+        eng = _engine(640, W, b, y, tuning=tuning)
+        assert eng.query()["chains_per_wg"] == 16 and name in eng.query()["step_kernel"]
         res, out = _run(eng, xs, 15, acc_begin=3, acc_end=15)
         outs.append((res.energies.cpu().numpy(), [o.cpu().numpy() for o in out], eng.read_param_grads_flat().cpu().numpy()))
         eng.close()
@@ -484,17 +352,14 @@ def test_oversized_networks_are_rejected_not_miscomputed():
         Engine([4] * 7, [0] * 7, 4, 0, 8, device=DEV)
 
 
-def test_shards_of_several_rounds_keep_sixteen_chain_workgroups():
-    """Default plans use 16-chain workgroups whatever the shard size (shards of more units than CUs run the round schedule,
-    tests/test_gpu_rounds.py); `rr=0` restores the older choice between the forms by their hardware rounds -- 9000 chains: 3 rounds
-    of 16-chain workgroups against 2 of 32-chain ones, the former 1.65x shorter each; 16 384 chains (4 against 2) 32-chain.  Per
-    chain all of them compute the same thing: states bitwise equal."""
-    from montecarlopredictivecoding_amd import _lib as L
+def test_shards_of_several_rounds_agree_across_schedules():
+    """Shards of more 16-chain units than CUs run the round schedule (tests/test_gpu_rounds.py); `rr=0` runs them as one launch in
+    hardware rounds, `ws=0` on the barrier kernel.  Per chain all of them compute the same thing: states bitwise equal."""
     W, b, y, xs = _problem(9000)
     outs = []
-    for tuning, want in ((None, 16), ("rr=0", 16), ("ws=2,ct=32", 32)):
+    for tuning in (None, "rr=0", "ws=0"):
         eng = _engine(9000, W, b, y, tuning=tuning)
-        assert eng.query()["chains_per_wg"] == want
+        assert eng.query()["chains_per_wg"] == 16
         assert ("round schedule" in eng.query()["step_kernel"]) == (tuning is None)
         res, out = _run(eng, xs, 12, acc_begin=4, acc_end=12)
         outs.append(([o.cpu().numpy() for o in out], res.energies.cpu().numpy()))
@@ -503,17 +368,12 @@ def test_shards_of_several_rounds_keep_sixteen_chain_workgroups():
         for a, c in zip(outs[0][0], other[0]):
             assert np.array_equal(a, c)
         np.testing.assert_allclose(outs[0][1], other[1], rtol=2e-6)
-    from montecarlopredictivecoding_amd.engine import Engine
-    for tuning, want in ((None, 16), ("rr=0", 32)):
-        eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, 16384, device=DEV, tuning=tuning)
-        assert eng.query()["chains_per_wg"] == want
-        eng.close()
 
 
 def test_sixteen_chain_plans_with_and_without_the_shared_lds_region_agree():
-    """16-chain plans keep the ring of read-out error chunks and the prediction errors E_l apart in LDS when both fit and run the
-    forward entries between the read-out chunks (build_phases_ws2); `overlay16=1` forces the shared region and the order 32-chain plans
-    use.  Another schedule of the same arithmetic: states, records, energies and Hebbian sums bitwise equal -- on cfg-M's net and on
+    """Plans keep the ring of read-out error chunks and the prediction errors E_l apart in LDS when both fit and run the
+    forward entries between the read-out chunks (build_phases_ws2); `overlay16=1` forces the shared region and its order (what a
+    plan that does not fit apart falls back to).  Another schedule of the same arithmetic: states, records, energies and Hebbian sums bitwise equal -- on cfg-M's net and on
     mcpc_ml's (20-128-128-784), SGD + kick and Adam."""
     from montecarlopredictivecoding_amd import _lib as L
     from montecarlopredictivecoding_amd.engine import Engine

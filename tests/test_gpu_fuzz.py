@@ -1,7 +1,7 @@
 """Seeded sweep of random network shapes and run modes against the NumPy oracle: ragged widths (not multiples of 16), 1-5
 latent layers, batches that are not multiples of the chain tile, every activation / loss / x optimizer / noise mode, non-zero
 pseudo-inputs, bias-free Linears, masked losses, ragged accumulation windows -- on the kernel form the engine picks by default
-(in-place, 16 chains per workgroup), on the 32-chain in-place form large shards get, and on the barrier kernel.  Complements the golden fixtures (fixed shapes, pinned by the reference itself)."""
+(in-place, wave-specialised) and on the barrier kernel.  Complements the golden fixtures (fixed shapes, pinned by the reference itself)."""
 import numpy as np
 import pytest
 import torch
@@ -33,7 +33,7 @@ def _random_case(i):
     return case, mode
 
 
-@pytest.mark.parametrize("kernel", ["default", "inplace32", "barrier"])
+@pytest.mark.parametrize("kernel", ["default", "barrier"])
 @pytest.mark.parametrize("i", range(N_CASES))
 def test_random_shape_matches_oracle(i, kernel):
     from montecarlopredictivecoding_amd import _lib as L
@@ -59,7 +59,7 @@ def test_random_shape_matches_oracle(i, kernel):
     ref = mo.run(net, inputs, X0, lspec, xopt, T, noise=noise, noise_var=1.5, accumulate_p_at=list(range(mode["acc_begin"], T)))
 
     eng = Engine(sizes, [act_l] * len(sizes), case["n_in"], n_out, B, device=DEV, ecoef=case["ecoef"],
-                 tuning={"barrier": "ws=0", "inplace32": "ws=2", "default": None}[kernel])
+                 tuning={"barrier": "ws=0", "default": None}[kernel])
     eng.bind_params([torch.from_numpy(w).to(DEV) for w in W], [None if x is None else torch.from_numpy(x).to(DEV) for x in b])
     eng.bind_inputs(None if case["inputs_zero"] else torch.from_numpy(inputs).to(DEV))
     if target is not None:
@@ -87,8 +87,8 @@ def test_random_shape_matches_oracle(i, kernel):
 @pytest.mark.parametrize("sizes,n_out", [([40, 384, 200], 784), ([64, 512, 256], 300), ([100, 600, 96], 64), ([256, 256, 256, 256], 1000),
                                          ([16, 500], 0)])
 def test_wide_networks_against_oracle(sizes, n_out):
-    """Widths near the limits of the LDS plans: the 32-chain in-place plan stops fitting, the engine falls back to
-    its 16-chain forms; results must not depend on which form ran."""
+    """Widths near the limits of the LDS plans: the in-place plan loses its LDS-resident epilogue operands, then
+    stops fitting and the engine falls back to the barrier kernel; results must not depend on which form ran."""
     from montecarlopredictivecoding_amd import _lib as L
     from montecarlopredictivecoding_amd.engine import Engine
     B, T, lr, seed = 40, 5, 0.02, 9
@@ -100,7 +100,7 @@ def test_wide_networks_against_oracle(sizes, n_out):
     ref = mo.run(net, inputs, X0, lspec, mo.XOpt(mo.OPT_SGD, lr), T, noise=lambda t, l: philox.layer_normals(seed, t, l, 0, B, sizes[l]),
                  accumulate_p_at=list(range(1, T)))
     seen = set()
-    for tuning in (None, "ws=2", "ws=0"):
+    for tuning in (None, "ws=0"):
         eng = Engine(sizes, [L.ACT_RELU] * len(sizes), sizes[0], n_out, B, device=DEV, tuning=tuning)
         q = eng.query()
         seen.add((q["step_kernel"], q["chains_per_wg"]))
@@ -122,7 +122,7 @@ def test_wide_networks_against_oracle(sizes, n_out):
         want = np.concatenate([np.concatenate([gw.reshape(-1), gb.reshape(-1)]) for gw, gb in zip(ref.gW, ref.gb)])
         np.testing.assert_allclose(flat, want, rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(want).max())), err_msg=f"tuning {tuning}")
         eng.close()
-    assert len(seen) >= 2
+    assert len(seen) >= 1
 
 
 @pytest.mark.parametrize("seed", range(6))

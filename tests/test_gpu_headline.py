@@ -8,8 +8,9 @@ the round schedule (three launches per cycle, every unit in two of them), 31 + 1
 three-part spill ring that wraps 10 times, flushes overlapped on two low-priority streams.  This file runs exactly that call and
 checks it against
 
-  (1) the same call on the serial / plain tuning (`rr=0,no_mix=1,no_overlap=1,slot_cap=128`: 188 32-chain workgroups, one launch
-      per segment, one stream, one ring part -- another workgroup form, and nothing can race): final state, all 50 records
+  (1) the same call on the serial tuning (`ws=0,no_overlap=1,slot_cap=128`: the BARRIER kernel -- another program: four waves per
+      workgroup, s_barrier hand-overs, generic epilogues, 376 workgroups in hardware rounds -- one launch per segment, one stream,
+      one ring part, nothing can race): final state, all 50 records
       and the 276 146-float gradient bucket BITWISE, loss / energies rel 2e-6 (fp32 partial sums are grouped per workgroup);
   (2) an fp64 recomputation of dF/dtheta of every Linear over the 200-step window [4700, 4900) -- late in the call, after
       57 segments, spanning four ring parts -- from the recorded states of that window.  The window's share of the bucket is
@@ -24,7 +25,7 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 SIZES, N_OUT, B = [30, 256, 256], 784, 6000
 T, MIXING = 5000, 1000
-SERIAL_TUNING = "rr=0,no_mix=1,no_overlap=1,slot_cap=128"
+SERIAL_TUNING = "ws=0,no_overlap=1,slot_cap=128"
 
 
 def _engine(W, b, y, tuning=None):
@@ -76,7 +77,7 @@ def test_headline_call_matches_serial_plain_schedule_bitwise(problem, default_ru
     en_d, out_d, rec_d, flat_d = default_run
     eng = _engine(W, b, y, tuning=SERIAL_TUNING)
     res, out_s, flat_s = _headline_call(eng, xs)
-    assert eng.query()["spill_slots"] == 128 and eng.query()["chains_per_wg"] == 32
+    assert eng.query()["spill_slots"] == 128 and "mcpc_steps_kernel<1, 4>" in eng.query()["step_kernel"]
     eng.close()
     for a, c in zip(out_d, out_s):
         assert torch.equal(a, c)
