@@ -991,7 +991,7 @@ int launch_heb6(const HebArgs& a, hipStream_t stream) {
 // Allocated by the first run that accumulates Hebbian sums (inference-only engines never pay for it): the spill ring, the
 // slabs of the split-K partial sums (sized for a flush of half the ring), the low-priority stream and events of the
 // overlapped flush.
-int ensure_spill(mcpc_engine* e) {
+int ensure_spill(mcpc_engine* e, hipStream_t stream) {
     if (e->spill_ready) return 0;
     int rc;
     if (e->half_slots < e->slots && !e->aux) {
@@ -1020,11 +1020,13 @@ int ensure_spill(mcpc_engine* e) {
         if (l >= 1 && !e->spill_e[l] && (rc = dmalloc(e->spill_e[l], n))) return rc;
     }
     if (e->has_head && !e->spill_eo && (rc = dmalloc(e->spill_eo, (size_t)e->slots * e->Bpad * e->out_pad))) return rc;
-    // rows of a 16-chain unit that is all padding (never launched) read as zero in every slot: the Hebbian GEMMs sum over all Bpad rows
+    // rows of a 16-chain unit that is all padding (never launched) read as zero in every slot: the Hebbian GEMMs sum over all Bpad rows.
+    // On the RUN's stream: the step kernels and (behind ev_steps) the flushes of this and every later run are ordered after it, also when
+    // the caller's stream is a non-blocking one that the null stream does not synchronise with.
     if (e->nwg_live * e->ct < e->Bpad && e->ws == 2) {
         const size_t live = (size_t)e->nwg_live * 16, dead = (size_t)e->Bpad - live;
         auto zero_tail = [&](float* base, int npad) {
-            return hipMemset2D(base + live * npad, (size_t)e->Bpad * npad * sizeof(float), 0, dead * npad * sizeof(float), (size_t)e->slots) == hipSuccess;
+            return hipMemset2DAsync(base + live * npad, (size_t)e->Bpad * npad * sizeof(float), 0, dead * npad * sizeof(float), (size_t)e->slots, stream) == hipSuccess;
         };
         bool ok = true;
         for (int l = 0; l < e->L; ++l) { ok = ok && zero_tail(e->spill_a[l], e->npad[l]); if (l >= 1) ok = ok && zero_tail(e->spill_e[l], e->npad[l]); }
@@ -1229,7 +1231,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
                            e->d.batch, e->d.n_in, e->d.sizes[0], e->Bpad, e->npad[0]);
     }
     const bool run_accumulates = acc_b < acc_e && r->t_begin < acc_e && r->t_begin + r->n_steps > acc_b;
-    if (run_accumulates) { const int rc = ensure_spill(e); if (rc) return rc; }
+    if (run_accumulates) { const int rc = ensure_spill(e, stream); if (rc) return rc; }
     if (r->acc_reset && run_accumulates) {
         for (int j = 0; j < nlin; ++j) {
             HIP_TRY(hipMemsetAsync(e->lin[j].G, 0, (size_t)e->lin[j].out_pad * e->lin[j].g_ld * 4, stream));

@@ -225,9 +225,12 @@ class Engine:
     def param_count(self) -> int:
         return int(self._lib.mcpc_param_count(self._h))
 
-    def read_param_grads_flat(self, scale=1.0) -> torch.Tensor:
-        flat = torch.empty(self.param_count(), dtype=torch.float32, device=self.device)
-        L.check(self._lib.mcpc_read_param_grads_flat(self._h, _ptr(flat), flat.numel(), scale, self._stream()))
+    def read_param_grads_flat(self, scale=1.0, tail=0) -> torch.Tensor:
+        """The flat gradient bucket (W0, b0, W1, b1, ...) scaled by `scale`; `tail` extra floats behind it (uninitialised: the caller's
+        own words that travel with the bucket through its one all-reduce)."""
+        n = self.param_count()
+        flat = torch.empty(n + tail, dtype=torch.float32, device=self.device)
+        L.check(self._lib.mcpc_read_param_grads_flat(self._h, _ptr(flat), n, scale, self._stream()))
         return flat
 
     # ---- the library's own collective (hosts that are not on torch.distributed; include/mcpc.h "multi-GPU") ------

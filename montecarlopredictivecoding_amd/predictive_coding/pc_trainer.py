@@ -7,7 +7,7 @@ API parity target: /root/reference/predictive_coding/pc_trainer.py:22-1108 -- co
 
 How a call is executed
 ----------------------
-``train_on_batch`` first *recognises* the call (``recognise.py``).  Three outcomes:
+``train_on_batch`` first *recognises* the call (``recognise.py``).  Three outcomes on the engine, one beside it:
 
 fused     the whole T-step loop runs inside ``mcpc_run`` (libmcpc.so): network
           Sequential[Linear, PCLayer, act, ...], quadratic energies, Gaussian / Bernoulli / masked /
@@ -19,9 +19,12 @@ stepwise  same network/loss, but arbitrary callbacks, ``update_p_at='all'``, cus
           (any torch optimizer), dynamic x-lr ...: per step the HIP kernel produces dF/dx and
           dF/dtheta (``update_x=0``), the reference's control flow around them is replayed with the
           user's torch optimizers and callbacks.  A RuntimeWarning names the reason.
-rejected  anything the kernels do not express (S/M masks, non-quadratic ``energy_fn``, ``loss_x_fn``,
-          optimised inputs, non-Sequential models ...) raises ``NotImplementedError`` naming the
-          reason.  There is no silent torch or CPU execution of the loop.
+generic   anything the kernels do not express (S/M masks, non-quadratic ``energy_fn``, per-datapoint energies,
+          ``loss_x_fn``, optimised / unwrapped inputs, ``backward_kwargs``, an ``early_stop_condition``, models
+          that are not the Sequential chain ...: SURVEY section 8b, "must work, need not be fast") runs on the
+          package's own torch-autograd restatement of the reference's step (``generic_loop.py``) and says so with
+          a RuntimeWarning naming the reason -- never silently, and never for a call the engine can run.
+rejected  a model on the CPU (there is no CPU path: ``MCPCLibraryError``) and ``plot_progress`` (out of scope).
 """
 import collections
 import os
@@ -37,6 +40,7 @@ from .. import _lib as L
 from .. import dist
 from ..engine import Engine
 from . import recognise
+from .generic_loop import run_generic
 from .pc_layer import PCLayer
 
 
@@ -67,6 +71,10 @@ def slow_down_warning(base, prop, solution):
 
 class PCTrainer(object):
     """Trainer for predictive-coding networks built from :class:`PCLayer`."""
+
+    # tests/test_generic_loop.py sets this on an instance to check generic_loop.py against the reference's fixtures in the CPU suite;
+    # nothing else does: a model on the CPU raises (there is no CPU path)
+    _test_only_generic_on_cpu = False
 
     def __init__(
         self,
@@ -156,8 +164,9 @@ class PCTrainer(object):
         self.mcpc_process_group = None        # torch.distributed group for the Hebbian all-reduce (or None)
         self.mcpc_world_batch = None          # global batch for the 1/(n*B) normalisation when sharded
         self.mcpc_sharded = False
+        self.mcpc_reduce_results = False      # set_shard(reduce_results=True): results are those of the whole batch
         self.mcpc_materialize_unused_grads = False   # reference quirk: autograd fills .grad even if never used
-        self.last_call_mode = None            # 'fused' | 'stepwise' (for tests / diagnostics)
+        self.last_call_mode = None            # 'fused' | 'stepwise' | 'generic' (for tests / diagnostics)
         # trajectories larger than this (bytes of host-bound records per call) are recorded slice by slice into a
         # two-buffer device ring that is drained to pinned host memory while the next slice runs (figure_5 pulls
         # 10 000 steps x all latents to the host, pc_trainer.py:440-445,772-774)
@@ -279,16 +288,25 @@ class PCTrainer(object):
         else:
             self._optimizer_p = self._manual_optimizer_p_fn()
 
+    def reset_plot_progress(self):
+        """API parity (reference pc_trainer.py:489-498): the plotting tallies; plotting itself is out of scope (plot_progress_at=[])."""
+        self._h = 0
+        self._plot_progress = {"key": [], "h": [], "t": [], "value": []}
+
     # ---- distributed sharding (no counterpart in the reference: it is single-device) -------------------
-    def set_shard(self, process_group=None, chain_base: int = 0, world_batch: typing.Optional[int] = None):
+    def set_shard(self, process_group=None, chain_base: int = 0, world_batch: typing.Optional[int] = None,
+                  reduce_results: bool = False):
         """Declare that this trainer holds one shard of a larger batch of chains.
 
         ``chain_base``  global index of the first local chain (keeps Philox noise independent of the sharding),
         ``world_batch`` total number of chains over all shards (the reference divides grads by ``len(inputs)``); ``None``:
-                        every learning call sums the local batches over the group (one int64 all-reduce -- a collective, so it
-                        is issued by every rank on every learning call and never cached on a rank-local value: shards may be
-                        uneven and the last batch of a data loader ragged),
-        ``process_group`` the group whose members' Hebbian sums are all-reduced once per learning call.
+                        the local batch travels with the gradient bucket as one extra float of its all-reduce (fused calls: no
+                        further collective and no host synchronisation; never cached on a rank-local value -- shards may be uneven
+                        and the last batch of a data loader ragged),
+        ``process_group`` the group whose members' Hebbian sums are all-reduced once per learning call,
+        ``reduce_results`` True: ``results["loss" / "energy" / "overall"]`` are those of the WHOLE batch, as in the reference
+                        (pc_layer.py:295 sums the energy over the batch; pc_trainer.py:785-797): one more all-reduce per call, of the
+                        [T, L + 2] fp64 table.  False (default): every rank gets its shard's partial sums.
         """
         self.mcpc_process_group = process_group
         self.mcpc_chain_base = int(chain_base)
@@ -296,6 +314,7 @@ class PCTrainer(object):
             raise ValueError("world_batch must be positive")
         self.mcpc_world_batch = None if world_batch is None else int(world_batch)
         self.mcpc_sharded = True
+        self.mcpc_reduce_results = bool(reduce_results)
 
     def _global_batch(self, local_batch: int) -> int:
         """Batch the reference divides by (``len(inputs)``, pc_trainer.py:905): the local one for an unsharded trainer,
@@ -369,7 +388,26 @@ class PCTrainer(object):
                                          callback_after_backward, callback_after_t, callback_after_t_kwargs,
                                          backward_kwargs, is_clear_energy_after_use, is_return_batchelement_loss)
         if plan is None:
-            raise NotImplementedError("this call cannot be executed by the MCPC HIP engine: " + why_not_fused)
+            # outside what the kernels express: the package's generic torch loop (generic_loop.py), loudly.  Not on the CPU: the
+            # engine has no CPU path and the generic loop is not a way around that.
+            dev = next((p.device for p in self._model.parameters()), None)
+            if (dev is None or dev.type != "cuda") and not self._test_only_generic_on_cpu:
+                raise L.MCPCLibraryError(
+                    "the model lives on %s: the MCPC engine runs on an MI355X only (move the model and inputs to 'cuda'); "
+                    "there is no CPU path" % dev)
+            self.last_call_mode = "generic"
+            return run_generic(
+                self, why_not_fused, inputs=inputs, loss_fn=loss_fn, loss_fn_kwargs=loss_fn_kwargs,
+                is_sample_x_at_batch_start=is_sample_x_at_batch_start,
+                is_reset_optimizer_x_at_batch_start=is_reset_optimizer_x_at_batch_start,
+                is_reset_optimizer_p_at_batch_start=is_reset_optimizer_p_at_batch_start, is_unwrap_inputs=is_unwrap_inputs,
+                is_optimize_inputs=is_optimize_inputs, callback_after_backward=callback_after_backward,
+                callback_after_backward_kwargs=callback_after_backward_kwargs, callback_after_t=callback_after_t,
+                callback_after_t_kwargs=callback_after_t_kwargs, is_return_results_every_t=is_return_results_every_t,
+                is_checking_after_callback_after_t=is_checking_after_callback_after_t, backward_kwargs=backward_kwargs,
+                is_clear_energy_after_use=is_clear_energy_after_use, is_return_outputs=is_return_outputs,
+                is_return_representations=is_return_representations, is_return_xs=is_return_xs,
+                is_return_batchelement_loss=is_return_batchelement_loss)
         common = dict(inputs=inputs, loss_fn=loss_fn, is_sample_x_at_batch_start=is_sample_x_at_batch_start,
                       is_reset_optimizer_x_at_batch_start=is_reset_optimizer_x_at_batch_start,
                       is_reset_optimizer_p_at_batch_start=is_reset_optimizer_p_at_batch_start,
@@ -400,20 +438,25 @@ class PCTrainer(object):
     def _plan(self, inputs, loss_fn, loss_fn_kwargs, is_unwrap_inputs, is_optimize_inputs, callback_after_backward,
               callback_after_t, callback_after_t_kwargs, backward_kwargs, is_clear_energy_after_use,
               is_return_batchelement_loss):
-        """Returns (plan dict, "") or (None, reason).  plan['mode'] is 'fused' or 'stepwise'."""
+        """Returns (plan dict, "") or (None, reason: the call runs on the generic loop).  plan['mode'] is 'fused' or 'stepwise'."""
         net, why = recognise.describe_model(self._model)
         if net is None:
             return None, why
         if is_unwrap_inputs or is_optimize_inputs:
-            return None, "is_unwrap_inputs / is_optimize_inputs are not supported"
+            return None, "is_unwrap_inputs / is_optimize_inputs"
         if self._loss_x_fn is not None or self._loss_inputs_fn is not None:
-            return None, "loss_x_fn / loss_inputs_fn are not supported"
-        if self._energy_coefficient != 1.0:
-            return None, "energy_coefficient != 1 is not supported"
+            return None, "loss_x_fn / loss_inputs_fn"
+        if not self._energy_coefficient > 0.0:
+            return None, "energy_coefficient <= 0"
         if self._early_stop_condition.strip() != "False":
-            return None, "early_stop_condition other than 'False' is not supported"
+            return None, "an early_stop_condition other than 'False'"
         if backward_kwargs or is_clear_energy_after_use or is_return_batchelement_loss:
-            return None, "backward_kwargs / is_clear_energy_after_use / is_return_batchelement_loss are not supported"
+            return None, "backward_kwargs / is_clear_energy_after_use / is_return_batchelement_loss"
+        if self._energy_coefficient != 1.0:
+            # overall = loss + energy * c (pc_trainer.py:821-836): every layer's c_l scaled by c -- errors, x gradients and Hebbian
+            # sums follow -- and the energy the results report divided by c again (_collect_results)
+            import dataclasses
+            net = dataclasses.replace(net, ecoef=[float(np.float32(c_l) * np.float32(self._energy_coefficient)) for c_l in net.ecoef])
         if not isinstance(inputs, torch.Tensor) or inputs.dim() != 2 or inputs.shape[1] != net.n_in:
             return None, f"inputs must be a [batch, {net.n_in}] tensor"
         if inputs.dtype != torch.float32:
@@ -537,13 +580,15 @@ class PCTrainer(object):
         net = plan["net"]
         results = {"loss": [], "energy": [], "overall": []}
         self._engine_for(plan).sync_check()        # the one host sync of the call (also surfaces device-side faults)
+        if self.mcpc_sharded and self.mcpc_reduce_results:
+            dist.allreduce_flat(res.energies, self.mcpc_process_group)      # [T or 1, L + 2] fp64: loss, E_l, overall of the whole batch
         en = res.energies.cpu().numpy()
         rows = range(T) if is_return_results_every_t else [0]
         nl = len(net.sizes)
         for r in rows:
             if loss_fn is not None:
                 results["loss"].append(float(en[r, 0]))
-            results["energy"].append(float(en[r, 1:1 + nl].sum()))
+            results["energy"].append(float(en[r, 1:1 + nl].sum()) / self._energy_coefficient)
             results["overall"].append(float(en[r, -1]))
         n_rec = T if is_return_results_every_t else 1
         if is_return_outputs:
@@ -563,10 +608,17 @@ class PCTrainer(object):
 
     def _apply_p_step(self, plan, eng, net, n_acc):
         """Normalise (pc_trainer.py:905-913), all-reduce across shards, hand to the user's optimizer_p."""
-        B_global = self._global_batch(plan["B"])
-        flat = eng.read_param_grads_flat(scale=dist.grad_scale(n_acc, B_global))
-        if self.mcpc_sharded:
-            dist.allreduce_flat(flat, self.mcpc_process_group)     # RCCL: one bucket per call
+        if self.mcpc_sharded and self.mcpc_world_batch is None:
+            # the job-wide batch is not known on this rank: the local one rides in the bucket's last float through the ONE all-reduce,
+            # and the division by the group's sum happens on the device afterwards (no second collective, no host sync; ADVICE r3)
+            flat = eng.read_param_grads_flat(scale=dist.grad_scale(n_acc, 1), tail=1)
+            flat[-1] = float(plan["B"])
+            dist.allreduce_flat(flat, self.mcpc_process_group)
+            flat = flat[:-1] / flat[-1]
+        else:
+            flat = eng.read_param_grads_flat(scale=dist.grad_scale(n_acc, self._global_batch(plan["B"])))
+            if self.mcpc_sharded:
+                dist.allreduce_flat(flat, self.mcpc_process_group)     # RCCL: one bucket per call
         dist.assign_flat_grads(net.linears, flat)
         self._optimizer_p.step()
 
@@ -726,6 +778,8 @@ class PCTrainer(object):
                           energy_mode=L.ENERGY_ALL, energies_out=energies,
                           rec_begin=t, rec_stride=1, rec_count=1 if (keep and is_return_outputs and net.n_out > 0) else 0,
                           rec_x=False, rec_out=True)
+            if self.mcpc_sharded and self.mcpc_reduce_results:
+                dist.allreduce_flat(energies[t], self.mcpc_process_group)         # the whole batch's loss / energies of this step
             if keep:
                 if is_return_outputs:
                     results["outputs"].append(res.rec_out[0] if net.n_out > 0 else xs[-1].detach().clone())
@@ -736,7 +790,7 @@ class PCTrainer(object):
                 row = energies[t].cpu().numpy()
                 if loss_fn is not None:
                     results["loss"].append(float(row[0]))
-                results["energy"].append(float(row[1:1 + nl].sum()))
+                results["energy"].append(float(row[1:1 + nl].sum()) / self._energy_coefficient)
                 results["overall"].append(float(row[-1]))
             if dynamic_lr:
                 overalls.append(float(energies[t, -1]))

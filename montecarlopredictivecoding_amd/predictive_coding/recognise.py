@@ -200,8 +200,11 @@ def describe_x_optimizer(fn, kwargs) -> typing.Tuple[typing.Optional[XOptDescrip
 def describe_callback(callback, kwargs, trainer) -> typing.Tuple[typing.Optional[typing.Optional[float]], str]:
     """Returns (noise_var or None for 'no callback', "") if fusable, else (None, reason) with ok=False signalled by reason.
 
-    Fusable = the callback is a Langevin kick: this package's tagged ``random_step``, or ANY callable that behaves like the
-    reference's ``random_step`` (utils/model.py:35-44) when probed -- e.g. the user's own unmodified copy of those ten lines."""
+    Fusable = the callback is a Langevin kick: this package's tagged ``random_step``, or a plain Python function whose CODE can be
+    nothing but the reference's ``random_step`` (utils/model.py:35-44: straight-line code over ``get_model_xs()`` /
+    ``get_optimizer_x()`` / ``x.grad.normal_`` / ``optimizer.step()``, no branch, no use of ``t``, no closure, no other name --
+    ``_static_langevin_check``) AND which behaves like it when probed -- e.g. the user's own unmodified copy of those ten lines.
+    Anything else (a kick that also logs, counts, clamps, skips steps ...) keeps the step-wise path, where it is really called."""
     if callback is None:
         return None, ""
     tag = getattr(callback, "_mcpc", None)
@@ -215,7 +218,59 @@ def describe_callback(callback, kwargs, trainer) -> typing.Tuple[typing.Optional
         if var < 0:
             return None, "negative noise variance"
         return var, ""
-    return _probe_langevin_callback(callback, kwargs, trainer)
+    why = _static_langevin_check(callback)
+    if why:
+        return None, f"callback_after_t is not provably a plain Langevin kick ({why})"
+    verdict = _probe_langevin_callback(callback, kwargs, trainer)
+    if verdict[0] is not None and callback not in _FUSED_ANNOUNCED:
+        import warnings
+        _FUSED_ANNOUNCED.add(callback)
+        warnings.warn(f"callback_after_t {getattr(callback, '__qualname__', callback)!r} (defined in "
+                      f"{getattr(callback, '__module__', '?')}) is the Langevin kick random_step (noise_var = {verdict[0]:g}): it is fused into the "
+                      "HIP x update (Philox noise) and NOT invoked per step", RuntimeWarning, stacklevel=4)
+    return verdict
+
+
+_FUSED_ANNOUNCED = set()
+
+# What the code of an untagged callback may mention if it is to be fused without ever being called again: the reference's random_step
+# (utils/model.py:35-44) uses get_model_xs, get_optimizer_x, grad, normal_, np.sqrt, defaults and step -- nothing else.
+_KICK_ATTRS = frozenset({"get_model_xs", "get_optimizer_x", "get_optimizer_x_lr", "grad", "normal_", "sqrt", "defaults", "param_groups",
+                         "step", "zero_grad"})
+_KICK_MODULES = frozenset({"numpy", "math", "torch"})
+_KICK_FORBIDDEN_OPS = ("STORE_GLOBAL", "STORE_ATTR", "STORE_SUBSCR", "DELETE_", "IMPORT_", "MAKE_FUNCTION", "LOAD_CLOSURE", "LOAD_DEREF",
+                       "STORE_DEREF", "LOAD_CLASSDEREF", "YIELD", "RAISE", "COMPARE_OP", "CONTAINS_OP", "IS_OP", "POP_JUMP", "JUMP_IF",
+                       "SETUP_WITH", "BEFORE_WITH", "SETUP_FINALLY", "LOAD_BUILD_CLASS", "LOAD_NAME", "STORE_NAME", "MATCH_")
+
+
+def _static_langevin_check(callback) -> str:
+    """"" if the function's bytecode can only be a plain Langevin kick, else the reason.  A static guarantee, so that fusing the
+    callable (never calling it again) cannot drop anything it would have done: a plain function without closure whose code is free
+    of conditional branches and comparisons (nothing can depend on t or on a counter), never reads its first parameter (t), loads
+    no global but the numpy / math / torch modules, and touches no attribute outside the handful random_step needs."""
+    import dis
+    import types
+    if not isinstance(callback, types.FunctionType):
+        return "not a plain Python function"
+    if callback.__closure__:
+        return "it closes over variables"
+    code = callback.__code__
+    if code.co_argcount + code.co_kwonlyargcount < 1 or code.co_flags & 0x0C:       # *args / **kwargs
+        return "its signature is not (t, _pc_trainer, ...)"
+    t_name = code.co_varnames[0]
+    for ins in dis.get_instructions(code):
+        op = ins.opname
+        if any(op.startswith(f) for f in _KICK_FORBIDDEN_OPS):
+            return f"its code contains {op} (a branch, comparison, store or import)"
+        if op in ("LOAD_FAST", "LOAD_FAST_CHECK") and ins.argval == t_name:
+            return f"it reads its step argument {t_name!r}"
+        if op == "LOAD_GLOBAL":
+            mod = callback.__globals__.get(ins.argval)
+            if not isinstance(mod, types.ModuleType) or mod.__name__.split(".")[0] not in _KICK_MODULES:
+                return f"it uses the global {ins.argval!r}"
+        if op in ("LOAD_ATTR", "LOAD_METHOD") and ins.argval not in _KICK_ATTRS:
+            return f"it touches .{ins.argval}"
+    return ""
 
 
 # ---- behavioural recognition of a Langevin callback -------------------------------------------------------------------------
@@ -293,7 +348,8 @@ def _probe_key(callback, kwargs, trainer, lr, T):
 
 def _probe_langevin_callback(callback, kwargs, trainer):
     """Run ``callback(t, **kwargs)`` on a scratch trainer (the kwarg that IS the trainer is replaced by a stub whose latent
-    tensors are CPU probes) at t = 0, T // 2, T - 1 and accept it as a Langevin kick iff, every time, it
+    tensors are CPU probes) at t = 0, 1, T // 3, T // 2, T - 2, T - 1 (its code has already been shown not to read t:
+    _static_langevin_check) and accept it as a Langevin kick iff, every time, it
       * fills every ``x.grad`` with ``normal_(0, std)`` -- one common std, no private generator -- and leaves it at that
         (the gradients ``optimizer.step()`` sees have the moments of N(0, std^2): nothing rescaled them afterwards),
       * calls ``optimizer.step()`` exactly once, and touches neither the x values nor anything else of the trainer.
@@ -319,7 +375,7 @@ def _probe_langevin_callback(callback, kwargs, trainer):
     verdict = None
     try:
         stds = []
-        for t in sorted({0, T // 2, T - 1}):
+        for t in sorted({0, min(1, T - 1), T // 3, T // 2, max(T - 2, 0), T - 1}):
             g = torch.Generator().manual_seed(1234 + t)
             params, logs = [], []
             for shape in _PROBE_SHAPES:

@@ -37,8 +37,8 @@ def run_case(rank, world, process_group=None, world_batch=None, dev="cuda:0"):
         layer._sample_x_fn = lambda inp, _x=x: _x.clone()
     tr = get_mcpc_trainer(model, CFG, training=True)
     if world > 1:
-        tr.set_shard(process_group=process_group, chain_base=lo, world_batch=world_batch)
-    out = {"lo": lo, "hi": hi, "modes": [], "loss": [], "energy": []}
+        tr.set_shard(process_group=process_group, chain_base=lo, world_batch=world_batch, reduce_results=True)
+    out = {"lo": lo, "hi": hi, "modes": [], "loss": [], "energy": [], "overall": []}
     for call in range(2):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -50,6 +50,7 @@ def run_case(rank, world, process_group=None, world_batch=None, dev="cuda:0"):
         out["modes"].append(tr.last_call_mode)
         out["loss"].append(torch.tensor(res["loss"], dtype=torch.float64))
         out["energy"].append(torch.tensor(res["energy"], dtype=torch.float64))
+        out["overall"].append(torch.tensor(res["overall"], dtype=torch.float64))
         out[f"weights{call}"] = [p.detach().cpu().clone() for lin in model if isinstance(lin, torch.nn.Linear) for p in (lin.weight, lin.bias)]
         out[f"grads{call}"] = [lin.weight.grad.detach().cpu().clone() for lin in model if isinstance(lin, torch.nn.Linear)]
         out[f"xs{call}"] = [layer.get_x().detach().cpu().clone() for layer in layers]

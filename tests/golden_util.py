@@ -22,7 +22,8 @@ def fixture_names(prefix="", exclude=()):
     # format, consumed by tests/test_evaluators_golden.py and tests/test_gpu_widening.py / test_gpu_learning.py
     # g13_* (stationary statistics of the reference's own sampler, oracle/gen_golden_sampling.py) and g14_* (get_representations)
     # are consumed by tests/test_gpu_sampling.py and tests/test_sampling_fixtures.py
-    exclude = tuple(exclude) + ("g10_", "g11_", "g12_", "g13_", "g14_")
+    # g15_* (the keyword surface outside the kernels, oracle/gen_golden_generic.py) are consumed by tests/test_generic_loop.py
+    exclude = tuple(exclude) + ("g10_", "g11_", "g12_", "g13_", "g14_", "g15_")
     return [n for n in names if not any(n.startswith(x) for x in exclude)]
 
 

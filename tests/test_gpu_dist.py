@@ -57,13 +57,22 @@ def test_one_rank_rccl_group_matches_unsharded_run(world_batch):
                             device_id=torch.device(DEV))
     try:
         pt._PHILOX_STEPS[0] = base_steps                  # same Philox step counter as the unsharded run
-        shard_w, shard_g = _learning_call(True, world_batch)   # world_batch=None: derived by all-reducing the local batch
+        shard_w, shard_g = _learning_call(True, world_batch)   # world_batch=None: the local batch travels in the bucket
     finally:
         dist.destroy_process_group()
     for a, c in zip(plain_g, shard_g):
-        assert a.is_cuda and torch.equal(a, c)
+        assert a.is_cuda
+        if world_batch is not None:
+            assert torch.equal(a, c)
+        else:
+            # the local batch rides in the bucket's last float and the division by the group's sum follows the all-reduce:
+            # (G / n_acc) / B where the unsharded run multiplies by 1 / (n_acc B) -- one rounding apart
+            torch.testing.assert_close(a, c, rtol=3e-7, atol=0)
     for a, c in zip(plain_w, shard_w):
-        assert torch.equal(a, c)
+        if world_batch is not None:
+            assert torch.equal(a, c)
+        else:
+            torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-7)          # (one SGD step of lr 0.5 on those gradients)
     assert any(float(g.abs().max()) > 0 for g in plain_g)
 
 

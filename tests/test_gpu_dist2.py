@@ -7,7 +7,9 @@ PCTrainer.train_on_batch with `set_shard(process_group, chain_base=lo, world_bat
 The reference divides by len(inputs) = the WHOLE batch (pc_trainer.py:905-909), so B_global must be the group's sum.
   * weights after each call: bitwise equal on both ranks, and equal (1e-4 of the largest gradient entry: summation order) to the unsharded 6000-chain run;
   * trajectories: every rank's final state is BITWISE the unsharded run's rows [lo, hi) (global chain ids feed the Philox counter);
-  * per-step loss / energy: the ranks' partial sums add up to the unsharded values.
+  * per-step loss / energy / overall (`reduce_results=True`: one all-reduce of the [T, L + 2] fp64 table per call): both
+    ranks report the whole batch's values, equal to the unsharded run's;
+  * `world_batch=None`: the local batch rides in the gradient bucket's last float (no second collective, no host sync).
 """
 import os
 import socket
@@ -80,8 +82,10 @@ def test_two_ranks_on_one_gpu_through_the_facade(tmp_path):
                 # (a chain that crosses a ReLU kink a step earlier or later amplifies that: all but a handful of elements agree)
                 d = (cat - full[f"xs{call}"][l]).abs()
                 assert float((d > 5e-3).float().mean()) < 1e-3 and float(d.max()) < 1.0
-        for key in ("loss", "energy"):
-            total = r[0][key][call] + r[1][key][call]
-            torch.testing.assert_close(total, full[key][call], rtol=2e-6 if call == 0 else 1e-3, atol=0)
+        # set_shard(reduce_results=True): every rank reports the WHOLE batch's loss / energy / overall, as the reference does
+        # (pc_layer.py:295, pc_trainer.py:785-797) -- both ranks the same numbers, equal to the unsharded run's
+        for key in ("loss", "energy", "overall"):
+            assert torch.equal(r[0][key][call], r[1][key][call]), key
+            torch.testing.assert_close(r[0][key][call], full[key][call], rtol=2e-6 if call == 0 else 1e-3, atol=0)
     # the second call really started from other weights than the first
     assert not torch.equal(full["weights0"][2], full["weights1"][2])

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import philox
+from tests import parity_log
 from tests.golden_util import Golden, fixture_names
 
 pytestmark = pytest.mark.gpu
@@ -67,20 +68,30 @@ def run_call(eng, g, ci, call, acc_window=None, **kw):
     return res, (up, acc)
 
 
-def check_against_golden(g, ci, call, res, eng, xs_final, sched, x_atol=3e-4, e_rtol=3e-5):
+def check_against_golden(g, ci, call, res, eng, xs_final, sched, x_atol=None, e_rtol=None, group=None):
+    """Tolerances: BASELINE.md section 3's contract -- energies rel 1e-6, states 1e-5 absolute -- against the reference's own fp32
+    trajectories (50-100 steps).  Achieved on an MI355X (profiles/r04_parity_errors.txt): energies 2.1e-7 (SGD-x) / 6.6e-7 (Adam-x),
+    states 1.4e-6 / 1.9e-6, read-out 4.8e-6.  Adam-x energies are held to 3e-6: the kernel's x update uses v_rcp_f32 / v_sqrt_f32
+    (1 ulp each) where torch divides and takes an IEEE square root."""
+    adam = call["xopt"] == "adam"
+    if x_atol is None:
+        x_atol = 1e-5
+    if e_rtol is None:
+        e_rtol = 3e-6 if adam else 1e-6
+    group = group or ("fixtures, Adam-x" if adam else "fixtures, SGD-x")
     nc = g.case.get("rec_chains", None)
     L_ = len(g.case["sizes"])
     en = res.energies.cpu().numpy()
-    np.testing.assert_allclose(en[:, 1:1 + L_].sum(1), g.get(ci, "energy"), rtol=e_rtol, atol=1e-5)
-    np.testing.assert_allclose(en[:, 0], g.get(ci, "loss"), rtol=e_rtol, atol=1e-5)
-    np.testing.assert_allclose(en[:, -1], g.get(ci, "overall"), rtol=e_rtol, atol=1e-5)
+    parity_log.close(group, "energy[t]", en[:, 1:1 + L_].sum(1), g.get(ci, "energy"), rtol=e_rtol, atol=1e-6)
+    parity_log.close(group, "loss[t]", en[:, 0], g.get(ci, "loss"), rtol=e_rtol, atol=1e-6)
+    parity_log.close(group, "overall[t]", en[:, -1], g.get(ci, "overall"), rtol=e_rtol, atol=1e-6)
     for t in call.get("record_at", []):
         for l in range(L_):
-            np.testing.assert_allclose(res.rec_x[l][t].cpu().numpy()[:nc], g.get(ci, f"x_t{t}_l{l}"), rtol=0, atol=x_atol)
+            parity_log.close(group, "x[t] (records)", res.rec_x[l][t].cpu().numpy()[:nc], g.get(ci, f"x_t{t}_l{l}"), rtol=0, atol=x_atol)
         if g.case["n_out"]:
-            np.testing.assert_allclose(res.rec_out[t].cpu().numpy()[:nc], g.get(ci, f"out_t{t}"), rtol=0, atol=3 * x_atol)
+            parity_log.close(group, "outputs[t]", res.rec_out[t].cpu().numpy()[:nc], g.get(ci, f"out_t{t}"), rtol=0, atol=3 * x_atol)
     for l in range(L_):
-        np.testing.assert_allclose(xs_final[l].cpu().numpy()[:nc], g.get(ci, f"x_final_l{l}"), rtol=0, atol=x_atol)
+        parity_log.close(group, "x final", xs_final[l].cpu().numpy()[:nc], g.get(ci, f"x_final_l{l}"), rtol=0, atol=x_atol)
     # parameter gradients as the reference leaves them in .grad
     up, acc = sched
     B = g.case["B"]
@@ -95,15 +106,15 @@ def check_against_golden(g, ci, call, res, eng, xs_final, sched, x_atol=3e-4, e_
         dW, db = dW.cpu().numpy(), db.cpu().numpy()
         if g.has(ci, f"gW{j}"):
             ref = g.get(ci, f"gW{j}")
-            np.testing.assert_allclose(dW, ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()))
+            parity_log.close(group, "dF/dW", dW, ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()))
         if g.has(ci, f"gb{j}"):
             ref = g.get(ci, f"gb{j}")
-            np.testing.assert_allclose(db, ref, rtol=2e-4, atol=1e-4 * max(1.0, np.abs(ref).max()))
+            parity_log.close(group, "dF/db", db, ref, rtol=2e-4, atol=1e-4 * max(1.0, np.abs(ref).max()))
         if g.has(ci, f"gW{j}_idx"):
             idx, ref = g.get(ci, f"gW{j}_idx"), g.get(ci, f"gW{j}_val")
             scale_abs = g.get(ci, f"gW{j}_abs") / dW.size
-            np.testing.assert_allclose(dW.reshape(-1)[idx], ref, rtol=2e-3, atol=2e-3 * scale_abs)
-            np.testing.assert_allclose(np.abs(dW.astype(np.float64)).sum(), g.get(ci, f"gW{j}_abs"), rtol=2e-4)
+            parity_log.close(group, "dF/dW (sampled entries)", dW.reshape(-1)[idx], ref, rtol=2e-3, atol=2e-3 * scale_abs)
+            parity_log.close(group, "sum |dF/dW|", np.abs(dW.astype(np.float64)).sum(), g.get(ci, f"gW{j}_abs"), rtol=2e-4)
 
 
 @pytest.mark.parametrize("kernel", ["default", "barrier"])

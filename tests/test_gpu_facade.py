@@ -156,8 +156,9 @@ def _users_own_random_step(t, _pc_trainer, var=2.):
 
 
 def test_untagged_reference_random_step_is_fused_and_other_callbacks_warn():
-    """north_star: "figure_*.py scripts run unchanged".  The reference's own random_step is recognised by what it DOES
-    (recognise._probe_langevin_callback) and fused as Philox noise: the call is bitwise the one made with this package's tagged
+    """north_star: "figure_*.py scripts run unchanged".  The reference's own random_step is recognised by what its code CAN do
+    (recognise._static_langevin_check: straight-line code over the handful of names a Langevin kick needs) and by what it DOES
+    (recognise._probe_langevin_callback), and fused as Philox noise: the call is bitwise the one made with this package's tagged
     random_step.  A callback that is not a plain Langevin kick still runs (step-wise HIP path) -- and says so."""
     from montecarlopredictivecoding_amd.predictive_coding import pc_trainer as pt
     pc, um = _mods()
@@ -188,9 +189,11 @@ def test_untagged_reference_random_step_is_fused_and_other_callbacks_warn():
         slow = [w for w in caught if issubclass(w.category, RuntimeWarning) and "leaves the fused HIP loop" in str(w.message)]
         if key == "other":
             assert trainer.last_call_mode == "stepwise" and len(slow) == 1
-            assert "not the N(0, std) it drew" in str(slow[0].message)
+            assert "not provably a plain Langevin kick" in str(slow[0].message) and ".mul_" in str(slow[0].message)
         else:
             assert trainer.last_call_mode == "fused" and not slow
+            said = [w for w in caught if issubclass(w.category, RuntimeWarning) and "NOT invoked per step" in str(w.message)]
+            assert len(said) <= (1 if key == "own" else 0)      # an untagged callback that is fused is named, once per process
         finals[key] = [x.detach().clone() for x in trainer.get_model_xs()]
         overalls[key] = res["overall"]
     for a, c in zip(finals["tagged"], finals["own"]):

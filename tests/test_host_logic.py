@@ -155,13 +155,16 @@ def test_cpu_model_fails_loudly_not_silently():
 
 
 def test_unsupported_configurations_name_their_reason():
+    # what the kernels do not express goes to the generic torch loop -- on the GPU; a CPU model still fails loudly (no CPU path)
     m = nn.Sequential(nn.Linear(3, 3), pc.PCLayer(M=torch.ones(3)), nn.Linear(3, 2))
     m.train()
     tr = pc.PCTrainer(m, T=4, plot_progress_at=[])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        with pytest.raises(NotImplementedError, match="S/M masks"):
+        with pytest.raises(L.MCPCLibraryError, match="no CPU path"):
             tr.train_on_batch(inputs=torch.zeros(2, 3), is_log_progress=False)
+    plan, why = tr._plan(torch.zeros(2, 3), None, {}, False, False, None, None, {}, {}, False, False)
+    assert plan is None and "S/M masks" in why
     tr2 = pc.PCTrainer(um.get_model(CFG, False), T=4)          # plot_progress_at defaults to 'all'
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -199,7 +202,9 @@ def test_untagged_reference_random_step_is_recognised_by_behaviour():
     torch.manual_seed(11); np.random.seed(12)
     want = (torch.rand(4), np.random.rand(3))
     torch.manual_seed(11); np.random.seed(12)
-    assert recognise.describe_callback(_reference_random_step, {"_pc_trainer": tr}, tr) == (2.0, "")
+    recognise._FUSED_ANNOUNCED.discard(_reference_random_step)
+    with pytest.warns(RuntimeWarning, match="_reference_random_step.*fused.*NOT invoked per step"):      # said once, by name
+        assert recognise.describe_callback(_reference_random_step, {"_pc_trainer": tr}, tr) == (2.0, "")
     assert recognise.describe_callback(_reference_random_step, {"_pc_trainer": tr, "var": 0.7}, tr) == (0.7, "")
     # the probe consumed nothing of the script's seeded generators
     assert torch.equal(torch.rand(4), want[0]) and np.array_equal(np.random.rand(3), want[1])
@@ -232,10 +237,40 @@ def test_untagged_reference_random_step_is_recognised_by_behaviour():
     def wants_model(t, _pc_trainer):
         _pc_trainer.get_model().eval()
 
-    for fn, word in ((twice, "2 times"), (uniform, "normal_"), (rescaled, "not the N(0, std) it drew"), (annealed, "differs"),
-                     (writes_x, "x values"), (wants_model, "get_model")):
+    # what a behavioural probe at a few t cannot see -- a kick that also logs, counts in a closure, skips a step, or
+    # clamps beyond the probe's range -- must NOT be fused (fusing means the callable is never called again)
+    seen = []
+
+    def counting(t, _pc_trainer):
+        seen.append(t)
+        _reference_random_step(t, _pc_trainer)
+
+    def logging_kick(t, _pc_trainer, var=2.):
+        print("kick", var)
+        for x in _pc_trainer.get_model_xs():
+            x.grad.normal_(0., np.sqrt(var / _pc_trainer.get_optimizer_x().defaults['lr']))
+        _pc_trainer.get_optimizer_x().step()
+
+    def skips_a_step(t, _pc_trainer, var=2.):
+        if t == 7:
+            return
+        for x in _pc_trainer.get_model_xs():
+            x.grad.normal_(0., np.sqrt(var / _pc_trainer.get_optimizer_x().defaults['lr']))
+        _pc_trainer.get_optimizer_x().step()
+
+    def clamps(t, _pc_trainer, var=2.):
+        for x in _pc_trainer.get_model_xs():
+            x.grad.normal_(0., np.sqrt(var / _pc_trainer.get_optimizer_x().defaults['lr'])).clamp_(-100, 100)
+        _pc_trainer.get_optimizer_x().step()
+
+    import functools
+    for fn, word in ((twice, "global '_reference_random_step'"), (uniform, ".uniform_"), (rescaled, ".mul_"), (annealed, "reads its step argument"),
+                     (writes_x, ".data"), (wants_model, ".get_model"), (counting, "closes over"), (logging_kick, "global 'print'"),
+                     (skips_a_step, "reads its step argument"), (clamps, ".clamp_"),
+                     (functools.partial(_reference_random_step, var=1.0), "not a plain Python function")):
         var, why = recognise.describe_callback(fn, {"_pc_trainer": tr}, tr)
-        assert var is None and word in why, (fn.__name__, why)
+        assert var is None and word in why, (getattr(fn, "__name__", fn), why)
+    assert seen == []                                       # ... and none of them was run to find that out
     other = get_mcpc_trainer(m, CFG, training=False)
     assert recognise.describe_callback(_reference_random_step, {"_pc_trainer": other}, tr)[0] is None     # bound to another trainer
     assert recognise.describe_callback(lambda t: None, {}, tr)[0] is None                                  # a closure: cannot be probed
