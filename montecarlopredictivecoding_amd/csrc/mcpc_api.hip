@@ -174,6 +174,7 @@ struct mcpc_engine {
     bool spill_ready = false;       // the spill ring, its stream/events and the slabs exist (allocated by the first accumulating run)
     // LDS plan
     int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_bytes = 0;
+    int lds_zero = 0;               // 16 floats nothing writes: the GEMM core's over-reading lanes read them (KParams::lds_zero)
     bool xl = false;                // 16-chain in-place plan with room: state rows, biases, mu_1 rows and target words live in LDS (KParams::xl)
     int lds_x[kMaxLatent]{}, lds_bias[kMaxLatent]{}, lds_hbias = 0, lds_yw = 0;
     // per-step phase table (device copy)
@@ -307,6 +308,7 @@ int plan_lds(mcpc_engine* e) {
     for (int l = 1; l < e->L; ++l) { e->lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
     e->lds_e[0] = 0;
     e->lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
+    e->lds_zero = off; off += 16;            // (mcpc_gemm6.h: what lanes beyond a ragged k range read)
     e->lds_bytes = off * (int)sizeof(float);
     if (e->lds_bytes > 160 * 1024)
         return fail(MCPC_ENOMEM, "network needs %d bytes of LDS per workgroup (> 163840): latent widths too large for the fused kernel", e->lds_bytes);
@@ -355,9 +357,9 @@ int plan_lds_ws2(mcpc_engine* e, bool allow_xl = true) {
         if (L >= 2 && fits_apart(hc, nb) && !e->knobs.overlay16) { e->ws2_overlay = false; e->lds_eo = off + e_sum; }
     }
     off += e->ws2_overlay ? std::max(ring_floats, e_sum) : ring_floats + e_sum;
-    // The bf16x6 core reads the LDS operand in whole 32-deep k-blocks: up to 12 floats beyond a row whose width is not a multiple of
-    // 32.  Those lanes are zeroed in registers (mcpc_gemm6.h: tail_keep), so what lies there is irrelevant; 16 floats of slack keep
-    // even the read itself inside the workgroup's allocation.
+    // The bf16x6 core reads the LDS operand in whole 32-deep k-blocks; the lanes whose k values lie beyond a row whose width is not a
+    // multiple of 32 read THESE 16 floats instead of what lies behind the row (mcpc_gemm6.h): zero-filled at launch, never written.
+    e->lds_zero = off;
     off += 16;
     // with room to spare (16-chain plans: 45 KB at cfg-M) the lean epilogues keep what they read every step in LDS: the state rows
     // X_l (layout of FX_l), the bias rows, the mu_1 rows (layout of FX_0), the read-out bias and the bit-packed target rows
@@ -1292,7 +1294,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         for (int l = 0; l < e->L; ++l) widest = std::max(widest, e->npad[l]);
         P.lean_ok = e->Bpad < (1 << 24) && (uint64_t)e->Bpad * (uint64_t)widest * 4u < (1ull << 32) && !e->knobs.no_lean;
     }
-    P.err = e->err; P.dummy = e->dummy; P.lds_floats = e->lds_bytes / 4;
+    P.err = e->err; P.dummy = e->dummy; P.lds_floats = e->lds_bytes / 4; P.lds_zero = e->lds_zero;
     P.clk = e->profiling ? e->clk : nullptr;
     P.xl = e->xl ? 1 : 0;
     {

@@ -19,9 +19,11 @@
 //   C: the fp32 accumulator tile of the 16x16 MFMAs, same layout as before (lane (c, q): units 4q..4q+3 of chain c).
 // Fragments of a k-block travel ONE block ahead of their MFMAs in two register sets (P, Q) of 12 VGPRs per tile; the sets double as
 // the cross-entry prefetch (blocks 0 and 1 of the next table entry are requested into them while the current block is handed over).
-// k ranges that are not a multiple of 32 (kw % 32 == 16): the weights beyond kw are zeros AND the B lanes beyond kw are zeroed in
-// registers (MCPC_LOAD_B, the last block only), so the excess products are exact zeros WHATEVER the LDS holds behind the row -- the
-// next chain's row, another region of the plan, or bytes another kernel left behind.  (Round 3 relied on "finite neighbours"; a
+// k ranges that are not a multiple of 32 (kw % 32 == 16): the weights beyond kw are zeros AND the B lanes beyond kw read ZEROS -- in the
+// last k-block the lanes whose eight k values lie beyond kw (g >= 2) take their address from a 16-float region of the plan that is
+// zero-filled at launch and never written (KParams::lds_zero) instead of from behind their row -- so the excess products are exact
+// zeros WHATEVER the LDS holds behind the row: the next chain's row, another region of the plan, or bytes another kernel left behind.
+// (One v_cndmask per B load.  Zeroing the loaded values instead, 8 v_and per load, cost 3 % at cfg-M and 7 % at 256 chains.)  (Round 3 relied on "finite neighbours"; a
 // non-finite neighbour -- 0 x NaN -- was the intermittent NaN of tests/test_gpu_fuzz.py::test_wide_networks_against_oracle, DESIGN
 // section 8, reproduced by scripts/nan_repro.py and pinned by tests/test_gpu_lds_poison.py.)
 #pragma once
@@ -48,13 +50,6 @@ __device__ __forceinline__ frag_t split8(f32x4 x0, f32x4 x1) {
     frag_t f;
     f.h = u32x4{h[0], h[1], h[2], h[3]}; f.m = u32x4{m[0], m[1], m[2], m[3]}; f.l = u32x4{l[0], l[1], l[2], l[3]};
     return f;
-}
-
-__device__ __forceinline__ f32x4 and4(f32x4 v, uint32_t m) {
-    f32x4 r;
-    r.x = __uint_as_float(__float_as_uint(v.x) & m); r.y = __uint_as_float(__float_as_uint(v.y) & m);
-    r.z = __uint_as_float(__float_as_uint(v.z) & m); r.w = __uint_as_float(__float_as_uint(v.w) & m);
-    return r;
 }
 
 // the six products of one k-block for NT tiles x CTT chain tiles, small terms first; consecutive MFMAs go to different
@@ -90,13 +85,17 @@ __device__ __forceinline__ void mfma6_block(f32x4 (&acc)[NTT][CTT], const frag_t
 // keeps a 32-chain GEMM wave inside its 256 registers.  Static register names need the rotation unrolled over three k-blocks.
 template <int NT, int NTT, int CTT, int NW>
 __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nkb, int kw,
-                                           const float* B, int ldb, int lane, frag_t (&pre)[NTT]) {
+                                           const float* B, int ldb, int lane, frag_t (&pre)[NTT], const float* zeros) {
     static_assert(CTT == 1, "one chain tile per workgroup (the 32-chain forms left the tree in round 4)");
     constexpr int N0 = NT < 2 ? NT : 2, N1 = NT - N0;            // tiles of group 0 / group 1
     const int c = lane & 15, g = lane >> 4;
-    // lanes whose eight k values of the LAST block lie beyond kw (g >= 2 when kw % 32 == 16) read as zeros
-    const uint32_t tail_keep = (uint32_t)(kKB * (nkb - 1) + 8 * g) < (uint32_t)kw ? ~0u : 0u;
     const float* bp = B + c * ldb + 8 * g;
+    // the LAST block: lanes whose eight k values lie beyond kw (g >= 2 when kw % 32 == 16) read the plan's zero region instead
+#ifdef MCPC_EXP_NOTAILMASK      // timing experiment only (results depend on foreign LDS again)
+    const float* const bp_last = bp + (nkb - 1) * kKB; (void)kw; (void)zeros;
+#else
+    const float* const bp_last = (uint32_t)(kKB * (nkb - 1) + 8 * g) < (uint32_t)kw ? bp + (nkb - 1) * kKB : zeros;
+#endif
     // wave-uniform base + a 32-bit per-lane byte offset that never changes during the GEMM (no VALU address arithmetic per load)
     uint32_t voff[NT];
 #pragma unroll
@@ -108,12 +107,9 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
     const int last = nkb - 1;
 #define MCPC_LOAD_B(k_)                                                                             \
     do {                                                                                            \
-        const int kc_ = (k_) < last ? (k_) : last;          /* clamped, never conditional */        \
-        const uint32_t keep_ = (k_) < last ? ~0u : tail_keep;                                       \
-        _Pragma("unroll") for (int ct = 0; ct < CTT; ++ct) {                                        \
-            bC[ct][0] = and4(*reinterpret_cast<const f32x4*>(bp + ct * 16 * ldb + kc_ * kKB), keep_);     \
-            bC[ct][1] = and4(*reinterpret_cast<const f32x4*>(bp + ct * 16 * ldb + kc_ * kKB + 4), keep_); \
-        }                                                                                           \
+        const float* const src_ = (k_) < last ? bp + (k_) * kKB : bp_last;     /* never conditional */ \
+        bC[0][0] = *reinterpret_cast<const f32x4*>(src_);                                           \
+        bC[0][1] = *reinterpret_cast<const f32x4*>(src_ + 4);                                       \
     } while (0)
     // fragments of group G_ (0 / 1) of block k_ (clamped) into half-set s_
 #define MCPC_LOAD_HALF(s_, G_, k_)                                                                  \
@@ -185,19 +181,19 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
 // nt (wave-uniform, 1..NTT) selects a straight-line instantiation: no per-tile branches in the loop
 template <int N, int NTT, int CTT, int NW>
 __device__ __forceinline__ void gemm_dispatch(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nt, int nkb, int kw,
-                                              const float* B, int ldb, int lane, frag_t (&pre0)[NTT]) {
+                                              const float* B, int ldb, int lane, frag_t (&pre0)[NTT], const float* zeros) {
     if constexpr (N >= NTT) {
-        gemm_fixed<NTT, NTT, CTT, NW>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0);
+        gemm_fixed<NTT, NTT, CTT, NW>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0, zeros);
     } else {
-        if (nt == N) gemm_fixed<N, NTT, CTT, NW>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0);
-        else gemm_dispatch<N + 1, NTT, CTT, NW>(acc, A, aoff, nt, nkb, kw, B, ldb, lane, pre0);
+        if (nt == N) gemm_fixed<N, NTT, CTT, NW>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0, zeros);
+        else gemm_dispatch<N + 1, NTT, CTT, NW>(acc, A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros);
     }
 }
-// kw: valid k width of the B rows (a multiple of 16, 32 (nkb - 1) < kw <= 32 nkb)
+// kw: valid k width of the B rows (a multiple of 16, 32 (nkb - 1) < kw <= 32 nkb); zeros: 16 floats of LDS that stay zero for the launch
 template <int NTT, int CTT, int NW>
 __device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const void* A, const int (&aoff)[NTT], int nt, int nkb, int kw,
-                                           const float* B, int ldb, int lane, frag_t (&pre0)[NTT]) {
-    gemm_dispatch<1, NTT, CTT, NW>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0);
+                                           const float* B, int ldb, int lane, frag_t (&pre0)[NTT], const float* zeros) {
+    gemm_dispatch<1, NTT, CTT, NW>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros);
 }
 
 // request the fragments of k-block 0 of a phase's GEMM (issued one phase early: weights do not depend on any barrier)

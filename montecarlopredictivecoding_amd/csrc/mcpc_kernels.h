@@ -138,6 +138,8 @@ struct KParams {
                                      // target of the workgroup's chains live in LDS for the whole launch (mcpc_ws2_lean.h: XL)
     int spill_sys;                   // Hebbian spill stores at system scope (write-through): shards whose spill per step is far beyond the L2s
     int lds_floats;                  // floats of dynamic LDS of this plan (cleared once per launch: see mcpc_gemm6.h, k ranges)
+    int lds_zero;                    // float offset of 16 floats of the plan that nothing writes after that: what the GEMM core's lanes beyond a
+                                     // ragged k range read (mcpc_gemm6.h)
     unsigned long long* clk;         // profiling only (else null): [0] += shader cycles (s_memtime), [1] += 100 MHz wall ticks (s_memrealtime)
                                      // of one wave of workgroup 0 over the launch -- their ratio is the shader clock under THIS load
 #ifdef MCPC_STAMPS
@@ -475,7 +477,8 @@ __device__ __forceinline__ void bwd_epilogue_mode(const KParams& P, const KPhase
 }
 
 #ifndef MCPC_BARRIER_WAVES_PER_EU
-#define MCPC_BARRIER_WAVES_PER_EU 2      // two workgroups per CU (one's GEMMs cover the other's epilogues); 1: no spilled VGPRs, one workgroup per CU
+#define MCPC_BARRIER_WAVES_PER_EU 1      // one workgroup per CU, no spilled VGPRs (256 + 112 AGPRs): 129 us per step at cfg-M; 2 (two workgroups
+                                         // per CU, one's GEMMs covering the other's epilogues, 72 VGPRs spilled to scratch): 147 us (round 4)
 #endif
 template <int CTT, int NW>
 __global__ __launch_bounds__(NW * 64, MCPC_BARRIER_WAVES_PER_EU) void mcpc_steps_kernel(const KParams P) {
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(NW * 64, MCPC_BARRIER_WAVES_PER_EU) void mcpc_steps
             // (Requesting them after the GEMM's last fragment load was measured slower on MI355X.)
             if (ph.type != PH_HEADB) issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
             if (nt > 0 && ph.nkb > 0)
-                gemm_tiles<NTW, CTT, NW>(acc, ph.A, aoff, nt, ph.nkb, ph.kw, lds + ph.b_lds, ph.ldb, lane, pre0);
+                gemm_tiles<NTW, CTT, NW>(acc, ph.A, aoff, nt, ph.nkb, ph.kw, lds + ph.b_lds, ph.ldb, lane, pre0, lds + P.lds_zero);
             // the next phase's first weight fragments travel while this phase's epilogue runs
             if (has_next) prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next);
             if (ph.flags & PHF_ACC_TO_B) {
