@@ -40,6 +40,9 @@ int fail(int code, const char* fmt, ...) {
 inline int pad16(int n) { return (n + 15) / 16 * 16; }
 inline int kblocks(int k_pad) { return (k_pad + kKB - 1) / kKB; }      // k-blocks of the GEMM core that cover k_pad (a multiple of 16)
 inline int grid_for(size_t n, int block = 256) { return (int)std::min<size_t>((n + block - 1) / block, 4096); }
+// which Linears (et x at tiles of 16) take the LDS-tiled Hebbian kernels (mcpc_hebbian.h): wide ones, and 256 outputs with a narrow input
+inline bool heb_wide(int et, int at) { return et >= 8 && at % 8 == 0 && (at <= 16 || at % 16 == 0); }
+inline bool heb_narrow_in(int et, int at) { return !heb_wide(et, at) && et == 16 && (at == 1 || at == 2 || at == 4); }
 
 struct Lin {
     const float* W = nullptr;      // borrowed, torch layout [out][in]
@@ -52,6 +55,7 @@ struct Lin {
     float* G = nullptr;            // gradient sums [out_pad][g_ld]
     float* Gb = nullptr;           // [out_pad]
     int g_ld = 0;
+    bool spill_tm = false;         // its Hebbian operands are spilled tile-major (the bf16x6 kernel mcpc_heb7_kernel reads them)
     size_t slab_off = 0;           // float offset of this Linear's split-K slabs inside mcpc_engine::slab
     size_t slab_floats = 0;        // ... and their size
 };
@@ -80,6 +84,7 @@ struct Knobs {
     int no_xl = 0;            // 1: 16-chain plans keep the state and the per-step constants in global memory even when the LDS has the room (A/B, parity tests)
     int rr = 1;               // 0: shards of more 16-chain units than CUs run as one launch in hardware rounds instead of the round schedule (setup_rounds)
     int rr_qmax = 100;        // round schedule: most steps per launch in stretches without Hebbian accumulation
+    int heb171 = 0;           // 1: the 17-tile group of a read-out on <17, 1> with twice the activation groups instead of <17, 2> (A/B)
     int heb_fp32 = 0;         // 1: the tiled Hebbian GEMM runs on the fp32 MFMA (mcpc_heb_kernel) instead of the bf16x6 form (A/B, parity tests)
 };
 
@@ -101,7 +106,7 @@ int parse_tuning(const char* str, Knobs& k) {
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"no_overlap", &k.no_overlap},
             {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"cu_slack", &k.cu_slack}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
-            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}, {"heb_fp32", &k.heb_fp32}, {"rr", &k.rr}, {"rr_qmax", &k.rr_qmax}, {"no_xl", &k.no_xl}};
+            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}, {"heb_fp32", &k.heb_fp32}, {"heb171", &k.heb171}, {"rr", &k.rr}, {"rr_qmax", &k.rr_qmax}, {"no_xl", &k.no_xl}};
         bool found = false;
         for (auto& t : table)
             if (key == t.name) { *t.dst = val; found = true; }
@@ -775,6 +780,12 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     else if (e->slots >= kn.ring_parts) { e->half_slots = e->slots / kn.ring_parts; e->slots = e->half_slots * kn.ring_parts; }
     else { e->slots &= ~1; e->half_slots = e->slots / 2; }                   // fewer slots than parts: two halves
     // (the ring itself is allocated by the first run that accumulates Hebbian sums: ensure_spill)
+    // layout of the spilled operands per Linear: tile-major for the bf16x6 tiled kernel, row-major for the others (plan_hebbian's
+    // choice of kernel depends on the shapes only)
+    for (int j = 1; j < nlin; ++j) {
+        const int et = e->lin[j].out_pad / 16, at = e->lin[j].in_pad / 16;
+        e->lin[j].spill_tm = (heb_wide(et, at) || heb_narrow_in(et, at)) && !kn.heb_fp32;
+    }
 
     if ((rc = e->ws == 2 ? build_phases_ws2(e) : build_phases(e))) return bail(rc);
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
@@ -917,8 +928,8 @@ struct HebPlan {
 HebPlan plan_hebbian(const mcpc_engine* e, int ne, int na, int rows) {
     HebPlan h;
     const int et = ne / 16, at = na / 16;
-    const bool wide = et >= 8 && at % 8 == 0 && (at <= 16 || at % 16 == 0);
-    const bool narrow_in = !wide && et == 16 && (at == 1 || at == 2 || at == 4);       // e.g. 256 x 32
+    const bool wide = heb_wide(et, at);
+    const bool narrow_in = heb_narrow_in(et, at);       // e.g. 256 x 32
     h.tiled = wide || narrow_in;
     h.swapped = narrow_in;
     if (wide) {
@@ -975,18 +986,19 @@ int launch_heb(const HebArgs& a, hipStream_t stream) {
     return 0;
 }
 
-template <int TE, int RA>
-int launch_heb6(const HebArgs& a, hipStream_t stream) {
-    constexpr int lds_bytes = 3 * 16 * (TE + 8 * RA) * kHeb6LD * 2;
+template <int TE, int RA, bool SW = false>
+int launch_heb7(const HebArgs& a, hipStream_t stream) {
+    // two plane buffers + the bias sums + every wave's transpose scratch for one activation tile (2 row tiles x 4 x 17 float4)
+    constexpr int lds_bytes = 2 * 3 * 16 * TE * kHeb7LD * 2 + 16 * TE * (int)sizeof(float) + 8 * 2 * 272 * (int)sizeof(float);
     static bool attr_set[16] = {false};      // per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        if (hipFuncSetAttribute((const void*)mcpc_heb6_kernel<TE, RA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)mcpc_heb7_kernel<TE, RA, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
             return fail(MCPC_EHIP, "hipFuncSetAttribute failed for the Hebbian kernel");
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((mcpc_heb6_kernel<TE, RA>), dim3(a.n_mt * a.n_nt * a.ksplit), dim3(kHebThreads), lds_bytes, stream, a);
+    hipLaunchKernelGGL((mcpc_heb7_kernel<TE, RA, SW>), dim3(a.n_mt * a.n_nt * a.ksplit), dim3(kHebThreads), lds_bytes, stream, a);
     return 0;
 }
 
@@ -1084,6 +1096,11 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
             // transposed product: the activations take the E slot, the errors the A slot; slab = [split][na][ne]
             HebArgs a{A, E, slab, slab_b, rows, na, ne, h.rps, 1, 1, h.ksplit, 0};
             int rc = 0;
+            if (!e->knobs.heb_fp32) {
+                if (h.te[0] == 1) rc = launch_heb7<1, 2, true>(a, stream);
+                else if (h.te[0] == 2) rc = launch_heb7<2, 2, true>(a, stream);
+                else rc = launch_heb7<4, 2, true>(a, stream);
+            } else
             if (h.te[0] == 1) rc = launch_heb<1, 2, true>(a, stream);
             else if (h.te[0] == 2) rc = launch_heb<2, 2, true>(a, stream);
             else rc = launch_heb<4, 2, true>(a, stream);
@@ -1097,12 +1114,19 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
                 int rc = 0;
                 const int te = h.te[part];
                 if (!e->knobs.heb_fp32) {
-                    if (te == 17 && h.ra == 2) rc = launch_heb6<17, 2>(a, stream);
-                    else if (te == 16 && h.ra == 2) rc = launch_heb6<16, 2>(a, stream);
-                    else if (te == 8 && h.ra == 2) rc = launch_heb6<8, 2>(a, stream);
-                    else if (te == 17) rc = launch_heb6<17, 1>(a, stream);
-                    else if (te == 16) rc = launch_heb6<16, 1>(a, stream);
-                    else rc = launch_heb6<8, 1>(a, stream);
+                    if (te == 17 && h.ra == 2 && !e->knobs.heb171) rc = launch_heb7<17, 2>(a, stream);
+                    else if (te == 17 && h.ra == 2) {
+                        // 136 accumulators + the rest do not fit 256 registers (19 spilled): 8 activation tiles per workgroup instead,
+                        // i.e. twice the activation groups -- this group's 272 error columns are read twice (+6.5 MB per step at cfg-M)
+                        HebArgs a1 = a;
+                        a1.n_nt = 2 * a.n_nt;
+                        rc = launch_heb7<17, 1>(a1, stream);
+                    }
+                    else if (te == 16 && h.ra == 2) rc = launch_heb7<16, 2>(a, stream);
+                    else if (te == 8 && h.ra == 2) rc = launch_heb7<8, 2>(a, stream);
+                    else if (te == 17) rc = launch_heb7<17, 1>(a, stream);
+                    else if (te == 16) rc = launch_heb7<16, 1>(a, stream);
+                    else rc = launch_heb7<8, 1>(a, stream);
                 } else
                 if (te == 17 && h.ra == 2) rc = launch_heb<17, 2>(a, stream);
                 else if (te == 16 && h.ra == 2) rc = launch_heb<16, 2>(a, stream);
@@ -1251,6 +1275,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         K.rec = r->rec_count > 0 ? r->rec_x[l] : nullptr;
         K.spill_e = l == 0 ? e->e0sum : e->spill_e[l];
         K.spill_a = e->spill_a[l];
+        K.spill_e_tm = (l >= 1 && e->lin[l].spill_tm) ? 1 : 0;               // E_l is the error operand of Linear l,
+        K.spill_a_tm = (l + 1 < nlin && e->lin[l + 1].spill_tm) ? 1 : 0;      // f(x_l) the activation operand of Linear l + 1
         K.ext_noise = nullptr;
         if (l >= 1) {
             K.Wf = (const f32x4*)e->lin[l].Wf; K.Wb = (const f32x4*)e->lin[l].Wb; K.bias = e->lin[l].bias_pad;
@@ -1266,6 +1292,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         H.Wf = (const f32x4*)ln.Wf; H.Wb = (const f32x4*)ln.Wb; H.bias = ln.bias_pad;
         H.ybits = e->ybits; H.y_binary = e->knobs.no_ybits ? e->y_binary + 1 : e->y_binary; H.ywords = e->ywords;
         H.y = e->ypad; H.ytile = e->ytile; H.rec_out = r->rec_count > 0 ? r->rec_out : nullptr; H.spill_e = e->spill_eo;
+        H.spill_tm = e->lin[e->L].spill_tm ? 1 : 0;
         H.n = e->d.n_out; H.npad = e->out_pad; H.ntiles = e->out_pad / 16;
         H.loss_kind = r->loss_kind;
         H.inv_var = r->loss_kind == MCPC_LOSS_GAUSSIAN ? (float)(1.0 / (double)r->loss_var) : 1.0f;

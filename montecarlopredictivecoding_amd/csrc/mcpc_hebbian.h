@@ -5,6 +5,8 @@
 // flush of 64 steps): split-K over the grid, every split writes its partial tile to a slab, the slabs are summed in a fixed
 // order by mcpc_reduce_jobs_kernel (bitwise reproducible; no float atomics).
 //
+// (fp32-MFMA kernel mcpc_heb_kernel, rounds 2-3: row-major spill; kept behind tuning heb_fp32=1 as the independent form the bf16x6
+// kernel mcpc_heb7_kernel below is checked against.)
 // Workgroup = 8 waves (two per SIMD), tile = TE x TA MFMA tiles of 16 x 16 (TE <= 17 error tiles x TA = 8 RA activation
 // tiles: 272 x 256 outputs for the read-out Linear), so that a spilled byte is read once per workgroup column and every
 // k-row of the tile costs (TE + TA) x 64 B for TE x TA x 256 MACs: 8.2 B per CU-cycle at the full fp32 MFMA rate, which
@@ -192,102 +194,175 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
     }
 }
 
-constexpr int kHeb6KB = 32;
-// bf16 elements between the rows of two units in an LDS plane: 32 of data + 8 of padding.  With rows of exactly 64 B the sixteen lanes
-// of a ds_read_b128 group (unit m = 0..15, same k chunk) start at banks 16 m mod 64 -- four lanes per bank quartet -- and the
-// ds_write_b128s of the split pass collide four ways as well (SQ_LDS_BANK_CONFLICT = 0.50 of the LDS-active cycles, round 3 PMC); with
-// 80 B they start at 20 m mod 64: sixteen different quartets, both ways.
-constexpr int kHeb6LD = 40;            // spilled rows per stage = K of one bf16 MFMA
+// ---- bf16x6 form of the tiled kernel, round 4: mcpc_heb7_kernel (the default; tuning heb_fp32=1 selects the fp32-MFMA kernel above) -----
+// The same GEMM with the spilled fp32 operands split into three bf16 pieces (the six products whose magnitude is above 2^-24 of the
+// leading one, fp32 accumulation, small terms first; mcpc_bf16x6.h) on v_mfma_f32_16x16x32_bf16: against an fp64 sum its error is that
+// of the fp32-MFMA kernel (max 2.7e-7 / rms 3.1e-8 of sum|terms| against 2.1e-7 / 2.7e-8 at K = 4096, scripts/heb_bf16_ubench.hip).
+//
+// Round 3's form (mcpc_heb6_kernel) kept the planes of BOTH panels of a 32-row stage in LDS (126 KB: no second buffer), so every stage
+// was "all threads split -> barrier -> all waves MFMA -> barrier": MFMA busy 58 %, LDS bank conflicts 0.41 of the LDS-active cycles
+// (profiles/r03_pmc_summary.json), 17 us of whole-chip time per accumulating step at cfg-M for 9.4 us of MFMA work.  This form:
+//   * reads a TILE-MAJOR spill (KLayer::spill_tm: [row tile of 16][unit tile of 16][q = unit quad][c = row][4 units], the layout in
+//     which a step-kernel epilogue wave's float4-per-lane store is ONE contiguous KiB -- its row-major stores were sixteen 64-byte pieces
+//     of sixteen rows, about 100 cycles of the CU's vector-memory path each, the path the step kernel is bound by);
+//   * the ACTIVATION operand never touches LDS: wave w owns activation tiles RA w .. RA w + RA - 1 and no other wave needs them, so
+//     lane (m, g) gathers its eight values (unit m, rows 4g..4g+3 of both row tiles of the stage) straight from global memory
+//     (8 dwords per tile, the same 16 cache lines for all eight) and splits them in registers;
+//   * the ERROR panel (all waves need all TE tiles) goes through LDS as three bf16 planes [unit][32 rows] in rows of 80 B, now
+//     DOUBLE-BUFFERED (2 x 65 KB at TE = 17): the split of stage s+1 and the MFMAs of stage s run in the same barrier interval, waves
+//     0-3 splitting first and waves 4-7 multiplying first, so that on every SIMD one wave's conversion sits beside the other's MFMAs;
+//   * a thread of the split pass holds (row c, row 16 + c) x 4 units -- the same lane of the two row tiles of one unit tile, two
+//     coalesced float4 loads -- and writes one dword per unit and plane: k-slot pair (2c, 2c+1) = rows (c, 16 + c).  The MFMA's k order
+//     is free as long as both operands use it, and with the 80-byte unit stride the 32 lanes of a ds_write_b32 group hit 32 different
+//     banks (no conflicts), as do the 16 lanes of the operand's ds_read_b128.
+constexpr int kHeb7KB = 32;            // spilled rows per stage = K of one bf16 MFMA = two row tiles
+constexpr int kHeb7LD = 40;            // bf16 elements between the rows of two units in an LDS plane: 32 of data + 8 of padding (80 B)
 
-// ---- bf16x6 form of the tiled kernel (the default; tuning heb_fp32=1 selects the fp32-MFMA kernel above) ---------------------------
-// The same GEMM with the spilled fp32 operands split into three bf16 pieces (the six products whose magnitude is above
-// 2^-24 of the leading one, fp32 accumulation, small terms first; mcpc_bf16x6.h) on v_mfma_f32_16x16x32_bf16: against an fp64 sum its error is that of
-// the fp32-MFMA kernel (max 2.7e-7 / rms 3.1e-8 of sum|terms| against 2.1e-7 / 2.7e-8 at K = 4096, scripts/heb_bf16_ubench.hip), at
-// 1.66 x its rate on the same shapes (0.785 ms against 1.30 ms for the 784 x 256 flush of 64 steps on the whole chip).
-//   global -> registers (one float4 per row and thread, a stage ahead) -> v_cvt_pk_bf16_f32 -> LDS planes -> MFMA operands:
-// TE error tiles x 8 RA activation tiles per workgroup, 8 waves, wave w owns activation tiles RA w .. RA w + RA - 1.
-// LDS: three bf16 planes of the stage's operands, TRANSPOSED: plane[p][unit][r], 32 r = 64 B of data per unit in rows of 80 B (kHeb6LD),
-// so that the MFMA operand of lane (m, g) -- unit m, k = 8g..8g+7 -- is ONE conflict-free ds_read_b128.
-// Split pass: thread (ug, c) takes four consecutive units x the 8-row chunk c: 8 float4 loads (a chunk's 16 lanes = 256 contiguous bytes
-// of a spilled row), one ds_write_b128 per unit and plane.  512 units = 512 tasks = one per thread; a 17th error tile (TE = 17:
-// 784 = 17 + 16 + 16 tiles) is 512 more elements = ONE per thread (row tid / 16, unit 16 TE' + tid % 16), written with ds_write_b16.
-template <int TE, int RA>
-__global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb6_kernel(const HebArgs P) {
-    constexpr int TA = 8 * RA;
-    constexpr int TEM = TE >= 16 ? 16 : TE;             // error tiles handled by the float4 tasks
-    constexpr bool XT = TE == 17;                       // one extra error tile handled element-wise
-    static_assert(TE <= 17 && 4 * 4 * (TEM + TA) <= kHebThreads, "one task per thread");
-    constexpr int NU = 16 * (TE + TA);                  // units (columns) per stage: E panel then A panel
-    constexpr int PLANE = NU * kHeb6LD;                   // bf16 elements per plane
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds6[];       // [3][NU][32] bf16
+// SWAPPED: the launch computes the TRANSPOSED product for a Linear with a narrow input (the E slot holds its activations, the A slot
+// its errors); the bias sums (column sums of the errors) then come from the A operand, and the reduction writes the slab back transposed.
+template <int TE, int RA, bool SWAPPED = false>
+__global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb7_kernel(const HebArgs P) {
+    constexpr int TPW = (TE + 7) / 8;                   // error tiles a wave converts per stage (tile j = w + 8 i)
+    constexpr int PLANE = 16 * TE * kHeb7LD;            // bf16 elements per plane
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds7[];       // [2 buffers][3 planes][16 TE units][40] bf16
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 15, g = lane >> 4;
+    const int m = lane & 15, g = lane >> 4;             // MFMA view: unit m of a tile, k group g
+    const int c = lane & 15, q = lane >> 4;             // split view: row c of a row tile, unit quad q
     const int total = P.n_mt * P.n_nt * P.ksplit;
     int id = blockIdx.x;
-    if (total % 8 == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+    if (total % 8 == 0) id = (id & 7) * (total >> 3) + (id >> 3);      // consecutive logical ids (one K split) on one XCD
     const int per_split = P.n_mt * P.n_nt;
     const int split = id / per_split, rem = id - split * per_split;
     const int nt = rem / P.n_mt, mt = rem - nt * P.n_mt;
-    const int e_col0 = P.e_col_base + mt * 16 * TE, a_col0 = nt * 16 * TA;
+    const int e_col0 = P.e_col_base + mt * 16 * TE, a_col0 = nt * 16 * 8 * RA;
+    const int net = P.ne / 16, nat = P.na / 16;         // unit tiles per row tile of the two images
+    const int e_tile0 = e_col0 / 16, a_tile0 = a_col0 / 16 + RA * w;
     const int r0 = split * P.rows_per_split;
     const int r1 = min(P.rows, r0 + P.rows_per_split);
-    const int n_stage = (r1 - r0) / kHeb6KB;
+    const int n_stage = (r1 - r0) / kHeb7KB;
+    const size_t rt_base = (size_t)r0 / 16;             // first row tile of this split (rows_per_split is a multiple of 32)
 
-    // the float4 task of this thread; LDS unit index: E tiles 0 .. TEM-1, [the extra tile TEM], then the A tiles
-    const int ug = tid >> 2, c = tid & 3;
-    const bool mine = ug < 4 * (TEM + TA);
-    const bool is_a = 4 * ug >= 16 * TEM;
-    const int col = is_a ? a_col0 + 4 * ug - 16 * TEM : e_col0 + 4 * ug;
-    const int width = is_a ? P.na : P.ne;
-    const bool on = mine && col < width;                  // (widths are multiples of 16: a group of four is in or out as a whole)
-    const float* const src = (is_a ? P.A : P.E) + (size_t)(r0 + 8 * c) * width + (on ? col : 0);
-    const int lunit = 4 * ug + ((XT && is_a) ? 16 : 0);
-    const int loff = (mine ? lunit : 0) * kHeb6LD + 8 * c;  // element offset of the group's first unit inside a plane
-    // the extra tile: element (row tid / 16, unit tid % 16)
-    const int xr = tid >> 4, xu = tid & 15;
-    const bool xon = XT && e_col0 + 16 * TEM + xu < P.ne;
-    const float* const xsrc = P.E + (size_t)(r0 + xr) * P.ne + (xon ? e_col0 + 16 * TEM + xu : 0);
-    const int xoff = (16 * TEM + xu) * kHeb6LD + xr;
-    f32x4 v[8];
-    float xv = 0.f;
-    auto load_stage = [&](int s) {
+    // ---- what this thread loads per stage ------------------------------------------------------------------------------------
+    // Addresses = a wave-uniform 64-bit base (scalar registers, advanced by the scalar ALU) + ONE 32-bit byte offset per lane that never
+    // changes: with per-lane 64-bit pointers the address arithmetic alone took ~45 VGPRs, and <16, 2> / <17, 2> (128 / 136 accumulators)
+    // spilled 300-550 of them.
+    typedef const char __attribute__((address_space(1)))* gb_t;
+    bool e_on[TPW];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)(s * kHeb6KB + j) * width));
-        if constexpr (XT) xv = __builtin_nontemporal_load(xsrc + (size_t)s * kHeb6KB * P.ne);
-    };
-    f32x4 bsum = splat(0.f);
-    float xbsum = 0.f;
-    auto split_store = [&]() {
-        if (mine) {
+    for (int i = 0; i < TPW; ++i) e_on[i] = (w + 8 * i) < TE && e_tile0 + w + 8 * i < net;
+    bool a_on[RA];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {                // unit 4 ug + u: rows 8 c .. 8 c + 7 are v[0..7][u]
-                u32x4 hi, mid, lo;
+    for (int j = 0; j < RA; ++j) a_on[j] = a_tile0 + j < nat;
+    const uint32_t e_lane = 16u * (uint32_t)lane;                                             // float4 `lane` of a tile
+    const size_t e_rt_bytes = (size_t)net * 1024, a_rt_bytes = (size_t)nat * 1024;             // one row tile of the images
+    f32x4 eraw[TPW][2];                                 // E: (row c | row 16 + c) x units 4q..4q+3 of tile w + 8 i
+    f32x4 araw[RA][2];                                  // A: the same float4s of this wave's own tiles a_tile0 + j
+    // The activation operand of lane (m, g) is unit m x rows (4g+i, 16+4g+i): a 16 x 16 transpose away from what a coalesced load
+    // gives a lane (row c x 4 units).  It goes through a scratch of this WAVE's own in LDS (no other wave reads it: no barrier, only the
+    // wave's own lgkmcnt): written as float4s, read back as 8 dwords per tile.  Quad q's 16 rows start 17 float4 slots apart, so
+    // that the 32 lanes of a ds_read_b32 group ((q, g mod 2, m mod 4): dword 68 q + 16 g + 4 i + m mod 4) hit 32 different banks.
+    // (Gathering the 8 dwords straight from global memory cost 7 % of the kernel: each such wave instruction touches 16 cache lines.)
+    float* const a_scr = reinterpret_cast<float*>(lds7 + 2 * 3 * PLANE) + 16 * TE + (size_t)w * (2 * 272);     // (one tile's two row tiles: reused tile after tile)
+    const int a_wr = 4 * (17 * q + c);                                                          // float offset of this lane's float4 in a tile image
+    const int a_rd = 4 * (17 * (m >> 2) + 4 * g) + (m & 3);                                     // ... of (unit m, row 4 g)
+    // (no load under a branch: hipcc joins the paths behind s_waitcnt vmcnt(0) -- a stage past the end re-reads the last one, a tile
+    // past the image the first one, and what they return is dropped by a select)
+    const int s_last = n_stage > 0 ? n_stage - 1 : 0;
+    auto load_e = [&](int s_) {
+#if defined(MCPC_HEB_EXP) && MCPC_HEB_EXP == 4      // timing experiment only: no global loads
+        if (P.rows >= 0) return;
+#endif
+        const int s = s_ < s_last ? s_ : s_last;
+        const gb_t base = (gb_t)P.E + (rt_base + 2 * (size_t)s) * e_rt_bytes;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = on ? v[2 * j][u] : 0.f, b = on ? v[2 * j + 1][u] : 0.f;
-                    bsum[u] += a + b;
-                    unsigned h, mm, ll;
-                    split3_pair_fast(f32x2{a, b}, h, mm, ll);       // (9 instructions per pair instead of 13: mcpc_bf16x6.h)
-                    hi[j] = h; mid[j] = mm; lo[j] = ll;
-                }
-                *reinterpret_cast<u32x4*>(lds6 + 0 * PLANE + loff + u * kHeb6LD) = hi;
-                *reinterpret_cast<u32x4*>(lds6 + 1 * PLANE + loff + u * kHeb6LD) = mid;
-                *reinterpret_cast<u32x4*>(lds6 + 2 * PLANE + loff + u * kHeb6LD) = lo;
+        for (int i = 0; i < TPW; ++i) {
+            const gb_t tb = base + (size_t)(e_on[i] ? e_tile0 + w + 8 * i : e_tile0) * 1024;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                // (the tile-past-the-image select is applied where the value is USED: a select here would make the wave wait for the load at once)
+                eraw[i][b] = __builtin_nontemporal_load(reinterpret_cast<const gf32x4*>(tb + b * e_rt_bytes + e_lane));
             }
         }
-        if constexpr (XT) {
-            const float a = xon ? xv : 0.f;
-            xbsum += a;
-            const unsigned h = pk_bf16(a, 0.f);
-            const float ra = a - bf16lo_f32(h);
-            const unsigned mm = pk_bf16(ra, 0.f);
-            const float sa = ra - bf16lo_f32(mm);
-            lds6[0 * PLANE + xoff] = (unsigned short)h;
-            lds6[1 * PLANE + xoff] = (unsigned short)mm;
-            lds6[2 * PLANE + xoff] = (unsigned short)pk_bf16(sa, 0.f);
+    };
+    auto load_a = [&](int s_) {
+#if defined(MCPC_HEB_EXP) && MCPC_HEB_EXP == 4
+        if (P.rows >= 0) return;
+#endif
+        const int s = s_ < s_last ? s_ : s_last;
+        const gb_t base = (gb_t)P.A + (rt_base + 2 * (size_t)s) * a_rt_bytes;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const gb_t tb = base + (size_t)(a_on[j] ? a_tile0 + j : 0) * 1024;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                araw[j][b] = __builtin_nontemporal_load(reinterpret_cast<const gf32x4*>(tb + b * a_rt_bytes + e_lane));
         }
+    };
+    // ---- bias sums: column sums of the errors (E panel; SWAPPED: the A operand) ----------------------------------------------
+    // (E panel: per stage the 16 rows-pairs of a unit quad are summed across their DPP row and ONE lane adds the quad's four sums to a
+    // running fp32 value in LDS -- a fixed lane, stage after stage: the same order in every run -- instead of 4 TPW accumulator registers
+    // per thread in a kernel that has none to spare)
+    float* const bias_lds = reinterpret_cast<float*>(lds7 + 2 * 3 * PLANE);          // [16 TE] behind the two plane buffers
+    float asum[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) asum[j] = 0.f;
+    const bool e_bias = !SWAPPED && nt == 0, a_bias = SWAPPED && mt == 0;
+
+    // registers -> planes of buffer `buf`: tile j = w + 8 i, unit 16 j + 4 q + u, k-slot pair c
+    auto split_store = [&](int buf, bool real) {        // real: a stage of the split (not the re-conversion past its end): its rows count for the bias
+#if defined(MCPC_HEB_EXP) && MCPC_HEB_EXP == 2      // timing experiment only (wrong sums): no conversion, no plane stores
+        if (P.rows >= 0) return;
+#endif
+        unsigned short* const base = lds7 + (size_t)buf * 3 * PLANE + (size_t)(4 * q) * kHeb7LD + 2 * c;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if ((w + 8 * i) >= TE) continue;
+            const f32x4 v0 = e_on[i] ? eraw[i][0] : splat(0.f), v1 = e_on[i] ? eraw[i][1] : splat(0.f);
+            if (e_bias && real) {
+                f32x4 t = v0 + v1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float v = t[u];
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                    t[u] = v;
+                }
+                if (c == 0) {
+                    f32x4* const bp = reinterpret_cast<f32x4*>(bias_lds + 16 * (w + 8 * i) + 4 * q);
+                    *bp = *bp + t;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned h, mm, ll;
+                split3_pair_fast(f32x2{v0[u], v1[u]}, h, mm, ll);
+                unsigned short* const dst = base + (size_t)(16 * (w + 8 * i) + u) * kHeb7LD;
+                *reinterpret_cast<unsigned*>(dst) = h;
+                *reinterpret_cast<unsigned*>(dst + PLANE) = mm;
+                *reinterpret_cast<unsigned*>(dst + 2 * PLANE) = ll;
+            }
+        }
+    };
+    struct Op { u32x4 h, m, l; };
+    auto make_a = [&](int j) {
+        // registers -> the wave's scratch -> (unit m, rows 4g+i of both row tiles)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) *reinterpret_cast<f32x4*>(a_scr + b * 272 + a_wr) = a_on[j] ? araw[j][b] : splat(0.f);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        Op o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned h, mm, ll;
+            const float a0 = a_scr[a_rd + 4 * i], a1 = a_scr[272 + a_rd + 4 * i];
+            split3_pair_fast(f32x2{a0, a1}, h, mm, ll);
+            o.h[i] = h; o.m[i] = mm; o.l[i] = ll;
+            if (a_bias) asum[j] += a0 + a1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the next tile's stores come after these reads)
+        __builtin_amdgcn_wave_barrier();
+        return o;
     };
 
     f32x4 acc[TE][RA];
@@ -296,40 +371,83 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb6_kernel(const HebArgs
 #pragma unroll
         for (int j = 0; j < RA; ++j) acc[i][j] = splat(0.f);
 
-    if (n_stage > 0) load_stage(0);
-    const unsigned short* const base = lds6 + (size_t)m * kHeb6LD + 8 * g;       // lane (m, g) of tile t reads plane[p][16 t + m][8 g .. 8 g + 7]
-    struct Op { u32x4 h, m, l; };
-    auto ld_op = [&](int tile) {
-        const unsigned short* p = base + (size_t)(16 * tile) * kHeb6LD;
-        Op o;
-        o.h = *reinterpret_cast<const u32x4*>(p);
-        o.m = *reinterpret_cast<const u32x4*>(p + PLANE);
-        o.l = *reinterpret_cast<const u32x4*>(p + 2 * PLANE);
-        return o;
-    };
-    for (int s = 0; s < n_stage; ++s) {
-        split_store();                                    // stage s: registers -> three bf16 planes in LDS
-        __syncthreads();
-        if (s + 1 < n_stage) load_stage(s + 1);            // travels during the MFMAs
-        Op ao[RA];
-#pragma unroll
-        for (int j = 0; j < RA; ++j) ao[j] = ld_op(TE + RA * w + j);
-        Op e = ld_op(0);
+    // The six products of an error tile, small terms first: (l h) (m m) (h l) | (m h) (h m) | (h h).  A plane of the error operand is
+    // re-read for the NEXT tile as soon as its last product of this tile has been issued (l after the first, m after the fourth; only
+    // the h plane, used by the last product, needs a second register set): the LDS round trip of the next tile's operands hides
+    // behind this tile's MFMAs at 4 extra registers instead of 12.
+    auto mfma_stage = [&](int buf, const Op (&ao)[RA]) {
+#if defined(MCPC_HEB_EXP) && MCPC_HEB_EXP == 5      // timing experiment only: no MFMA phase
+        if (P.rows >= 0) return;
+#endif
+        const unsigned short* const rd = lds7 + (size_t)buf * 3 * PLANE + (size_t)m * kHeb7LD + 8 * g;     // lane (m, g): plane[p][16 t + m][8 g ..]
+        u32x4 eh = *reinterpret_cast<const u32x4*>(rd), em = *reinterpret_cast<const u32x4*>(rd + PLANE),
+              el = *reinterpret_cast<const u32x4*>(rd + 2 * PLANE);
 #pragma unroll
         for (int i = 0; i < TE; ++i) {
-            // the next error tile's operands are requested before this tile's MFMAs (pinned: left alone hipcc sinks the reads)
-            Op en = e;
+            const unsigned short* const nx = rd + (size_t)(16 * (i + 1 < TE ? i + 1 : i)) * kHeb7LD;
             __builtin_amdgcn_sched_barrier(0);
-            if (i + 1 < TE) en = ld_op(i + 1);
-            // six products per accumulator, small terms first, the accumulators of the tile alternating
-#define H6(ep_, ap_) _Pragma("unroll") for (int j = 0; j < RA; ++j) acc[i][j] = mfma6(e.ep_, ao[j].ap_, acc[i][j])
-            H6(m, m); H6(l, h); H6(h, l); H6(m, h); H6(h, m); H6(h, h);
-#undef H6
+            const u32x4 ehn = *reinterpret_cast<const u32x4*>(nx);
+#define H7(e_, ap_) _Pragma("unroll") for (int j = 0; j < RA; ++j) acc[i][j] = mfma6(e_, ao[j].ap_, acc[i][j])
+            H7(el, h);
             __builtin_amdgcn_sched_barrier(0);
-            e = en;
+            el = *reinterpret_cast<const u32x4*>(nx + 2 * PLANE);
+#if defined(MCPC_HEB_EXP) && MCPC_HEB_EXP == 6      // timing experiment: the m plane is free (and re-read) one product earlier
+            H7(em, m); H7(em, h);
+            __builtin_amdgcn_sched_barrier(0);
+            em = *reinterpret_cast<const u32x4*>(nx + PLANE);
+            H7(eh, l); H7(eh, m); H7(eh, h);
+#else
+            H7(em, m); H7(eh, l); H7(em, h);
+            __builtin_amdgcn_sched_barrier(0);
+            em = *reinterpret_cast<const u32x4*>(nx + PLANE);
+            H7(eh, m); H7(eh, h);
+#endif
+#undef H7
+            __builtin_amdgcn_sched_barrier(0);
+            eh = ehn;
         }
-        __syncthreads();                                  // every wave is done with the planes of stage s
+    };
+
+    // ---- pipeline: stage s multiplies out of buffer s & 1 while stage s + 1 is split into the other one ------------------------
+    if (tid < 16 * TE) bias_lds[tid] = 0.f;
+    __syncthreads();
+    if (n_stage == 0) return;
+    load_e(0);
+    load_a(0);
+    split_store(0, true);
+    load_e(1);
+    __syncthreads();
+    // One wave of every SIMD converts while the other multiplies: waves 0-3 split stage s + 1 first and multiply stage s afterwards,
+    // waves 4-7 the other way round (two copies of the loop, the same barrier count).  The conversion of stage s + 1 into the last
+    // buffer past the end is harmless (it re-converts the last stage into the buffer nobody reads any more).
+#if defined(MCPC_HEB_EXP) && MCPC_HEB_EXP == 3      // timing experiment: no stagger, every wave splits first
+    if (w < 8) {
+#else
+    if (w < 4) {
+#endif
+        for (int s = 0; s < n_stage; ++s) {
+            split_store((s + 1) & 1, s + 1 < n_stage);
+            load_e(s + 2);
+            Op ao[RA];
+#pragma unroll
+            for (int j = 0; j < RA; ++j) ao[j] = make_a(j);    // stage s (loaded one stage ago)
+            load_a(s + 1);
+            mfma_stage(s & 1, ao);
+            __syncthreads();          // buffer (s + 1) & 1 is complete; every wave is done reading buffer s & 1
+        }
+    } else {
+        for (int s = 0; s < n_stage; ++s) {
+            Op ao[RA];
+#pragma unroll
+            for (int j = 0; j < RA; ++j) ao[j] = make_a(j);
+            load_a(s + 1);
+            mfma_stage(s & 1, ao);
+            split_store((s + 1) & 1, s + 1 < n_stage);
+            load_e(s + 2);
+            __syncthreads();
+        }
     }
+
     // C layout of tile (i, j): row 4 g + reg -> error unit, column m -> activation unit
     float* out = P.slab + (size_t)split * P.ne * P.na;
 #pragma unroll
@@ -344,22 +462,20 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb6_kernel(const HebArgs
             for (int reg = 0; reg < 4; ++reg) out[(size_t)(u0 + reg) * P.na + a] = acc[i][j][reg];
         }
     }
-    // bias sums (column sums of E, workgroups of the first activation group only).  float4 tasks: the four chunk lanes of a unit
-    // group are adjacent lanes.  Extra tile: 32 rows spread over tid / 16 -> through LDS.
-    if (nt == 0) {
-        f32x4 bb = bsum;
+    if (e_bias) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { float t = bb[u]; t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); bb[u] = t; }
-        if (c == 0 && mine && !is_a && col < P.ne) *reinterpret_cast<f32x4*>(P.slab_b + (size_t)split * P.ne + col) = bb;
-        if constexpr (XT) {
-            float* red = reinterpret_cast<float*>(lds6);
-            red[tid] = xbsum;
-            __syncthreads();
-            if (tid < 16 && e_col0 + 16 * TEM + tid < P.ne) {
-                float t = 0.f;
-                for (int r = 0; r < 32; ++r) t += red[16 * r + tid];
-                P.slab_b[(size_t)split * P.ne + e_col0 + 16 * TEM + tid] = t;
-            }
+        for (int i = 0; i < TPW; ++i) {
+            if ((w + 8 * i) >= TE || !e_on[i]) continue;
+            if (c == 0) *reinterpret_cast<f32x4*>(P.slab_b + (size_t)split * P.ne + 16 * (e_tile0 + w + 8 * i) + 4 * q) =
+                            *reinterpret_cast<const f32x4*>(bias_lds + 16 * (w + 8 * i) + 4 * q);
+        }
+    }
+    if (a_bias) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            float v = asum[j];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (g == 0 && a_on[j]) P.slab_b[(size_t)split * P.na + 16 * (a_tile0 + j) + m] = v;
         }
     }
 }

@@ -32,6 +32,7 @@ struct KLayer {
     float* rec;            // trajectory records [rec_count][B][n] (unpadded) or null
     float* spill_e;        // l>=1: [slots][Bpad][npad] errors;  l==0: running sum of e_1 [Bpad][npad]
     float* spill_a;        // [slots][Bpad][npad] activations f(x_l)
+    int spill_e_tm, spill_a_tm;   // 1: that image is TILE-MAJOR (spill_offset): what the bf16x6 Hebbian kernel reads (mcpc_heb7_kernel); 0: row-major
     const float* ext_noise;// [n_steps][B][n] or null
     const f32x4* Wf;       // l>=1: packed forward weights of Linear l  [ntiles][nkb_in][64]
     const f32x4* Wb;       // l>=1: packed backward weights of Linear l [ntiles(l-1)][ntiles][64]
@@ -56,6 +57,7 @@ struct KHead {
     int ywords;            // words per chain = ceil(npad / 32)
     float* rec_out;        // [rec_count][B][n] or null
     float* spill_e;        // [slots][Bpad][npad]
+    int spill_tm;          // 1: tile-major (see KLayer::spill_e_tm)
     int n, npad, ntiles;
     int loss_kind;
     float inv_var;
@@ -155,6 +157,13 @@ struct KParams {
 // Float offset of units u0 .. u0+3 (u0 a multiple of 4) of `chain` in an image of npad-wide rows:
 __device__ __forceinline__ size_t tile_major_offset(int chain, int u0, int npad) {
     return (((size_t)(chain >> 4) * (npad >> 4) + (u0 >> 4)) * 64 + (chain & 15) + 16 * ((u0 >> 2) & 3)) * 4;
+}
+
+// Float offset of units u0 .. u0+3 of `row` in a spilled image [rows][npad]: row-major, or tile-major (tile_major_offset) -- the layout in
+// which the float4-per-lane store of an epilogue wave (16 rows x 16 units) is one contiguous KiB and which mcpc_heb7_kernel reads.
+__device__ __forceinline__ size_t spill_offset(int tm, size_t row, int u0, int npad) {
+    return tm ? (((row >> 4) * (size_t)(npad >> 4) + (size_t)(u0 >> 4)) * 64 + (row & 15) + 16 * ((u0 >> 2) & 3)) * 4
+              : row * (size_t)npad + (size_t)u0;
 }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -298,10 +307,10 @@ __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph
             if (l > 0) st4(e_lds + cl * ld + u0, e);
             if (slot >= 0) {
                 const f32x4 z = splat(0.f);
-                const size_t srow = ((size_t)slot * Bpad + chain) * npad + u0;
-                st4s(spill_a + srow, live ? fx : z);
+                const size_t srow = (size_t)slot * Bpad + chain;
+                st4s(spill_a + spill_offset(Ly.spill_a_tm, srow, u0, npad), live ? fx : z);
                 if (l > 0) {
-                    st4s(spill_e + srow, live ? e : z);
+                    st4s(spill_e + spill_offset(Ly.spill_e_tm, srow, u0, npad), live ? e : z);
                 } else if (live) {    // Linear 0 sees a constant input: only sum_t e_1 is needed
                     float* sp = spill_e + (size_t)chain * npad + u0;
                     st4s(sp, ld4s(sp) + e);
@@ -375,7 +384,7 @@ __device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& 
                 e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
             }
             st4(eo_lds + cl * ld + (u0 - 16 * ph.tile0), e);
-            if (slot >= 0) st4s(spill + ((size_t)slot * Bpad + chain) * npad + u0, e);
+            if (slot >= 0) st4s(spill + spill_offset(H.spill_tm, (size_t)slot * Bpad + chain, u0, npad), e);
             if (rec != nullptr && live) st_unpadded(rec, chain, n, u0, o);
         }
     }

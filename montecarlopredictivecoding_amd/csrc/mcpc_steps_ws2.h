@@ -198,6 +198,7 @@ __device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPha
     const float inv_var = vreg(H.inv_var);
     const int eo_off = vreg(ph.out_lds), tile0x16 = vreg(16 * ph.tile0);
     float* const spill = slot >= 0 ? vreg(H.spill_e + (size_t)slot * P.Bpad * H.npad) : nullptr;
+    const int spill_tm = vreg(H.spill_tm);
     float* const rec = (rec_idx >= 0 && H.rec_out != nullptr) ? H.rec_out + (size_t)rec_idx * P.B * H.n : nullptr;
     float lsum = 0.f;
 #pragma unroll
@@ -241,7 +242,7 @@ __device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPha
                 e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
             }
             st4(lds + eo_off + cl * ld + (u0 - tile0x16), e);
-            if (slot >= 0) st4s(spill + (size_t)chain * npad + u0, e);
+            if (slot >= 0) st4s(spill + spill_offset(spill_tm, (size_t)chain, u0, npad), e);
             if (rec != nullptr && live) st_unpadded(rec, chain, H.n, u0, o);
         }
     }

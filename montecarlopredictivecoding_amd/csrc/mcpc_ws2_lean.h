@@ -174,8 +174,10 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
 #else
                 const uint32_t sb = rowb[ct] + tb;
 #endif
-                spill_st4(spill_a, img_bytes, sb, mask4(act4<ACT>(x), L.livem[ct]), sys);
-                if (l > 0) spill_st4(spill_e, img_bytes, sb, mask4(e, L.livem[ct]), sys);
+                // tile-major image: (chain's row tile, unit tile) is one contiguous KiB, lane (c, q) its float4 number c + 16 q
+                const uint32_t sb_tm = mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q);
+                spill_st4(spill_a, img_bytes, Ly.spill_a_tm ? sb_tm : sb, mask4(act4<ACT>(x), L.livem[ct]), sys);
+                if (l > 0) spill_st4(spill_e, img_bytes, Ly.spill_e_tm ? sb_tm : sb, mask4(e, L.livem[ct]), sys);
                 else if (e0_in_regs) e0acc[ct] = e0acc[ct] + e;                          // (one tile per wave: i == 0 only)
                 else gst4s(spill_e, rowb[ct] + tb, gld4s(spill_e, rowb[ct] + tb) + e);   // Linear 0: only sum_t e_1 is needed
             }
@@ -492,7 +494,9 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
 #ifdef MCPC_EXP_SPILL_LINEAR
             if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q), mask4(e, L.livem[ct]), P.spill_sys != 0);
 #else
-            if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, rowb[ct] + tb, mask4(e, L.livem[ct]), P.spill_sys != 0);
+            if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4,
+                                     H.spill_tm ? mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q) : rowb[ct] + tb,
+                                     mask4(e, L.livem[ct]), P.spill_sys != 0);
 #endif
             if (rec != nullptr && L.livem[ct]) st_unpadded(rec, (int)L.chain[ct], H.n, 16 * tile + 4 * L.q, o);
         }
