@@ -22,7 +22,7 @@ PMCG[tcc]="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum"
 PMCG[fetch]="FETCH_SIZE"
 PMCG[write]="WRITE_SIZE"
 PMCG[grbm]="GRBM_GUI_ACTIVE GRBM_COUNT"
-for MODE in learning inference; do
+for MODE in ${PMC_MODES:-learning inference}; do
   if [ $MODE = learning ]; then ARGS="--no-secondary"; else ARGS="--only-inference"; fi
   for G in sq_issue sq_mem sq_fifo sq_valu tcp tcp2 tcc fetch write grbm; do
     D=$OUT/raw_${MODE}_$G
@@ -34,4 +34,4 @@ for MODE in learning inference; do
   done
 done
 cd $ROOT
-python3 scripts/reduce_pmc.py --merge $OUT $OUT/pmc_summary.json
+[ -n "$PMC_NO_MERGE" ] || python3 scripts/reduce_pmc.py --merge $OUT $OUT/pmc_summary.json
