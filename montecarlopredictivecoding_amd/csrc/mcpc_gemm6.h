@@ -74,6 +74,11 @@ __device__ __forceinline__ void mfma6_block(f32x4 (&acc)[NTT][CTT], const frag_t
 #define MCPC_KSEL(k_) (k_)
 #endif
 
+#ifdef MCPC_EXP_NOSPLIT    // timing experiment only (wrong results): the B planes of block 0 serve every block (no LDS reads, no split)
+#define MCPC_EXP_SPLIT8(a_, b_) bs[0]
+#else
+#define MCPC_EXP_SPLIT8(a_, b_) split8(a_, b_)
+#endif
 // acc += W-tiles . B over nkb blocks.  On entry `pre` holds block 0 of every tile, requested by the caller's prefetch (one table
 // entry early); on return it is free.
 //
@@ -127,9 +132,14 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
 #define MCPC_M6(s_, G_, ct_, ap_, bp_)                                                              \
     _Pragma("unroll") for (int i = 0; i < ((G_) ? N1 : N0); ++i)                                    \
         acc[2 * (G_) + i][ct_] = mfma6(s_[i].ap_, bs[ct_].bp_, acc[2 * (G_) + i][ct_])
+#ifdef MCPC_EXP_HALFMFMA   // timing experiment only (wrong results): three of the six products
+#define MCPC_SUB(s_, G_, ct_)                                                                       \
+    do { MCPC_M6(s_, G_, ct_, m, m); MCPC_M6(s_, G_, ct_, l, h); MCPC_M6(s_, G_, ct_, h, l); } while (0)
+#else
 #define MCPC_SUB(s_, G_, ct_)                                                                       \
     do { MCPC_M6(s_, G_, ct_, m, m); MCPC_M6(s_, G_, ct_, l, h); MCPC_M6(s_, G_, ct_, h, l);         \
          MCPC_M6(s_, G_, ct_, m, h); MCPC_M6(s_, G_, ct_, h, m); MCPC_M6(s_, G_, ct_, h, h); } while (0)
+#endif
 #define MCPC_SPLIT1(ct_) bs[ct_] = split8(bC[ct_][0], bC[ct_][1])
     // One k-block: the chain tile's planes are read by both sub-steps, so the next block's split goes into a second copy beside
     // (k, G1) and is moved over at the end of the block (12 v_mov)
@@ -140,7 +150,7 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
         MCPC_SUB(sa_, 0, 0);                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                          \
         MCPC_LOAD_HALF(sa_, 1, (k_) + 1);                                                           \
-        const frag_t bsn_ = split8(bC[0][0], bC[0][1]);   /* (k + 1): read at the head of this block */ \
+        const frag_t bsn_ = MCPC_EXP_SPLIT8(bC[0][0], bC[0][1]);   /* (k + 1): read at the head of this block */ \
         MCPC_SUB(sb_, 1, 0);                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                          \
         MCPC_LOAD_B((k_) + 2);                                                                      \
