@@ -13,6 +13,8 @@ W, b, y, xs = make_problem(B, 30, dev)
 eng = Engine(SIZES, [L.ACT_RELU] * 3, 30, N_OUT, B, device=dev, tuning=os.environ.get("QUICK_TUNING"))
 eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
 base = dict(noise_mode=L.NOISE_PHILOX, loss_kind=L.LOSS_BERNOULLI, energy_mode=L.ENERGY_ALL, lr=0.03, seed=1)
+if os.environ.get("QUICK_NONOISE"): base.update(noise_mode=L.NOISE_NONE)            # what the Philox kick costs
+if os.environ.get("QUICK_ELAST"): base.update(energy_mode=L.ENERGY_LAST)            # what the per-step energies / loss cost
 out = []
 if os.environ.get("QUICK_PROFILE"): eng.set_profiling(True)
 if os.environ.get("QUICK_REC"): base.update(rec_begin=0, rec_stride=100, rec_count=(K + 99) // 100, rec_x=True)
