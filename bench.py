@@ -330,8 +330,9 @@ def main():
                                        "peak_is": "64 B per clock x the shader clock measured during these launches (%s)"
                                                   % ("%.3f GHz" % ghz if ghz and ghz > 0.5 else "not measured: 2.4 GHz peak"),
                                        "workgroups_per_launch": wg_per_launch,
-                                       "note": "the resource that binds the step kernel at 16 chains per workgroup (DESIGN section 4): "
-                                               "six MFMAs of 16 cycles per 3 KiB of fragments, four GEMM waves per CU on one 64 B/clk return path"},
+                                       "note": "the fragment stream of a workgroup on its CU's vector-memory return path: one of the serial terms "
+                                               "of a 16-chain step (MFMAs 11.3 us, fragment returns ~7.5, operand split 3.3, table skeleton 4.8 of "
+                                               "~35; timing builds in profiles/r04_k1_bounds.txt, DESIGN section 4)"},
                     "note": note}
             return line
 

@@ -41,5 +41,5 @@ for tuning in (None, "rr=0"):
             for _ in range(5):
                 call()
             dt = (time.perf_counter() - t0) / 5
-            print(f"{'rounds' if tuning is None else 'wg32':6s} {name:9s} T={T:5d}: {dt*1e3:7.2f} ms per call, {dt/T*1e6:6.1f} us per step", flush=True)
+            print(f"{'rounds' if tuning is None else 'rr=0':6s} {name:9s} T={T:5d}: {dt*1e3:7.2f} ms per call, {dt/T*1e6:6.1f} us per step", flush=True)
     eng.close()
