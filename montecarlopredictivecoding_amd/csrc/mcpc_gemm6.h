@@ -85,13 +85,14 @@ __device__ __forceinline__ void mfma6_block(f32x4 (&acc)[NTT][CTT], const frag_t
 // Register diet.  The wave's tiles are worked in two GROUPS of at most two (G0 = tiles 0, 1; G1 = tiles 2, 3); one k-block is two
 // sub-steps (k, G0), (k, G1) of 6 x 2 x CTT MFMAs each, and the fragments of sub-step u + 2 travel while u and u + 1 compute --
 // the distance of a whole k-block, as with two full sets -- in THREE rotating half-sets of 24 VGPRs: sub-step u reads set u mod 3,
-// the request for u + 2 goes into the set u - 1 has just freed.  72 VGPRs instead of 96; with 32 + 32 accumulators (the current
-// block and the read-out's back-projection), the fp32 B rows, their three planes and the split's temporaries that is what
-// keeps a 32-chain GEMM wave inside its 256 registers.  Static register names need the rotation unrolled over three k-blocks.
+// the request for u + 2 goes into the set u - 1 has just freed.  72 VGPRs instead of 96 (the kernel allocates 243 of 256 with
+// no scratch).  Static register names need the rotation unrolled over three k-blocks.
+// (Round 4 measured the two-chain-tile form of this loop -- CTT = 2, every fragment serving 32 chains, without scratch -- and dropped
+// it: 79 us per 32-chain step against 2 x 35.5, profiles/r04_k1_bounds.txt.)
 template <int NT, int NTT, int CTT, int NW>
 __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nkb, int kw,
                                            const float* B, int ldb, int lane, frag_t (&pre)[NTT], const float* zeros) {
-    static_assert(CTT == 1, "one chain tile per workgroup (the 32-chain forms left the tree in round 4)");
+    static_assert(CTT == 1, "one chain tile per workgroup (two were measured and dropped in round 4: DESIGN.md section 4)");
     constexpr int N0 = NT < 2 ? NT : 2, N1 = NT - N0;            // tiles of group 0 / group 1
     const int c = lane & 15, g = lane >> 4;
     const float* bp = B + c * ldb + 8 * g;

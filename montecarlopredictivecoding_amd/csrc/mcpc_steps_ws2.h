@@ -1,4 +1,4 @@
-// Wave-specialised Langevin step kernel, in-place variant (the default for large shards; 32 chains per workgroup).
+// Wave-specialised Langevin step kernel, in-place variant: the default kernel (16 chains per workgroup, one workgroup per CU).
 //
 // Roles as in mcpc_steps_ws.h: waves 0-3 ("G", one per SIMD) stream weight fragments and issue MFMAs, waves 4-7
 // ("E") run the epilogues.  What differs is how the two roles meet:
@@ -40,15 +40,13 @@ constexpr int kWs2Pairs = MCPC_WS2_PAIRS;          // (G, E) pairs per workgroup
 #define MCPC_WS2_WAVES_PER_EU 2
 #endif
 constexpr int kWs2NT = MCPC_WS2_SPAN / kWs2Pairs;   // unit tiles per pair per table entry: an entry hands out 16 tiles
-// Tiles per pair and entry of a 16-CHAIN workgroup (build-time knob): with one chain tile the same accumulator registers would
-// hold 8 unit tiles, i.e. half as many table entries and hand-overs per step.  Measured (round 2): 6 (the most that compiles
-// without spilling: three fragment sets of NT registers each) and 5 against 4 -- 50.7 / 50.0 / 51.4 us per step at 4096 chains,
-// 76.7 / 76.4 / 76.2 on the mixed schedule at 6000: within the noise, so the hand-over count is not what the 16-chain form
-// pays for, and the default stays 4 (one table layout, 140 KB less code).
+// Tiles per pair and entry (build-time knob).  Measured: 6 (a third group of two tiles in the register rotation) and 5 against 4 --
+// 50.7 / 50.0 / 51.4 us per step at 4096 chains in round 2, 34.9 against 34.4 with the bf16x6 core in round 3: the hand-over count is
+// not what a step pays for, and the default stays 4 (one table layout; mcpc_gemm6.h's rotation is written for at most four).
 #ifndef MCPC_WS2_NT16
 #define MCPC_WS2_NT16 kWs2NT
 #endif
-template <int CTT> constexpr int ws2_nt() { return CTT == 1 ? MCPC_WS2_NT16 : kWs2NT; }
+template <int CTT> constexpr int ws2_nt() { return MCPC_WS2_NT16; }
 constexpr int kWs2Threads = 2 * kWs2Pairs * 64;
 static_assert(kWs2Pairs == 4 || kWs2Pairs == 8, "4 or 8 pairs");
 
@@ -249,9 +247,9 @@ __device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPha
     return lsum;
 }
 
-// MIX: the launch is one half of a mixed schedule -- workgroups take their unit and their step offset from lists
-// (The body is a textual include, shared with mcpc_steps_ws2_mixed_kernel below: wrapped into a device function and inlined, the
-// SAME code compiled about 1 % slower -- other spills, P's fields re-read.)
+// MIX: the launch is one launch of a round-schedule cycle (setup_rounds, mcpc_api.hip) -- workgroups take their unit and the steps it
+// has already done from per-launch lists (KParams::wg_list / wg_rel).
+// (The body is a textual include: wrapped into a device function and inlined, the SAME code compiled about 1 % slower.)
 template <int CTT, bool MIX = false>
 __global__ __launch_bounds__(kWs2Threads, MCPC_WS2_WAVES_PER_EU) void mcpc_steps_ws2_kernel(const KParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];

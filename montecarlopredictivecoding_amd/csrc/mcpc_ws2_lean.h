@@ -15,7 +15,7 @@
 //     per step at 7000 chains);
 //   * three loads per slot whatever the entry type   -> each entry type requests exactly its operands.
 // The arithmetic per element is the generic epilogue's, operation for operation: trajectories stay bitwise those of the
-// other kernel forms (tests/test_gpu_fullsize.py::test_workgroup_variants_agree, the mixed-schedule tests).
+// other kernel forms and schedules (tests/test_gpu_fullsize.py, tests/test_gpu_rounds.py; bench.py self_check).
 //
 // XL (KParams::xl, 16-chain plans whose LDS has the room -- 45 KB more at cfg-M): the state rows x_l of the workgroup's chains, the
 // biases, the mu_1 rows and the bit-packed target rows are copied to LDS when the launch starts (ws2_fill_fx / ws2_fill_constants);
