@@ -21,7 +21,8 @@ Everything in the timed region goes through the C ABI (libmcpc.so); inputs are r
 `roofline` is computed from HIP events the library records on its launch stream (mcpc_set_profiling) during the timed
 calls; its `peak` is the ceiling of the pipe the kernel computes on (fp32 products as six bf16 MFMA products: dense bf16 peak / 6),
 the fp32 MFMA peak SURVEY 8(d) names is carried beside it; `traffic` comes from the tracked PMC summary of the same command
-(profiles/, separate --pmc passes: counters cannot be read inside this run) with its source named.  `cpu_baseline` (rank 0, N = 1 only) times oracle/torch_port.py -- a torch-autograd port with the reference's op
+(profiles/, separate --pmc passes: counters cannot be read inside this run) and is printed only when those passes ran THIS program --
+same kernel sources (mcpc_build_info's csrc hash), batch, T, kernel and launch count -- else null with the reason.  `cpu_baseline` (rank 0, N = 1 only) times oracle/torch_port.py -- a torch-autograd port with the reference's op
 mix -- on the host cores for a bounded sample.
 """
 import argparse
@@ -54,33 +55,45 @@ PEAK_BF16X6_TFLOPS = 2516.0 / 6.0
 # library measures during the timed launches (mcpc_last_shader_clock_ghz: 1.8-2.0 GHz; the 2.4 GHz peak only as a fallback).
 L1_FILL_BYTES_PER_CLK = 64
 PEAK_SHADER_GHZ = 2.4
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
 
 
-def pmc_traffic(mode, kernel_name):
-    """HBM bytes per launch of the step kernel from the tracked PMC summary (scripts/pmc_round.sh + scripts/reduce_pmc.py: separate
-    --pmc passes of this command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads), or None."""
+def pmc_traffic(mode, kernel_name, csrc, batch, T, launches_per_call):
+    """(HBM bytes per launch of the step kernel, None) from the tracked PMC summary -- scripts/pmc_round.sh + scripts/reduce_pmc.py:
+    separate --pmc passes of this command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads -- or (None, reason).
+
+    Counters cannot be read inside this run, so the figure is a MEASUREMENT OF ANOTHER RUN and is only printed when that run was this
+    program: the summary's `meta` (written by the passes themselves from their own bench lines) must name the kernel sources this
+    library was built from (`csrc`: identical csrc/ = identical kernels, whatever the commit), this batch and T, the exact kernel, and
+    the launch count of one call of this schedule.  Anything else -> `traffic: null` with the reason (VERDICT r4 weak #9, ADVICE r4)."""
     try:
         with open(PMC_SUMMARY) as f:
             summ = json.load(f)
-        sect = summ.get(mode) or {}
-        key = next((k for k in sect if k.startswith("mcpc_steps_ws2_kernel") or k in kernel_name), None)
-        if key is None:
-            return None
-        ent = sect[key]
+    except (OSError, ValueError) as exc:
+        return None, "no PMC summary (%s: %s)" % (os.path.relpath(PMC_SUMMARY, ROOT), type(exc).__name__)
+    meta = summ.get("meta") or {}
+    key = re.sub(r"^mcpc::", "", kernel_name.split(" (")[0])
+    for what, got, want in (("csrc", meta.get("csrc"), csrc), ("batch", meta.get("batch"), batch), ("T", meta.get("T"), T)):
+        if got != want:
+            return None, "the PMC summary was collected for %s=%r, this run has %r (re-collect: scripts/pmc_round.sh)" % (what, got, want)
+    ent = (summ.get(mode) or {}).get(key)
+    if ent is None:
+        return None, "the PMC summary has no entry for kernel %r in section %r" % (key, mode)
+    try:
         n, d, c = ent["dispatches"], ent["derived"], ent["counters"]
+        if launches_per_call and n != launches_per_call:
+            return None, "the PMC passes saw %d launches of %s per call, this schedule issues %d" % (n, key, launches_per_call)
         out = {"hbm_read_bytes_per_launch": d["hbm_read_bytes"] / n, "hbm_write_bytes_per_launch": d["hbm_write_bytes"] / n,
                "launches": n, "kernel": key,
-               "source": "profiles/r04_pmc_summary.json, section '%s' (rocprofv3 --pmc passes of `bench.py %s`, builder-run; "
-                         "FETCH_SIZE x 2, WRITE_SIZE as read)" % (mode, "--no-secondary" if mode == "learning" else "--only-inference")}
+               "source": "%s, section '%s' (rocprofv3 --pmc passes of `bench.py %s`, builder-run, same kernel sources as this "
+                         "library: csrc=%s; FETCH_SIZE x 2, WRITE_SIZE as read)" % (
+                             os.path.relpath(PMC_SUMMARY, ROOT), mode, "--no-secondary" if mode == "learning" else "--only-inference", csrc),
+               "meta": meta}
         if "TCC_REQ_sum" in c:
-            # the fragment stream out of L2: requests of 128 B (the call the passes profiled: summ['meta'])
-            out["l2_request_bytes_per_launch"] = c["TCC_REQ_sum"] * 128.0 / n
-        if "meta" in summ:
-            out["meta"] = summ["meta"]
-        return out
-    except (OSError, KeyError, ValueError, StopIteration):
-        return None
+            out["l2_request_bytes_per_launch"] = c["TCC_REQ_sum"] * 128.0 / n       # the fragment stream out of L2: requests of 128 B
+        return out, None
+    except (KeyError, ZeroDivisionError) as exc:
+        return None, "malformed PMC summary entry (%s)" % exc
 
 
 def make_problem(batch, seed, device):
@@ -143,6 +156,11 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="developer check: take the multi-rank code path (RCCL group, barriers, all-reduces) with whatever world size the "
                          "environment gives, 1 included -- the 1-GPU rehearsal of what the driver launches with torch.distributed.run")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (= RCCL over xGMI: what the driver's N > 1 runs use).  gloo: REHEARSAL of the multi-rank branch on ONE GPU "
+                         "(two ranks cannot share a device under RCCL): every rank runs on --rehearsal-device, the collectives are staged "
+                         "through the host -- the line says so and is not a measurement of N GPUs")
+    ap.add_argument("--rehearsal-device", type=int, default=0, help="with --dist-backend gloo: the one device every rank uses")
     args = ap.parse_args()
 
     # stdout carries ONE JSON line and nothing else: libraries that chat on fd 1 (RCCL prints a version banner there when a
@@ -165,14 +183,31 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "gloo":
+            local_rank = args.rehearsal_device
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    rehearsal = dist is not None and args.dist_backend == "gloo"
+
+    def all_reduce(t, op=None):
+        """The job's collective: RCCL on the device tensor; in a gloo rehearsal the tensor is staged through the host."""
+        op = dist.ReduceOp.SUM if op is None else op
+        if rehearsal:
+            host = t.cpu()
+            dist.all_reduce(host, op=op)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=op)
+        return t
 
     from montecarlopredictivecoding_amd import _lib as L
     from montecarlopredictivecoding_amd.engine import Engine
 
+    build, tree_csrc = L.build_info(), L.csrc_sha()
     B, K, Wm, T = args.batch, max(args.steps, 1), max(args.warmup, 0), args.T
     mixing = T // 5
     W, b, y, xs = make_problem(B, 30 + rank, device)
@@ -195,7 +230,7 @@ def main():
         if learning:
             flat = eng.read_param_grads_flat(scale=1.0 / ((T - mixing) * B * world))
             if dist is not None:
-                dist.all_reduce(flat)           # RCCL over xGMI: the path's only exchange step
+                all_reduce(flat)                # RCCL over xGMI: the path's only exchange step
         return res, flat
 
     def timed(learning, n_calls):
@@ -218,7 +253,7 @@ def main():
         eng.set_profiling(False)
         if dist is not None:
             tt = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt, res, plain
 
@@ -283,8 +318,16 @@ def main():
               and self_check["energies_max_rel"] <= 2e-6 and (fa is None or self_check["bucket_max_rel"] <= 1e-5))
         if dist is not None:
             flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag.item())
+            if fa is not None:
+                # the reduced bucket of the timed calls must be the SAME on every rank (one all-reduce, same summation tree)
+                _, bucket = one_call(True)
+                lo, hi = bucket.clone(), bucket.clone()
+                all_reduce(lo, op=dist.ReduceOp.MIN)
+                all_reduce(hi, op=dist.ReduceOp.MAX)
+                self_check["bucket_identical_on_all_ranks"] = bool(torch.equal(lo, hi))
+                ok = ok and self_check["bucket_identical_on_all_ranks"]
         self_check["ok"] = ok
         self_check["ranks_checked"] = world
     if rank == 0:
@@ -303,7 +346,7 @@ def main():
             clk = ghz if ghz and ghz > 0.5 else PEAK_SHADER_GHZ
             l1_peak = L1_FILL_BYTES_PER_CLK * clk
             l1_ach = FRAG_BYTES_PER_WG_STEP * spl * n_wg / wg_per_launch / avg_s / 1e9
-            pmc = pmc_traffic(mode, kernel)
+            pmc, pmc_why = pmc_traffic(mode, kernel, build["csrc"], B, T, round(n / K) if K else 0)
             line = {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16X6_TFLOPS, "unit": "TFLOP/s",
                     "frac": tf / PEAK_BF16X6_TFLOPS,
                     "peak_is": "the ceiling of the pipe this kernel computes on: every fp32 product is six v_mfma_f32_16x16x32_bf16 products "
@@ -312,7 +355,7 @@ def main():
                                   "note": "the fp32 MFMA peak SURVEY 8(d) prescribes for dtype f32; not a ceiling of this kernel"},
                     # HBM bytes per launch from the PMC counters (separate passes of the same command, tracked summary)
                     "traffic": None if pmc is None else pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"],
-                    "traffic_detail": pmc,
+                    "traffic_detail": pmc if pmc is not None else {"traffic_is_null_because": pmc_why},
                     "algorithmic_flop_per_launch": flops_per_step * spl,
                     "brackets": n, "steps_per_bracket": spl,
                     "avg_bracket_ms": avg_s * 1e3, "us_per_step": avg_s / spl * 1e6,
@@ -369,7 +412,7 @@ def main():
                 "workload": "cfg-M: 30-256-256-784 ReLU MCPC, Bernoulli read-out, %d chains/GPU, SGD-x lr 0.03 + Langevin noise var 2; "
                             "bench step = ONE CALL of T = %d Langevin steps (%d mixing + %d sampling), energies every step, "
                             "x every 100 steps; value = n_gpus * steps * T / wall; ms_per_step = ms per call" % (B, T, mixing, T - mixing),
-                "T": T, "mixing": mixing, "sampling": T - mixing, "steps_are": "calls",
+                "T": T, "batch": B, "mixing": mixing, "sampling": T - mixing, "steps_are": "calls",
                 # `dtype` f32: state, weights, energies and sums are fp32; every contraction multiplies fp32 operands as six bf16 MFMA
                 # products (hi/mid/lo pieces, all terms above 2^-24 of the leading one) with fp32 accumulation -- error against fp64 that
                 # of an fp32 MFMA chain, parity tolerances unchanged
@@ -398,7 +441,13 @@ def main():
                 "workgroups": q["n_workgroups"], "spill_slots": q["spill_slots"],
             },
             "roofline": roof,
+            # what was measured: the library says what it is (include/mcpc.h: mcpc_build_info) and whether it is a build of the
+            # kernel sources beside it; self_check fails on a timing-experiment build or on a stale binary
+            "build_info": dict(build, tree_csrc=tree_csrc, built_from_this_tree=build["csrc"] == tree_csrc),
         }
+        if rehearsal:
+            out["rehearsal"] = ("gloo rehearsal of the multi-rank branch: %d ranks share cuda:%d, collectives staged through the host -- NOT "
+                                "a measurement of %d GPUs" % (world, local_rank, world))
         if self_check is not None:
             out["self_check"] = self_check
         if world == 1 and not args.no_cpu_baseline:
@@ -408,6 +457,9 @@ def main():
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
+    if build["exp"] != "0" or build["csrc"] != tree_csrc:
+        sys.stderr.write("bench.py: the loaded library is not a clean build of this tree's kernel sources: %s (tree csrc %s)\n" % (build, tree_csrc))
+        sys.exit(1)
     if self_check is not None and not self_check["ok"]:
         sys.stderr.write("bench.py: SELF-CHECK FAILED: %s\n" % json.dumps(self_check))
         sys.exit(1)

@@ -10,7 +10,7 @@
  *   mcpc_host case.bin out.bin
  *
  * case.bin (little endian): int32 magic 0x4d435043, n_latent, n_in, n_out, batch, T, acc_begin, loss_kind, acts[6], sizes[6];
- *   float lr, noise_var, loss_var; uint64 seed; then float32 arrays: W_j [out_j][in_j], b_j [out_j] for every Linear,
+ *   double lr, noise_var, loss_var (Python floats are doubles: the library rounds them where torch does); uint64 seed; then float32 arrays: W_j [out_j][in_j], b_j [out_j] for every Linear,
  *   target [batch][n_out] (if n_out > 0), x0_l [batch][n_l] for every latent layer.
  * out.bin: double energies [T][8]; float x_l [batch][n_l] per layer; float grads [param_count] (normalised by n_acc * batch).
  *
@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }
     int32_t hdr[8], acts[MCPC_MAX_LATENT], sizes[MCPC_MAX_LATENT];
-    float fl[3];
+    double fl[3];
     uint64_t seed;
     read_exact(hdr, sizeof hdr, f); read_exact(acts, sizeof acts, f); read_exact(sizes, sizeof sizes, f);
     read_exact(fl, sizeof fl, f); read_exact(&seed, sizeof seed, f);
@@ -106,7 +106,7 @@ int main(int argc, char** argv) {
     memset(&rd, 0, sizeof rd);
     rd.T = T; rd.t_begin = 0; rd.n_steps = T;
     rd.loss_kind = loss_kind; rd.loss_var = fl[2];
-    rd.xopt_kind = MCPC_XOPT_SGD; rd.lr = fl[0]; rd.beta1 = 0.9f; rd.beta2 = 0.999f; rd.eps = 1e-8f;
+    rd.xopt_kind = MCPC_XOPT_SGD; rd.lr = fl[0]; rd.beta1 = 0.9; rd.beta2 = 0.999; rd.eps = 1e-8;
     rd.update_x = 1;
     rd.noise_mode = MCPC_NOISE_PHILOX; rd.noise_var = fl[1]; rd.seed = seed; rd.step_base = 0; rd.chain_base = 0;
     rd.acc_begin = acc_begin; rd.acc_end = T; rd.acc_reset = 1;

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MCPC_ABI_VERSION 3
+#define MCPC_ABI_VERSION 4
 #define MCPC_MAX_LATENT 6
 
 /* status codes */
@@ -103,19 +103,23 @@ typedef struct mcpc_run_desc {
     int32_t t_begin;             /* first step executed by this run */
     int32_t n_steps;             /* steps executed by this run (t_begin + n_steps <= T) */
 
+    /* Scalar hyper-parameters are DOUBLES (ABI 4): they are Python floats in the reference, and torch rounds each to fp32 exactly
+     * once, where it is used (alpha = -lr of SGD's add_; 1 - beta1 of Adam's lerp_; -lr / (1 - beta1^t) of its addcdiv_; 1 / _var of
+     * fe_fn).  The library rounds at the same places; an fp32 field would round before the subtraction / division instead
+     * (1 - double(0.9f) != 1 - 0.9). */
     int32_t loss_kind;           /* MCPC_LOSS_* */
-    float loss_var;              /* Gaussian variance (_var) */
     int32_t mask_start;          /* first output column that contributes: n_out - round(n_out*perc); 0 = unmasked */
+    double loss_var;             /* Gaussian variance (_var) */
 
     int32_t xopt_kind;           /* MCPC_XOPT_* */
-    float lr;
-    float beta1, beta2, eps;     /* Adam */
     int32_t adam_step0;          /* Adam step count before this run (0 at the start of a call) */
+    double lr;
+    double beta1, beta2, eps;    /* Adam */
 
     int32_t update_x;            /* 1: fused x update (the fast path). 0: gradients only -> xgrad (generic callbacks) */
 
     int32_t noise_mode;          /* MCPC_NOISE_* */
-    float noise_var;             /* random_step's `var` (2.0 = correct Langevin) */
+    double noise_var;            /* random_step's `var` (2.0 = correct Langevin) */
     uint64_t seed;               /* Philox key */
     uint64_t step_base;          /* Philox step counter of step 0 of this call (advances across calls) */
     uint64_t chain_base;         /* global id of this shard's first chain (sharding-invariant noise) */
@@ -136,6 +140,13 @@ typedef struct mcpc_run_desc {
 
 /* lifetime -------------------------------------------------------------------------------- */
 int mcpc_abi_version(void);
+/* What this binary is (ABI 4; nothing in the reference to mirror): one line of space-separated key=value words,
+ *   "libmcpc abi=4 arch=gfx950 csrc=<sha256[:16] of the kernel sources + this header> commit=<git short hash[+dirty]|unknown>
+ *    exp=0|1 stamps=0|1 flags=[<compiler flags>]"
+ * exp=1: the library was built with a timing-experiment switch (csrc/mcpc_build.h: it computes WRONG results on purpose and must
+ * never be tested or benchmarked as the product; the Python binding refuses it, bench.py asserts exp=0).  stamps=1: the diagnostic
+ * build with in-kernel phase stamps (correct results).  The string is static storage, valid for the life of the process. */
+const char* mcpc_build_info(void);
 const char* mcpc_last_error(void);
 int mcpc_create(const mcpc_net_desc* desc, mcpc_engine** out);
 int mcpc_destroy(mcpc_engine* e);

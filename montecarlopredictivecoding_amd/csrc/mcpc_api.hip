@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "mcpc_build.h"
 #include "mcpc_kernels.h"
 
 using namespace mcpc;
@@ -670,6 +671,18 @@ int setup_rounds(mcpc_engine* e, int n_cu) {
 extern "C" {
 
 int mcpc_abi_version(void) { return MCPC_ABI_VERSION; }
+
+const char* mcpc_build_info(void) {
+    // exp: the umbrella of mcpc_build.h, and -- should a switch ever be added without being listed there -- any -DMCPC_EXP / MCPC_HEB_EXP
+    // in the flags the Makefile recorded
+    static const bool exp = MCPC_TIMING_BUILD != 0 || std::strstr(MCPC_BUILD_FLAGS, "MCPC_EXP") != nullptr ||
+                            std::strstr(MCPC_BUILD_FLAGS, "MCPC_HEB_EXP") != nullptr;
+    static char buf[1024];
+    static const int n = std::snprintf(buf, sizeof buf, "libmcpc abi=%d arch=gfx950 csrc=%s commit=%s exp=%d stamps=%d flags=[%s]",
+                                       MCPC_ABI_VERSION, MCPC_BUILD_CSRC_SHA, MCPC_BUILD_COMMIT, exp ? 1 : 0, MCPC_STAMPS_BUILD, MCPC_BUILD_FLAGS);
+    (void)n;
+    return buf;
+}
 const char* mcpc_last_error(void) { return g_err.c_str(); }
 
 int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
@@ -708,7 +721,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     for (int l = 0; l < e->L; ++l) e->npad[l] = pad16(d->sizes[l]);
     e->out_pad = pad16(d->n_out);
     // The back-projection of the read-out error is accumulated in registers over the whole read-out: 16 tiles per workgroup
-    // (a last latent layer of up to 256 units) for the barrier kernel, 32 tiles (512 units) for the in-place kernel.
+    // (a last latent layer of up to 256 units) in both kernels (cap_ws2 = 4 GEMM waves x 4 tiles, cap_bar = 4 waves x 4 tiles).
     const int last_tiles = e->has_head ? e->npad[e->L - 1] / 16 : 0;
     const int cap_ws2 = kWs2Pairs * ws2_nt<1>(), cap_bar = kNT * kWaves;
     if (last_tiles > std::max(cap_ws2, cap_bar) || (last_tiles > cap_bar && e->ws != 2)) {
@@ -1172,15 +1185,15 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     if (r->loss_kind != MCPC_LOSS_NONE) {
         if (!e->has_head) return fail(MCPC_EINVAL, "a loss needs a read-out Linear (n_out > 0)");
         if (!e->target_bound) return fail(MCPC_ESTATE, "loss requested but no target bound");
-        if (r->loss_kind == MCPC_LOSS_GAUSSIAN && !(r->loss_var > 0.f)) return fail(MCPC_EINVAL, "loss_var must be positive");
+        if (r->loss_kind == MCPC_LOSS_GAUSSIAN && !(r->loss_var > 0.0)) return fail(MCPC_EINVAL, "loss_var must be positive");
         if (r->mask_start < 0 || r->mask_start >= e->d.n_out) return fail(MCPC_EINVAL, "mask_start=%d outside 0..%d", r->mask_start, e->d.n_out - 1);
     }
     if (r->xopt_kind != MCPC_XOPT_SGD && r->xopt_kind != MCPC_XOPT_ADAM) return fail(MCPC_EINVAL, "xopt_kind=%d", r->xopt_kind);
-    if (!(r->lr > 0.f)) return fail(MCPC_EINVAL, "lr must be positive");
+    if (!(r->lr > 0.0)) return fail(MCPC_EINVAL, "lr must be positive");
     if (r->noise_mode < 0 || r->noise_mode > 2) return fail(MCPC_EINVAL, "noise_mode=%d", r->noise_mode);
     if (r->noise_mode != MCPC_NOISE_NONE && r->xopt_kind != MCPC_XOPT_SGD)
         return fail(MCPC_EINVAL, "the fused Langevin kick is defined for SGD on x only (reference utils/model.py:35-44 steps the same optimizer)");
-    if (r->noise_mode != MCPC_NOISE_NONE && !(r->noise_var >= 0.f)) return fail(MCPC_EINVAL, "noise_var must be >= 0");
+    if (r->noise_mode != MCPC_NOISE_NONE && !(r->noise_var >= 0.0)) return fail(MCPC_EINVAL, "noise_var must be >= 0");
     if (r->noise_mode == MCPC_NOISE_EXTERNAL)
         for (int l = 0; l < e->L; ++l)
             if (!r->ext_noise[l]) return fail(MCPC_EINVAL, "ext_noise[%d] is null", l);
@@ -1221,10 +1234,10 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         float* tab = e->adam_host[hb];
         for (int s = 0; s < r->n_steps; ++s) {
             const double step = (double)(r->adam_step0 + s + 1);
-            const double bc1 = 1.0 - std::pow((double)r->beta1, step);
-            const double bc2 = 1.0 - std::pow((double)r->beta2, step);
-            tab[2 * s] = (float)((double)r->lr / bc1);
-            tab[2 * s + 1] = (float)(1.0 / std::sqrt(bc2));
+            const double bc1 = 1.0 - std::pow(r->beta1, step);
+            const double bc2 = 1.0 - std::pow(r->beta2, step);
+            tab[2 * s] = (float)(-(r->lr / bc1));         // addcdiv_'s value = -step_size, a python double rounded to fp32 once
+            tab[2 * s + 1] = (float)std::sqrt(bc2);              // bias_correction2_sqrt, likewise
         }
         HIP_TRY(hipMemcpyAsync(e->adam_coef, tab, need * sizeof(float), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipEventRecord(e->adam_ev[hb], stream));
@@ -1295,7 +1308,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         H.spill_tm = e->lin[e->L].spill_tm ? 1 : 0;
         H.n = e->d.n_out; H.npad = e->out_pad; H.ntiles = e->out_pad / 16;
         H.loss_kind = r->loss_kind;
-        H.inv_var = r->loss_kind == MCPC_LOSS_GAUSSIAN ? (float)(1.0 / (double)r->loss_var) : 1.0f;
+        H.inv_var = r->loss_kind == MCPC_LOSS_GAUSSIAN ? (float)(1.0 / r->loss_var) : 1.0f;
         H.mask_start = r->loss_kind == MCPC_LOSS_NONE ? 0 : r->mask_start;
         H.lds_eo = e->lds_eo; H.ld = kChunkTiles * 16 + kLdPad;
         H.lds_bias = e->lds_hbias; H.lds_yw = e->lds_yw;
@@ -1305,10 +1318,10 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     P.stagger_cycles = e->knobs.stagger;
     P.L = e->L; P.has_head = e->has_head; P.B = e->d.batch; P.Bpad = e->Bpad; P.T = r->T;
     P.xopt = r->xopt_kind; P.update_x = r->update_x ? 1 : 0;
-    P.lr = r->lr; P.beta2 = r->beta2;
-    P.omb1 = (float)(1.0 - (double)r->beta1); P.omb2 = (float)(1.0 - (double)r->beta2); P.eps = r->eps;
+    P.lr = (float)r->lr; P.beta2 = (float)r->beta2;
+    P.omb1 = (float)(1.0 - r->beta1); P.omb2 = (float)(1.0 - r->beta2); P.eps = (float)r->eps;
     P.noise_mode = r->update_x ? r->noise_mode : MCPC_NOISE_NONE;
-    P.noise_scale = (float)std::sqrt((double)r->noise_var * (double)r->lr);
+    P.noise_scale = (float)std::sqrt(r->noise_var * r->lr);
     P.seed = r->seed; P.step_base = r->step_base; P.chain_base = r->chain_base;
     P.acc_begin = acc_b; P.acc_end = acc_e;
     P.energy_mode = r->energy_mode;

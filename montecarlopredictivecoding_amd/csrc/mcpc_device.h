@@ -65,13 +65,21 @@ __device__ __forceinline__ float act_d(int a, float x, float fx) {
     return a == 1 ? (x > 0.0f ? 1.0f : 0.0f) : (a == 2 ? 1.0f - fx * fx : 1.0f);
 }
 
-// Adam's x update, x - step_size * m / (sqrt(v) / sqrt(bias2) + eps) (torch.optim.Adam: addcdiv_), with v_sqrt_f32 and
-// v_rcp_f32 (1 ulp each) instead of the IEEE-refined sqrtf and division: those cost ~27 VALU instructions per element, 16 us of
-// a 109 us MAP step at cfg-M (fp32 MFMA and VALU share one pipe).  The denominator is >= eps, far inside the normal range;
-// a denormal v (|g| < 1e-19) is below eps by 11 orders of magnitude either way.
-__device__ __forceinline__ float adam_x(float x, float m, float v, float step_size, float inv_bc2, float eps) {
-    return x - step_size * (m * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * inv_bc2 + eps));
+// Adam's x update, operation for operation what torch.optim.Adam's single-tensor path does (torch/optim/adam.py, _single_tensor_adam):
+//     denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps);  param.addcdiv_(exp_avg, denom, value=-step_size)
+// i.e. x + ((-step_size) * m) / (sqrt(v) / sqrt(bias2) + eps) -- addcdiv multiplies by the scalar FIRST and divides second (ATen
+// PointwiseOpsKernel: self + alpha * t1 / t2) -- with a correctly rounded square root and two correctly rounded divisions (hipcc's
+// default for HIP: -fhip-fp32-correctly-rounded-divide-sqrt).  Rounds 1-4 used v_sqrt_f32 / v_rcp_f32 (1 ulp each, ~27 VALU
+// instructions per element fewer) and held the MAP path's energies to 3e-6 instead of 1e-6; the epilogue waves hide their arithmetic
+// behind the GEMM waves (profiles/r04_k1_bounds.txt items 3, 8), so the exact forms cost nothing measurable.
+__device__ __forceinline__ float adam_x(float x, float m, float v, float neg_step_size, float bc2_sqrt, float eps) {
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    return x + (neg_step_size * m) / denom;
 }
+// the moments, as torch updates them: exp_avg.lerp_(grad, 1 - beta1) = fma(w, g - m, m) (ATen lerp, weight < 0.5);
+// exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2) = fma((1 - beta2) * g, g, v * beta2)
+__device__ __forceinline__ float adam_m(float m, float g, float omb1) { return __builtin_fmaf(omb1, g - m, m); }
+__device__ __forceinline__ float adam_v(float v, float g, float beta2, float omb2) { return __builtin_fmaf(omb2 * g, g, v * beta2); }
 
 __device__ __forceinline__ float sigmoid_f(float o) {
     // same arithmetic as sigmoid_bce_f below, so that recording the loss never changes a trajectory

@@ -111,7 +111,7 @@ struct KParams {
     int n_phases;
     int stagger_cycles;    // workgroups >= 256 (the second resident on a CU) start this many cycles late
     const float* mu1;      // prediction of the top latent layer [Bpad][npad_0] (inputs W0^T + b0)
-    const float* adam_coef;// [n_steps][2]: step_size = lr/(1-b1^t), 1/sqrt(1-b2^t)
+    const float* adam_coef;// [n_steps][2]: -step_size = -lr/(1-b1^t), sqrt(1-b2^t)
     double* epart;         // [energy rows][nWG][kEnergyCols] per-workgroup partial sums
     int L, has_head;
     int B, Bpad;
@@ -441,15 +441,15 @@ __device__ __forceinline__ void bwd_epilogue(const KParams& P, const KPhase& ph,
                     // torch.optim.Adam single-tensor path: lerp_, mul_/addcmul_, sqrt/bias2 + eps, addcdiv_ (adam_x, mcpc_device.h)
                     const size_t mrow = tile_major_offset(chain, u0, npad);      // (tile-major: see tile_major_offset)
                     f32x4 m = ld4s(Ly.m + mrow), v = ld4s(Ly.v + mrow);
-                    m = m + (g - m) * P.omb1;
-                    v = v * P.beta2 + (g * g) * P.omb2;
+                    m.x = adam_m(m.x, g.x, P.omb1); m.y = adam_m(m.y, g.y, P.omb1); m.z = adam_m(m.z, g.z, P.omb1); m.w = adam_m(m.w, g.w, P.omb1);
+                    v.x = adam_v(v.x, g.x, P.beta2, P.omb2); v.y = adam_v(v.y, g.y, P.beta2, P.omb2); v.z = adam_v(v.z, g.z, P.beta2, P.omb2); v.w = adam_v(v.w, g.w, P.beta2, P.omb2);
                     st4s(Ly.m + mrow, m);
                     st4s(Ly.v + mrow, v);
-                    const float step_size = P.adam_coef[2 * s], inv_bc2 = P.adam_coef[2 * s + 1], eps = P.eps;
-                    xn.x = adam_x(x.x, m.x, v.x, step_size, inv_bc2, eps);
-                    xn.y = adam_x(x.y, m.y, v.y, step_size, inv_bc2, eps);
-                    xn.z = adam_x(x.z, m.z, v.z, step_size, inv_bc2, eps);
-                    xn.w = adam_x(x.w, m.w, v.w, step_size, inv_bc2, eps);
+                    const float nss = P.adam_coef[2 * s], bc2s = P.adam_coef[2 * s + 1], eps = P.eps;
+                    xn.x = adam_x(x.x, m.x, v.x, nss, bc2s, eps);
+                    xn.y = adam_x(x.y, m.y, v.y, nss, bc2s, eps);
+                    xn.z = adam_x(x.z, m.z, v.z, nss, bc2s, eps);
+                    xn.w = adam_x(x.w, m.w, v.w, nss, bc2s, eps);
                 }
                 if (P.noise_mode == MCPC_NOISE_PHILOX) {
                     xn = xn + normals4(seed, step, (uint32_t)l, (uint32_t)(chain_base + (uint64_t)chain), (uint32_t)(u0 >> 2)) * nscale;

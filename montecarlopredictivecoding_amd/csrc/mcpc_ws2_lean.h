@@ -329,16 +329,16 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
             if constexpr (ADAM) {
                 // torch.optim.Adam single-tensor path: lerp_, mul_/addcmul_, sqrt/bias2 + eps, addcdiv_ (adam_x, mcpc_device.h)
                 f32x4 m = mv[i][ct], v = vv[i][ct];
-                m = m + (g - m) * P.omb1;
-                v = v * P.beta2 + (g * g) * P.omb2;
+                m.x = adam_m(m.x, g.x, P.omb1); m.y = adam_m(m.y, g.y, P.omb1); m.z = adam_m(m.z, g.z, P.omb1); m.w = adam_m(m.w, g.w, P.omb1);
+                v.x = adam_v(v.x, g.x, P.beta2, P.omb2); v.y = adam_v(v.y, g.y, P.beta2, P.omb2); v.z = adam_v(v.z, g.z, P.beta2, P.omb2); v.w = adam_v(v.w, g.w, P.beta2, P.omb2);
                 const uint32_t mb = (mul24(L.chain[ct] >> 4, (uint32_t)Ly.ntiles) + (uint32_t)tile) * 1024u + 16u * (uint32_t)(L.c + 16 * L.q);
                 gst4s(Ly.m, mb, m);
                 gst4s(Ly.v, mb, v);
-                const float step_size = P.adam_coef[2 * s_tab], inv_bc2 = P.adam_coef[2 * s_tab + 1], eps = P.eps;
-                xn.x = adam_x(x.x, m.x, v.x, step_size, inv_bc2, eps);
-                xn.y = adam_x(x.y, m.y, v.y, step_size, inv_bc2, eps);
-                xn.z = adam_x(x.z, m.z, v.z, step_size, inv_bc2, eps);
-                xn.w = adam_x(x.w, m.w, v.w, step_size, inv_bc2, eps);
+                const float nss = P.adam_coef[2 * s_tab], bc2s = P.adam_coef[2 * s_tab + 1], eps = P.eps;
+                xn.x = adam_x(x.x, m.x, v.x, nss, bc2s, eps);
+                xn.y = adam_x(x.y, m.y, v.y, nss, bc2s, eps);
+                xn.z = adam_x(x.z, m.z, v.z, nss, bc2s, eps);
+                xn.w = adam_x(x.w, m.w, v.w, nss, bc2s, eps);
             } else {
                 xn = x - g * lr;
             }

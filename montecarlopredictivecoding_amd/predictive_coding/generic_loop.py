@@ -46,6 +46,12 @@ def run_generic(tr, reason, *, inputs, loss_fn, loss_fn_kwargs, is_sample_x_at_b
         "loop (reference semantics on torch autograd, one Python iteration per step: orders of magnitude slower than the fused "
         "kernels), this will slow down training. Reason: {}. ".format(reason), category=RuntimeWarning)
     T = tr._T
+    sharded = bool(getattr(tr, "mcpc_sharded", False))
+    if sharded and tr._early_stop_condition.strip() != "False":
+        # a condition evaluated on one shard's values could end the call on one rank and not on another: the ranks' collectives
+        # (one per parameter step) would no longer match
+        raise NotImplementedError("an early_stop_condition on a set_shard() trainer is not supported: the ranks could leave the loop at "
+                                  "different steps")
     layers = list(tr.get_model_pc_layers())
     has_layers = len(layers) > 0
     unwrap = ""
@@ -138,8 +144,23 @@ def run_generic(tr, reason, *, inputs, loss_fn, loss_fn_kwargs, is_sample_x_at_b
                     for group in tr._optimizer_x.param_groups:
                         group["lr"] = group["lr"] * factor
         if p_step:
-            div = len(tr._accumulate_p_at) * n_batch if tr._accumulate_p_at else n_batch
-            for p in tr.get_model_parameters():
+            params = list(tr.get_model_parameters())
+            if sharded:
+                # one shard of a larger batch (set_shard): the parameter gradients are sums over the chains, so the shards' sums are
+                # all-reduced as ONE flat bucket and divided by the job-wide batch -- what the fused path does (pc_trainer._apply_p_step);
+                # without this every rank would train its own replica
+                from .. import dist
+                flat = torch.cat([(torch.zeros_like(p) if p.grad is None else p.grad).reshape(-1) for p in params])
+                dist.allreduce_flat(flat, tr.mcpc_process_group)
+                n_global = tr._global_batch(n_batch)
+                off = 0
+                for p in params:
+                    p.grad = flat[off:off + p.numel()].view_as(p).clone()
+                    off += p.numel()
+            else:
+                n_global = n_batch
+            div = len(tr._accumulate_p_at) * n_global if tr._accumulate_p_at else n_global
+            for p in params:
                 p.grad = p.grad / div
             tr._optimizer_p.step()
         if callback_after_t is not None:
@@ -153,4 +174,15 @@ def run_generic(tr, reason, *, inputs, loss_fn, loss_fn_kwargs, is_sample_x_at_b
                         "when leaving <callback_after_t()>. ")
         if early_stop:          # the step that met the condition is completed (its parameter step included), then the call ends
             break               # (pc_trainer.py:979-981)
+    if sharded and tr.mcpc_reduce_results:
+        # set_shard(reduce_results=True): loss / energy / overall are sums over the chains -- those of the WHOLE batch, as in the
+        # reference (pc_layer.py:295), after one all-reduce of the call's table
+        from .. import dist
+        keys = [k for k in ("loss", "energy", "overall") if results[k]]
+        if keys:
+            dev = next(tr._model.parameters()).device
+            table = torch.tensor([results[k] for k in keys], dtype=torch.float64, device=dev)
+            dist.allreduce_flat(table, tr.mcpc_process_group)
+            for k, row in zip(keys, table.cpu().tolist()):
+                results[k] = row
     return results

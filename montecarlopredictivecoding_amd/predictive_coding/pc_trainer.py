@@ -24,7 +24,12 @@ generic   anything the kernels do not express (S/M masks, non-quadratic ``energy
           that are not the Sequential chain ...: SURVEY section 8b, "must work, need not be fast") runs on the
           package's own torch-autograd restatement of the reference's step (``generic_loop.py``) and says so with
           a RuntimeWarning naming the reason -- never silently, and never for a call the engine can run.
-rejected  a model on the CPU (there is no CPU path: ``MCPCLibraryError``) and ``plot_progress`` (out of scope).
+staged    (round 5) a model built on the CPU -- how most of the reference's call sites are written (figure_2.py:29-75,
+          figure_4.py:537, figure_5.py:25-27, figure_6.py:55-93: ``use_cuda = False`` or no ``.cuda()`` at all) -- is not refused:
+          W, b, x, inputs and the target (a few MB) are copied to the MI355X, the SAME fused / step-wise HIP path runs there,
+          and x, the results and ``param.grad`` come back to the CPU tensors the script holds (``plan["staged"]``; one
+          RuntimeWarning per trainer).  The computation never runs on the CPU: without a visible HIP device the call raises.
+rejected  any call when no HIP device is visible (there is no CPU path: ``MCPCLibraryError``) and ``plot_progress`` (out of scope).
 """
 import collections
 import os
@@ -42,6 +47,7 @@ from ..engine import Engine
 from . import recognise
 from .generic_loop import run_generic
 from .pc_layer import PCLayer
+from .utils import slow_down_warning
 
 
 # Philox step counter shared by every trainer of the process: consecutive calls never reuse noise,
@@ -60,13 +66,6 @@ def _take_philox_steps(n):
     base = _PHILOX_STEPS[0]
     _PHILOX_STEPS[0] += int(n)
     return base
-
-
-def slow_down_warning(base, prop, solution):
-    """Same message as the reference (predictive_coding/utils.py:8-16)."""
-    warnings.warn(
-        "In {}, you have {} enabled, this will slow down training. Set to {} to disable it. ".format(base, prop, solution),
-        category=RuntimeWarning)
 
 
 class PCTrainer(object):
@@ -388,12 +387,13 @@ class PCTrainer(object):
                                          callback_after_backward, callback_after_t, callback_after_t_kwargs,
                                          backward_kwargs, is_clear_energy_after_use, is_return_batchelement_loss)
         if plan is None:
-            # outside what the kernels express: the package's generic torch loop (generic_loop.py), loudly.  Not on the CPU: the
-            # engine has no CPU path and the generic loop is not a way around that.
-            dev = next((p.device for p in self._model.parameters()), None)
-            if (dev is None or dev.type != "cuda") and not self._test_only_generic_on_cpu:
+            # outside what the kernels express: the package's generic torch loop (generic_loop.py), loudly, on the device the model
+            # lives on ("must work, need not be fast").  It is no way around a missing GPU: without a visible HIP device
+            # every call raises, whatever path it would have taken.
+            if not torch.cuda.is_available() and not self._test_only_generic_on_cpu:
+                dev = next((p.device for p in self._model.parameters()), None)
                 raise L.MCPCLibraryError(
-                    "the model lives on %s: the MCPC engine runs on an MI355X only (move the model and inputs to 'cuda'); "
+                    "no HIP device is visible (the model lives on %s): the MCPC engine runs on an MI355X only; "
                     "there is no CPU path" % dev)
             self.last_call_mode = "generic"
             return run_generic(
@@ -461,21 +461,31 @@ class PCTrainer(object):
             return None, f"inputs must be a [batch, {net.n_in}] tensor"
         if inputs.dtype != torch.float32:
             return None, "inputs must be float32"
-        device = net.linears[0].weight.device
-        if device.type != "cuda":
-            raise L.MCPCLibraryError(
-                "the model lives on %s: the MCPC engine runs on an MI355X only (move the model and inputs to 'cuda'); "
-                "there is no CPU path" % device)
-        if inputs.device != device:
-            return None, f"inputs on {inputs.device}, model on {device}"
+        model_device = net.linears[0].weight.device
+        if any(p.device != model_device for lin in net.linears for p in lin.parameters()):
+            return None, "the model's parameters live on several devices"
+        staged = model_device.type != "cuda"
+        if staged:
+            # a model built on the CPU (figure_2.py:29-75, figure_4.py:537, figure_5.py:25-27, figure_6.py:55-93): its tensors are
+            # staged onto the MI355X for the call and the results written back -- the computation itself has no CPU form
+            if not torch.cuda.is_available():
+                raise L.MCPCLibraryError(
+                    "the model lives on %s and no HIP device is visible: the MCPC engine runs on an MI355X only; "
+                    "there is no CPU path" % model_device)
+            device = torch.device("cuda", torch.cuda.current_device())
+        else:
+            device = model_device
+        if inputs.device != model_device:
+            return None, f"inputs on {inputs.device}, model on {model_device}"
         B = inputs.shape[0]
-        loss, why = recognise.describe_loss(loss_fn, loss_fn_kwargs, net.n_out, B, device)
+        loss, why = recognise.describe_loss(loss_fn, loss_fn_kwargs, net.n_out, B, model_device)
         if loss is None:
             return None, why
         if loss.target is not None:
             if tuple(loss.target.shape) != (B, net.n_out):
                 return None, f"_target must have shape {(B, net.n_out)}"
-        plan = dict(net=net, loss=loss, B=B, device=device)
+        # plan["device"]: where the engine runs; plan["model_device"]: where the script's tensors live (the same unless staged)
+        plan = dict(net=net, loss=loss, B=B, device=device, model_device=model_device, staged=staged)
         # ---- can the whole loop be fused? otherwise fall to the step-wise HIP path
         reasons = []
         xopt, why = (None, "manual_optimizer_x_fn is set") if self._manual_optimizer_x_fn is not None else \
@@ -516,7 +526,23 @@ class PCTrainer(object):
             _ENGINES.move_to_end(key)
         return eng
 
-    def _sync_params(self, eng: Engine, net, force=False):
+    def _announce_staging(self, plan):
+        if plan["staged"] and not getattr(self, "_staging_announced", False):
+            self._staging_announced = True
+            warnings.warn(
+                "In PCTrainer.train_on_batch, the model lives on {}: its parameters, latent states, inputs and targets are staged onto {} "
+                "for every call, the MCPC HIP engine runs there, and x, the results and param.grad are written back to the {} tensors "
+                "(a few MB over PCIe per call; move the model to 'cuda' to avoid the copies). ".format(
+                    plan["model_device"], plan["device"], plan["model_device"]), category=RuntimeWarning)
+
+    @staticmethod
+    def _on_engine(plan, t):
+        """The tensor the engine is handed for a tensor of the script: itself, or its copy on the engine's device when staged."""
+        if t is None:
+            return None
+        return t.to(plan["device"]).contiguous() if plan["staged"] else t
+
+    def _sync_params(self, eng: Engine, net, force=False, plan=None):
         """(Re)bind + re-pack the Linear parameters when their storage or contents changed."""
         sig = tuple((lin.weight.data_ptr(), lin.weight._version,
                      None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version)) for lin in net.linears)
@@ -526,8 +552,14 @@ class PCTrainer(object):
             for lin in net.linears:
                 if not lin.weight.is_contiguous():
                     lin.weight.data = lin.weight.data.contiguous()
-            eng.bind_params([lin.weight.data for lin in net.linears],
-                            [None if lin.bias is None else lin.bias.data for lin in net.linears])
+            if plan is not None and plan["staged"]:
+                # staged model: the engine is bound to device copies (kept alive by the engine), refreshed whenever the CPU parameters
+                # change (an optimizer_p step bumps their version)
+                eng.bind_params([self._on_engine(plan, lin.weight.data) for lin in net.linears],
+                                [None if lin.bias is None else self._on_engine(plan, lin.bias.data) for lin in net.linears])
+            else:
+                eng.bind_params([lin.weight.data for lin in net.linears],
+                                [None if lin.bias is None else lin.bias.data for lin in net.linears])
             # (contiguous() above may have replaced storage: take the signature after binding)
             eng._bound_sig = tuple((lin.weight.data_ptr(), lin.weight._version,
                                     None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
@@ -544,7 +576,7 @@ class PCTrainer(object):
             # shapes are only known after Linear j; check against the expected [B, n_l]
             for l, layer in enumerate(layers):
                 x = layer.get_x()
-                if x is None or x.device != plan["device"] or tuple(x.shape) != (plan["B"], net.sizes[l]):
+                if x is None or x.device != plan["model_device"] or tuple(x.shape) != (plan["B"], net.sizes[l]):
                     need = True     # the layer's own forward emits the reference's RuntimeWarning
         if need:
             if is_sample_x_at_batch_start:
@@ -593,10 +625,11 @@ class PCTrainer(object):
         n_rec = T if is_return_results_every_t else 1
         if is_return_outputs:
             src = res.rec_out if net.n_out > 0 else res.rec_x[-1]
-            if src.device != plan["device"]:
-                # sliced recording drains latent records to pinned host memory; `outputs` are live device tensors in the reference
-                # (pc_trainer.py:733,770) whatever mcpc_record_chunk_bytes is: a model without a read-out gets them back there
-                src = src.to(plan["device"])
+            if src.device != plan["model_device"]:
+                # sliced recording drains latent records to pinned host memory; `outputs` are live tensors on the model's device in the
+                # reference (pc_trainer.py:733,770) whatever mcpc_record_chunk_bytes is: a model without a read-out gets them back
+                # there; so does a staged (CPU) model
+                src = src.to(plan["model_device"])
             results["outputs"] = [src[k] for k in range(n_rec)]
         if is_return_representations:
             host = res.rec_x[0].cpu()
@@ -619,8 +652,26 @@ class PCTrainer(object):
             flat = eng.read_param_grads_flat(scale=dist.grad_scale(n_acc, self._global_batch(plan["B"])))
             if self.mcpc_sharded:
                 dist.allreduce_flat(flat, self.mcpc_process_group)     # RCCL: one bucket per call
+        if plan["staged"]:
+            flat = flat.to(plan["model_device"])      # param.grad lives where the script's parameters (and its optimizer_p) live
         dist.assign_flat_grads(net.linears, flat)
         self._optimizer_p.step()
+
+    def _add_param_grads(self, plan, eng, j, lin, accumulate):
+        """dF/dtheta of Linear j (the engine's un-normalised sums) into ``.grad``: overwritten, or added like autograd does."""
+        if lin.weight.grad is None:
+            lin.weight.grad = torch.zeros_like(lin.weight)
+        if lin.bias is not None and lin.bias.grad is None:
+            lin.bias.grad = torch.zeros_like(lin.bias)
+        if not plan["staged"]:
+            eng.read_param_grads(j, lin.weight.grad, None if lin.bias is None else lin.bias.grad, 1.0, accumulate=accumulate)
+            return
+        dW = torch.empty(lin.weight.shape, dtype=torch.float32, device=plan["device"])
+        db = None if lin.bias is None else torch.empty(lin.bias.shape, dtype=torch.float32, device=plan["device"])
+        eng.read_param_grads(j, dW, db, 1.0, accumulate=False)
+        for g, d in ((lin.weight.grad, dW), (None if lin.bias is None else lin.bias.grad, db)):
+            if g is not None:
+                g.add_(d.to(g.device)) if accumulate else g.copy_(d)
 
     # ---- fused path ---------------------------------------------------------------------------------------
     def _run_fused(self, plan, inputs, loss_fn, is_sample_x_at_batch_start, is_reset_optimizer_x_at_batch_start,
@@ -633,14 +684,16 @@ class PCTrainer(object):
             self.recreate_optimize_x()          # kept for API compatibility (get_optimizer_x); never stepped here
         if is_reset_optimizer_p_at_batch_start:
             self.recreate_optimize_p()
-        self._sync_params(eng, net)
-        eng.bind_inputs(None if not bool(inputs.any()) else inputs.contiguous())
+        self._announce_staging(plan)
+        self._sync_params(eng, net, plan=plan)
+        eng.bind_inputs(None if not bool(inputs.any()) else self._on_engine(plan, inputs.contiguous()))
         if loss.target is not None:
             tgt = loss.target
             if tgt.dtype != torch.float32 or not tgt.is_contiguous() or tgt.device != plan["device"]:
                 tgt = tgt.to(device=plan["device"], dtype=torch.float32).contiguous()
             eng.bind_target(tgt)
-        eng.load_state([x.data for x in xs])
+        xs_eng = [self._on_engine(plan, x.data) for x in xs]          # the script's own tensors, or their device copies when staged
+        eng.load_state(xs_eng)
 
         do_update = self._T - 1 in self._update_p_at
         start = self._grad_window()
@@ -676,26 +729,24 @@ class PCTrainer(object):
         else:
             res = eng.run(T, acc_reset=acc_reset, rec_begin=rec_begin, rec_stride=1, rec_count=n_rec if any_rec else 0,
                           rec_x=rec_layers, rec_out=is_return_outputs and net.n_out > 0, **run_kw)
-        eng.store_state([x.data for x in xs])
+        eng.store_state(xs_eng)
+        if plan["staged"]:
+            for x, d in zip(xs, xs_eng):
+                x.data.copy_(d)                 # x back into the CPU nn.Parameters the script holds (PCLayer.get_x())
         if xopt.kind == L.XOPT_ADAM and isinstance(self._optimizer_x, optim.Adam):
             # the reference's optimizer_x object outlives the call (pc_trainer.py:742-752 recreates it only behind a flag):
             # leave it in the state T fused steps produce, so that a later call that keeps it continues correctly
-            ms = [torch.empty_like(x.data) for x in xs]
-            vs = [torch.empty_like(x.data) for x in xs]
+            ms = [torch.empty_like(d) for d in xs_eng]
+            vs = [torch.empty_like(d) for d in xs_eng]
             eng.store_adam_state(ms, vs)
             for x, m_, v_ in zip(xs, ms, vs):
-                self._optimizer_x.state[x] = {"step": torch.tensor(float(T)), "exp_avg": m_, "exp_avg_sq": v_}
+                self._optimizer_x.state[x] = {"step": torch.tensor(float(T)), "exp_avg": m_.to(x.device), "exp_avg_sq": v_.to(x.device)}
         if do_update:
             self._apply_p_step(plan, eng, net, len(self._accumulate_p_at))
-            self._sync_params(eng, net, force=True)
+            self._sync_params(eng, net, force=True, plan=plan)
         elif self.mcpc_materialize_unused_grads:
             for j, lin in enumerate(net.linears):
-                if lin.weight.grad is None:
-                    lin.weight.grad = torch.zeros_like(lin.weight)
-                if lin.bias is not None and lin.bias.grad is None:
-                    lin.bias.grad = torch.zeros_like(lin.bias)
-                eng.read_param_grads(j, lin.weight.grad, None if lin.bias is None else lin.bias.grad, 1.0,
-                                     accumulate=start is None)
+                self._add_param_grads(plan, eng, j, lin, accumulate=start is None)
         return self._collect_results(plan, res, T, is_return_results_every_t, is_return_outputs,
                                      is_return_representations, is_return_xs, loss_fn)
 
@@ -753,7 +804,8 @@ class PCTrainer(object):
             self.recreate_optimize_x()
         if is_reset_optimizer_p_at_batch_start:
             self.recreate_optimize_p()
-        eng.bind_inputs(None if not bool(inputs.any()) else inputs.contiguous())
+        self._announce_staging(plan)
+        eng.bind_inputs(None if not bool(inputs.any()) else self._on_engine(plan, inputs.contiguous()))
         if loss.target is not None:
             eng.bind_target(loss.target.to(device=plan["device"], dtype=torch.float32).contiguous())
         results = {"loss": [], "energy": [], "overall": []}
@@ -770,8 +822,8 @@ class PCTrainer(object):
         nl = len(net.sizes)
         B_global = self._global_batch(plan["B"]) if self._update_p_at else None     # (a collective when sharded: only if used)
         for t in range(T):
-            self._sync_params(eng, net)
-            eng.load_state([x.data for x in xs])
+            self._sync_params(eng, net, plan=plan)
+            eng.load_state([self._on_engine(plan, x.data) for x in xs])
             keep = is_return_results_every_t or t == T - 1
             res = eng.run(T, t_begin=t, n_steps=1, loss_kind=loss.kind, loss_var=loss.var, mask_start=loss.mask_start,
                           xopt=L.XOPT_SGD, lr=1.0, update_x=False, acc_begin=t, acc_end=t + 1, acc_reset=True,
@@ -782,7 +834,7 @@ class PCTrainer(object):
                 dist.allreduce_flat(energies[t], self.mcpc_process_group)         # the whole batch's loss / energies of this step
             if keep:
                 if is_return_outputs:
-                    results["outputs"].append(res.rec_out[0] if net.n_out > 0 else xs[-1].detach().clone())
+                    results["outputs"].append(res.rec_out[0].to(plan["model_device"]) if net.n_out > 0 else xs[-1].detach().clone())
                 if is_return_representations:
                     results["representations"].append(self.get_model_representations().clone().detach().cpu())
                 if is_return_xs:
@@ -802,13 +854,10 @@ class PCTrainer(object):
                 self._optimizer_p.zero_grad()
             # "backward": dF/dx from the kernel, dF/dtheta added into .grad like autograd does
             for x, g in zip(xs, res.xgrad):
+                g = g.to(x.device)
                 x.grad = g if x.grad is None else x.grad.add_(g)
             for j, lin in enumerate(net.linears):
-                if lin.weight.grad is None:
-                    lin.weight.grad = torch.zeros_like(lin.weight)
-                if lin.bias is not None and lin.bias.grad is None:
-                    lin.bias.grad = torch.zeros_like(lin.bias)
-                eng.read_param_grads(j, lin.weight.grad, None if lin.bias is None else lin.bias.grad, 1.0, accumulate=True)
+                self._add_param_grads(plan, eng, j, lin, accumulate=True)
             if callback_after_backward is not None:
                 callback_after_backward(t, **callback_after_backward_kwargs)
             if t in self._update_x_at:

@@ -231,7 +231,9 @@ def describe_callback(callback, kwargs, trainer) -> typing.Tuple[typing.Optional
     return verdict
 
 
-_FUSED_ANNOUNCED = set()
+import weakref                                                     # noqa: E402
+
+_FUSED_ANNOUNCED = weakref.WeakSet()        # (callbacks already announced; weak: a script's closures are not kept alive by a warning)
 
 # What the code of an untagged callback may mention if it is to be fused without ever being called again: the reference's random_step
 # (utils/model.py:35-44) uses get_model_xs, get_optimizer_x, grad, normal_, np.sqrt, defaults and step -- nothing else.
@@ -241,6 +243,18 @@ _KICK_MODULES = frozenset({"numpy", "math", "torch"})
 _KICK_FORBIDDEN_OPS = ("STORE_GLOBAL", "STORE_ATTR", "STORE_SUBSCR", "DELETE_", "IMPORT_", "MAKE_FUNCTION", "LOAD_CLOSURE", "LOAD_DEREF",
                        "STORE_DEREF", "LOAD_CLASSDEREF", "YIELD", "RAISE", "COMPARE_OP", "CONTAINS_OP", "IS_OP", "POP_JUMP", "JUMP_IF",
                        "SETUP_WITH", "BEFORE_WITH", "SETUP_FINALLY", "LOAD_BUILD_CLASS", "LOAD_NAME", "STORE_NAME", "MATCH_")
+# ... and the ONLY opcodes such a function may consist of (a deny-list silently lets through whatever a newer interpreter
+# adds -- 3.13's LOAD_FAST_LOAD_FAST, 3.14's LOAD_FAST_BORROW* read locals under other names): straight-line loads, calls, arithmetic,
+# the for-loop over get_model_xs() and the return.  Anything else -- an opcode of an interpreter this list was not written for
+# included -- fails the check, and the callback keeps the step-wise path, where it is really called.
+_KICK_ALLOWED_OPS = frozenset({
+    "RESUME", "NOP", "CACHE", "PRECALL", "PUSH_NULL", "COPY", "SWAP", "POP_TOP", "KW_NAMES", "EXTENDED_ARG", "COPY_FREE_VARS",
+    "LOAD_FAST", "LOAD_FAST_CHECK", "LOAD_FAST_AND_CLEAR", "LOAD_FAST_LOAD_FAST", "LOAD_FAST_BORROW", "LOAD_FAST_BORROW_LOAD_FAST_BORROW",
+    "STORE_FAST", "STORE_FAST_STORE_FAST", "STORE_FAST_LOAD_FAST", "LOAD_CONST", "LOAD_SMALL_INT", "LOAD_GLOBAL", "LOAD_ATTR", "LOAD_METHOD",
+    "CALL", "CALL_FUNCTION", "CALL_METHOD", "CALL_FUNCTION_KW", "CALL_KW", "BINARY_OP", "BINARY_SUBSCR", "BINARY_TRUE_DIVIDE", "BINARY_MULTIPLY",
+    "BINARY_ADD", "BINARY_SUBTRACT", "BINARY_POWER", "UNARY_NEGATIVE", "BUILD_TUPLE", "BUILD_LIST", "GET_ITER", "FOR_ITER", "END_FOR", "POP_ITER",
+    "JUMP_ABSOLUTE", "JUMP_BACKWARD", "JUMP_BACKWARD_NO_INTERRUPT", "JUMP_FORWARD", "RETURN_VALUE", "RETURN_CONST", "NOT_TAKEN", "DUP_TOP",
+    "ROT_TWO"})
 
 
 def _static_langevin_check(callback) -> str:
@@ -262,8 +276,13 @@ def _static_langevin_check(callback) -> str:
         op = ins.opname
         if any(op.startswith(f) for f in _KICK_FORBIDDEN_OPS):
             return f"its code contains {op} (a branch, comparison, store or import)"
-        if op in ("LOAD_FAST", "LOAD_FAST_CHECK") and ins.argval == t_name:
-            return f"it reads its step argument {t_name!r}"
+        if op not in _KICK_ALLOWED_OPS:
+            return f"its code contains {op}, which a plain Langevin kick has no use for (or this interpreter's bytecode is newer than the check)"
+        if op.startswith("LOAD_FAST") or op.startswith("STORE_FAST"):
+            # (the fused forms of newer interpreters carry a tuple of names)
+            names = ins.argval if isinstance(ins.argval, (tuple, list)) else (ins.argval,)
+            if t_name in names:
+                return f"it reads its step argument {t_name!r}"
         if op == "LOAD_GLOBAL":
             mod = callback.__globals__.get(ins.argval)
             if not isinstance(mod, types.ModuleType) or mod.__name__.split(".")[0] not in _KICK_MODULES:

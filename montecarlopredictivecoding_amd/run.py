@@ -1,0 +1,141 @@
+"""Launcher: run one of the reference's scripts UNCHANGED on the MI355X engine.
+
+    python -m montecarlopredictivecoding_amd.run figure_2.py [script arguments ...]
+
+north_star: "the PCLayer/PCTrainer constructor and callback API surface is preserved so figure_*.py scripts run unchanged".  The
+reference's scripts reach the hot path through four import lines (/root/reference/figure_2.py:14-21, figure_6.py:11-15):
+
+    import predictive_coding as pc
+    from utils.model import ...                     (random_step, get_model, the loss functions, the x initialisers)
+    from utils.training_evaluation import ...       (get_pc_trainer, get_mcpc_trainer, sample_pc, the evaluators)
+    from utils.data import ... / from utils.plotting import ...        (data loaders, plots: out of this repository's scope)
+
+and they sit in a directory that HOLDS regular packages of those names (`predictive_coding/__init__.py`, `utils/__init__.py`).  Python
+puts the script's directory at `sys.path[0]`, ahead of `PYTHONPATH`, so alias packages on `PYTHONPATH` lose to the script's own
+(missing #2: the script would silently run the reference's CPU loop).  The module search order cannot fix that; the
+import system can: :func:`install` puts a finder FIRST on `sys.meta_path` that answers
+
+    predictive_coding, predictive_coding.pc_layer, predictive_coding.pc_trainer, predictive_coding.utils
+    utils.model, utils.training_evaluation
+
+with this package's counterparts and declines everything else -- `utils` itself, `utils.data`, `utils.plotting`, `ResNet9`, ... stay
+the script's own (when no `utils` package exists anywhere, an empty one is provided so that `utils.model` has a parent).  The script
+is then executed with `runpy.run_path(..., run_name="__main__")`, its directory at `sys.path[0]` and `sys.argv` as if it had been
+started directly.
+
+`montecarlopredictivecoding_amd.run.install()` is the same switch for an interpreter that is already running (a notebook, a test).
+"""
+import importlib
+import importlib.abc
+import importlib.machinery
+import importlib.util
+import os
+import sys
+import types
+
+# reference module name -> this package's module that stands in for it
+ALIASES = {
+    "predictive_coding": "montecarlopredictivecoding_amd.predictive_coding",
+    "predictive_coding.pc_layer": "montecarlopredictivecoding_amd.predictive_coding.pc_layer",
+    "predictive_coding.pc_trainer": "montecarlopredictivecoding_amd.predictive_coding.pc_trainer",
+    "predictive_coding.utils": "montecarlopredictivecoding_amd.predictive_coding.utils",
+    "utils.model": "montecarlopredictivecoding_amd.utils.model",
+    "utils.training_evaluation": "montecarlopredictivecoding_amd.utils.training_evaluation",
+}
+
+
+class _AliasLoader(importlib.abc.Loader):
+    """Hands the import system an already-imported module of this package under the reference's name."""
+
+    def __init__(self, target):
+        self._target = target
+
+    def create_module(self, spec):
+        return importlib.import_module(self._target)
+
+    def exec_module(self, module):
+        pass                                    # (already executed under its own name)
+
+
+class _EmptyPackageLoader(importlib.abc.Loader):
+    def create_module(self, spec):
+        return None
+
+    def exec_module(self, module):
+        module.__path__ = []
+
+
+class EngineFinder(importlib.abc.MetaPathFinder):
+    """First on sys.meta_path: the reference's hot-path modules resolve to the engine-backed ones, whatever the script's directory holds."""
+
+    def find_spec(self, fullname, path=None, target=None):
+        aliased = ALIASES.get(fullname)
+        if aliased is not None:
+            is_pkg = fullname == "predictive_coding"
+            spec = importlib.machinery.ModuleSpec(fullname, _AliasLoader(aliased), is_package=is_pkg)
+            return spec
+        if fullname == "utils":
+            # the script's own package if there is one (its utils.data / utils.plotting must stay importable) ...
+            for finder in sys.meta_path:
+                if finder is self or not hasattr(finder, "find_spec"):
+                    continue
+                spec = finder.find_spec(fullname, path, target)
+                if spec is not None:
+                    return spec
+            # ... else an empty parent for utils.model / utils.training_evaluation
+            return importlib.machinery.ModuleSpec(fullname, _EmptyPackageLoader(), is_package=True)
+        return None
+
+
+_FINDER = None
+
+
+def install():
+    """Install the finder (idempotent) and drop already-imported modules of the aliased names so that the next import resolves here."""
+    global _FINDER
+    if _FINDER is None:
+        _FINDER = EngineFinder()
+    if _FINDER in sys.meta_path:
+        sys.meta_path.remove(_FINDER)
+    sys.meta_path.insert(0, _FINDER)
+    for name in list(sys.modules):
+        if name in ALIASES:
+            mod = sys.modules[name]
+            if getattr(mod, "__name__", name) != ALIASES[name]:
+                del sys.modules[name]
+    return _FINDER
+
+
+def uninstall():
+    if _FINDER is not None and _FINDER in sys.meta_path:
+        sys.meta_path.remove(_FINDER)
+
+
+def run_script(path, argv=()):
+    """Execute `path` as `__main__` with the finder installed, `sys.argv` = [path, *argv] and the script's directory at sys.path[0]."""
+    import runpy
+    path = os.path.abspath(path)
+    if not os.path.isfile(path):
+        raise FileNotFoundError(path)
+    install()
+    sys.argv = [path] + list(argv)
+    script_dir = os.path.dirname(path)
+    # `python script.py` puts the script's directory first; `python -m ...` put the current directory (or '') there instead
+    if sys.path and sys.path[0] in ("", os.getcwd()):
+        sys.path[0] = script_dir
+    else:
+        sys.path.insert(0, script_dir)
+    return runpy.run_path(path, run_name="__main__")
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    if not argv or argv[0] in ("-h", "--help"):
+        print(__doc__.strip().split("\n\n")[0], file=sys.stderr)
+        return 2
+    run_script(argv[0], argv[1:])
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

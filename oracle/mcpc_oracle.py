@@ -274,9 +274,10 @@ def run(net: NetSpec, inputs, xs0: Sequence[np.ndarray], loss: LossSpec, xopt: X
             step_size = dt.type(xopt.lr / bc1)
             for l in range(L):
                 m[l] = m[l] + (gs[l] - m[l]) * omb1                    # exp_avg.lerp_(grad, 1-beta1)
-                v[l] = v[l] * b2 + omb2 * gs[l] * gs[l]               # mul_(beta2).addcmul_(g, g, 1-beta2)
+                v[l] = v[l] * b2 + (omb2 * gs[l]) * gs[l]             # mul_(beta2).addcmul_(g, g, 1-beta2): (alpha * t1) * t2
                 denom = np.sqrt(v[l]) / dt.type(bc2s) + dt.type(xopt.eps)
-                xs[l] = xs[l] - step_size * (m[l] / denom)
+                # param.addcdiv_(exp_avg, denom, value=-step_size): ATen computes self + (alpha * t1) / t2 -- the scalar first
+                xs[l] = xs[l] + (-step_size * m[l]) / denom
         # -- p step normalisation (pc_trainer.py:904-914); optimizer_p itself is the caller's
         if t in update_p_at:
             div = dt.type(len(accumulate_p_at) * B if len(accumulate_p_at) > 0 else B)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Quick PMC look at the step kernel of a plain-schedule inference call (developer tool):  MCPC_TUNING=no_mix=1 bash scripts/pmc_quick.sh <tag>
+# Quick PMC look at the step kernel of an inference call (developer tool):  [MCPC_TUNING=rr=0] bash scripts/pmc_quick.sh <tag>
 set -e -o pipefail
 TAG=${1:-pmcq}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -73,8 +73,27 @@ def merge(d, out):
             if "WRITE_SIZE" in c:
                 dv["hbm_write_bytes"] = 1024.0 * c["WRITE_SIZE"]
             e["derived"] = dv
+    # meta: what the passes profiled, from THEIR OWN bench lines (<mode>_<group>.json next to the sums): bench.py prints
+    # roofline.traffic only when this matches the run it is printed in (kernel sources, batch, T, launches)
+    meta = {}
+    for path in sorted(glob.glob(os.path.join(d, "*_*.json"))):
+        if os.path.basename(path).startswith("sum_"):
+            continue
+        try:
+            line = json.loads([ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1])
+        except (IndexError, ValueError):
+            continue
+        b, cfg = line.get("build_info") or {}, line.get("config") or {}
+        this = {"csrc": b.get("csrc"), "commit": b.get("commit"), "exp": b.get("exp"), "batch": cfg.get("batch"), "T": cfg.get("T")}
+        if meta and any(meta[k] != v for k, v in this.items()):
+            raise SystemExit(f"the passes under {d} profiled different programs: {meta} vs {this} ({path})")
+        meta.update(this)
+    meta["command"] = ("rocprofv3 --pmc <one group per pass> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-self-check "
+                       "{--no-secondary | --only-inference} (scripts/pmc_round.sh)")
+    meta["corrections"] = "FETCH_SIZE and WRITE_SIZE in KiB -> bytes; FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM traffic from PMC)"
+    res["meta"] = meta
     json.dump(res, open(out, "w"), indent=1)
-    print("merged ->", out)
+    print("merged ->", out, meta)
 
 
 if __name__ == "__main__":

@@ -83,3 +83,53 @@ class Golden:
 
     def has(self, ci, key):
         return f"c{ci}_{key}" in self.z
+
+
+# ---- ReLU-kink events of a reference trajectory -------------------------------------------------------------------------------------
+# A fixture's trajectory is only determined to within the parity contract (states abs 1e-5) by the reference's own fp32 arithmetic as
+# long as no unit sits ON the ReLU kink: f'(x) jumps from 0 to 1 at x = 0, so a unit whose |x| is below the last-bit error of a correct
+# fp32 trajectory (~1e-6 at |x| ~ 10) takes one side or the other by the rounding of the GEMM that produced it -- MKL's summation order
+# in the reference, another one in any other correct implementation -- and that chain then follows a different (equally valid) path
+# for some tens of steps until the contraction pulls it back.  g2_cfgM_b64 holds one such event: chain 14, layer 2, unit 76 at step 42
+# has x = 4.5e-8 (found in round 5: the fused kernel happens to take the reference's side, the step-wise path the other, their energies
+# differ by 5.7e-6 for steps 43-99 and every OTHER chain agrees to 2e-6).  The tests hold the contract strictly up to an event and state
+# a separate, logged tolerance after it; the events are computed from the oracle's replay of the fixture, not from the failure.
+KINK_EPS = 2e-6
+_KINKS = {}
+
+
+def relu_kink_events(name):
+    """{call index: [(step, chain), ...]} -- steps at which a ReLU unit of that chain has |x| < KINK_EPS in the oracle's replay."""
+    if name in _KINKS:
+        return _KINKS[name]
+    g = Golden(name)
+    c = g.case
+    events = {}
+    relu_layers = [l for l, a in enumerate(c["acts"]) if a == "relu"]
+    if relu_layers and not name.startswith("g9_"):
+        xs, gW, gb, W, b = g.X0, None, None, g.W, g.b
+        for ci, call in enumerate(c["calls"]):
+            xs0 = xs if (not call.get("sample_x", True) and ci > 0) else g.X0
+            up, acc = g.schedules(call)
+            res = mo.run(g.net(W, b), g.inputs, xs0, g.loss_spec(), g.xopt(call), call["T"], noise=g.noise(ci),
+                         noise_var=call.get("noise_var", 2.0), update_p_at=up, accumulate_p_at=acc, record_at=list(range(call["T"])),
+                         gW_in=gW, gb_in=gb)
+            for t in range(call["T"]):
+                for l in relu_layers:
+                    for chain in np.nonzero((np.abs(res.rec_xs[t][l]) < KINK_EPS).any(axis=1))[0]:
+                        events.setdefault(ci, []).append((t, int(chain)))
+            xs, gW, gb = res.xs, res.gW, res.gb
+            if up:
+                W = [g.get(ci, f"W{j}_after") for j in range(len(W))]
+                b = [g.get(ci, f"b{j}_after") if bb is not None else None for j, bb in enumerate(b)]
+    _KINKS[name] = events
+    return events
+
+
+def first_kink_step(name, ci):
+    """Step of call ci after which the fixture's trajectory is no longer unique to within the contract (None: never).  An event in an
+    earlier call of a fixture whose later calls continue from its state counts from step -1 of the later call."""
+    ev = relu_kink_events(name)
+    if any(k < ci for k in ev):
+        return -1
+    return min((t for t, _ in ev.get(ci, [])), default=None)

@@ -143,3 +143,71 @@ def test_global_batch_is_a_collective_on_every_call_not_cached_per_local_size(tm
     mp.spawn(_ragged_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     for rank in range(2):
         assert np.load(os.path.join(tmp_path, f"ragged{rank}.npy")).tolist() == [128, 100, 128, 100, 777]
+
+
+# ---- the generic loop on a set_shard() trainer ---------------------------------------------------------------
+def _generic_model():
+    import montecarlopredictivecoding_amd.predictive_coding as pc
+    torch.manual_seed(77)
+    M = (torch.rand(5, 5) > 0.3).float()             # an M mask: outside what the kernels express -> generic loop
+    model = nn.Sequential(nn.Linear(4, 5), pc.PCLayer(M=M[0]), nn.Tanh(), nn.Linear(5, 3))
+    model.train()
+    return model
+
+
+def _generic_call(model, inputs, target, group=None, chain_base=0, world_batch=None, sharded=False):
+    import warnings
+    import montecarlopredictivecoding_amd.predictive_coding as pc
+    from montecarlopredictivecoding_amd.utils.model import fe_fn
+    tr = pc.PCTrainer(model, T=6, update_x_at="all", optimizer_x_fn=torch.optim.SGD, optimizer_x_kwargs={"lr": 0.05},
+                      update_p_at="last", accumulate_p_at=[2, 3, 4, 5], optimizer_p_fn=torch.optim.SGD,
+                      optimizer_p_kwargs={"lr": 0.5}, plot_progress_at=[])
+    tr._test_only_generic_on_cpu = True              # (no GPU in the CPU suite: the loop's arithmetic is what is under test)
+    if sharded:
+        tr.set_shard(process_group=group, chain_base=chain_base, world_batch=world_batch, reduce_results=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = tr.train_on_batch(inputs=inputs, loss_fn=fe_fn, loss_fn_kwargs={"_target": target, "_var": 0.7}, is_log_progress=False)
+    assert tr.last_call_mode == "generic"
+    return res
+
+
+def _linear_params(model):
+    return [p for m in model if isinstance(m, nn.Linear) for p in m.parameters()]      # (a PCLayer's x is a Parameter too)
+
+
+def _generic_data():
+    g = torch.Generator().manual_seed(5)
+    return torch.randn(10, 4, generator=g), torch.randn(10, 3, generator=g)
+
+
+def _generic_worker(rank, world, port, out_dir):
+    import torch.distributed as tdist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    inputs, target = _generic_data()
+    begin, end = (0, 6) if rank == 0 else (6, 10)    # uneven shards; the job-wide batch rides on a collective (world_batch=None)
+    model = _generic_model()
+    res = _generic_call(model, inputs[begin:end], target[begin:end], group=tdist.group.WORLD, chain_base=begin, sharded=True)
+    np.savez(os.path.join(out_dir, f"generic{rank}.npz"), overall=np.array(res["overall"]), loss=np.array(res["loss"]),
+             energy=np.array(res["energy"]), **{f"p{i}": p.detach().numpy() for i, p in enumerate(_linear_params(model))})
+    tdist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_generic_loop_on_a_sharded_trainer_all_reduces_grads_and_results(tmp_path):
+    """A set_shard() trainer whose call is outside the kernels (an M mask here) used to train diverging replicas: the generic loop
+    divided by the LOCAL batch and never all-reduced.  Two uneven gloo shards must end with identical parameters, equal to the
+    unsharded call's up to the summation order, and report the whole batch's loss / energy / overall (reduce_results=True)."""
+    mp.spawn(_generic_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    inputs, target = _generic_data()
+    model = _generic_model()
+    ref = _generic_call(model, inputs, target)
+    r = [np.load(os.path.join(tmp_path, f"generic{k}.npz")) for k in range(2)]
+    for i, p in enumerate(_linear_params(model)):
+        assert np.array_equal(r[0][f"p{i}"], r[1][f"p{i}"])
+        np.testing.assert_allclose(r[0][f"p{i}"], p.detach().numpy(), rtol=2e-5, atol=1e-6)
+    for key in ("loss", "energy", "overall"):
+        assert np.array_equal(r[0][key], r[1][key])
+        np.testing.assert_allclose(r[0][key], np.array(ref[key]), rtol=2e-6)

@@ -135,3 +135,38 @@ def test_bench_multi_rank_code_path_with_one_rank():
     assert out["roofline"]["bound"] == "mfma" and 0.0 < out["roofline"]["frac"] < 1.0
     sc = out["self_check"]                                    # the timed call replayed on the serial / plain schedule
     assert sc["ok"] and sc["bitwise_state"] and sc["bitwise_records"] and sc["bucket_max_rel"] <= 1e-5 and sc["ranks_checked"] == 1
+    assert out["build_info"]["exp"] == "0" and out["build_info"]["built_from_this_tree"] and out["build_info"]["abi"] == "4"
+    # --T 400 is not the call the tracked PMC passes profiled: the line must say null and why, not print another run's bytes
+    assert out["roofline"]["traffic"] is None and "traffic_is_null_because" in out["roofline"]["traffic_detail"]
+
+
+def test_bench_two_ranks_rehearsed_on_gloo():
+    """bench.py's N > 1 branch with TWO ranks, launched the way the driver launches it
+    (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`), both ranks on device 0 over gloo (two ranks cannot
+    share a device under RCCL): ONE JSON line, from rank 0 only; n_gpus 2; every rank's self-check counted; the reduced gradient bucket
+    identical on both ranks; value = the steps BOTH ranks did / the slower rank's wall time.  With this, RCCL itself is the only piece of
+    the driver's first N > 1 run that has not executed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    T, K = 300, 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", str(K), "--warmup", "1", "--T", str(T),
+           "--dist-backend", "gloo", "--no-cpu-baseline"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, run.stdout                                      # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == K and out["config"]["T"] == T and out["config"]["chains_total"] == 12000
+    assert out["scaling"] == "weak" and "gloo rehearsal" in out["rehearsal"]
+    assert "all-reduce of 276146 floats" in out["config"]["timed_mode"]
+    # value is whole-job: n_gpus * K * T / wall (two ranks time-share one device here, so it is about ONE GPU's rate, not two)
+    assert out["value"] == pytest.approx(2 * K * T / (out["ms_per_step"] * 1e-3 * K), rel=1e-6)
+    sc = out["self_check"]
+    assert sc["ok"] and sc["ranks_checked"] == 2 and sc["bitwise_state"] and sc["bitwise_records"]
+    assert sc["bucket_identical_on_all_ranks"] is True
+    assert "cpu_baseline" not in out                                       # rank 0 at N = 1 only
+    assert out["build_info"]["exp"] == "0" and out["build_info"]["built_from_this_tree"]

@@ -14,7 +14,8 @@ import torch
 
 from oracle import gen_golden, philox
 from oracle.cases import make_case_inputs
-from tests.golden_util import Golden, fixture_names
+from tests.golden_util import Golden, fixture_names, first_kink_step, relu_kink_events
+from tests import parity_log
 
 pytestmark = pytest.mark.gpu
 
@@ -66,13 +67,30 @@ def test_facade_replays_reference_harness(name):
         generic = any(k in call for k in ("x_lr_discount", "clip_x_grad", "xopt_extra", "update_x_at")) or \
             call.get("update_p_at", "never") == "all"
         assert trainer.last_call_mode == ("stepwise" if (call.get("noise", False) or generic) else "fused")
-        np.testing.assert_allclose(out["energy"], g.get(ci, "energy"), rtol=3e-5, atol=1e-5)
-        np.testing.assert_allclose(out["overall"], g.get(ci, "overall"), rtol=3e-5, atol=1e-5)
-        if g.case["loss"] != "none":
-            np.testing.assert_allclose(out["loss"], g.get(ci, "loss"), rtol=3e-5, atol=1e-5)
+        # the boundary the user calls, at the contract (energies rel 1e-6, states abs 1e-5), logged
+        # (these were rtol 3e-5 / atol 3e-4 and 1e-3, and unlogged).  The results lists are fp32 `.item()`s in
+        # the reference and fp64 sums here: 6e-8 of rounding on the reference's side is inside the 1e-6.
+        group = "facade (PCTrainer.train_on_batch, %s) vs reference fixtures" % trainer.last_call_mode
+        # ReLU-kink events of the reference's trajectory (tests/golden_util.py: a unit within 2e-6 of x = 0 takes its side of the kink
+        # by the last bit of a GEMM; g2_cfgM_b64 has six): strict up to the first one, a stated and logged tolerance after it
+        tk = first_kink_step(name, ci)
+        after = group + ", steps AFTER a ReLU-kink event of the reference trajectory"
+        kink_chains = {c for k, evs in relu_kink_events(name).items() if k <= ci for _, c in evs}
+        for key in ("energy", "overall") + (("loss",) if g.case["loss"] != "none" else ()):
+            got, want = np.asarray(out[key]), g.get(ci, key)
+            cut = len(want) if tk is None else tk + 1
+            parity_log.close(group, key + "[t]", got[:cut], want[:cut], rtol=1e-6, atol=1e-6)
+            if cut < len(want):
+                parity_log.close(after, key + "[t]", got[cut:], want[cut:], rtol=1e-5, atol=1e-6)
         for k, v in out.items():
-            if k.startswith("x_") or k.startswith("out_"):
-                np.testing.assert_allclose(v, g.get(ci, k), rtol=0, atol=1e-3 if k.startswith("out_") else 3e-4, err_msg=k)
+            if not (k.startswith("x_") or k.startswith("out_")):
+                continue
+            want = g.get(ci, k)
+            t_rec = call["T"] if k.startswith("x_final") else int(k.split("_")[1][1:])
+            if tk is not None and t_rec > tk and kink_chains:
+                keep = [c for c in range(want.shape[0]) if c not in kink_chains]       # those chains follow another valid path for a while
+                v, want = v[keep], want[keep]
+            parity_log.close(group, "states" if k.startswith("x_") else "outputs", v, want, rtol=0, atol=1e-5 if k.startswith("x_") else 3e-5, err_msg=k)
         updates = call.get("update_p_at", "never") != "never"
         zeroes = updates or call.get("accumulate_p_at", "never") != "never"
         if updates or (trainer.last_call_mode == "stepwise" and (zeroes or grads_carried)):

