@@ -23,6 +23,13 @@ the script's own (when no `utils` package exists anywhere, an empty one is provi
 is then executed with `runpy.run_path(..., run_name="__main__")`, its directory at `sys.path[0]` and `sys.argv` as if it had been
 started directly.
 
+Names the engine-backed modules do not define.  The reference's `utils/training_evaluation.py` also holds helpers that are not on the hot
+path and that its scripts import from the same module -- `train`, `test`, `MNIST_LinearClassifier`, `kl_divergence_discrete`
+(`figure_2.py:17-19`), `KLdivergence`, `get_paired_stat` (`figure_5.py:14`), `get_fid` (`table_1.py:8`).  They are not restated here: an
+attribute this package's module lacks is looked up (PEP 562 `__getattr__`) in the SCRIPT'S OWN module of that name -- found with the
+finders behind this one, executed once under a private name with this finder active, so that ITS `import predictive_coding` /
+`from utils.model import ...` resolve to the engine too -- and a name neither has raises the usual `ImportError`.
+
 `montecarlopredictivecoding_amd.run.install()` is the same switch for an interpreter that is already running (a notebook, a test).
 """
 import importlib
@@ -88,6 +95,46 @@ class EngineFinder(importlib.abc.MetaPathFinder):
 
 
 _FINDER = None
+_OWN = {}           # reference module name -> the script's own module of that name (or the exception its import raised)
+
+
+def script_own_attr(reference_name, attr):
+    """`attr` of the SCRIPT'S OWN module `reference_name` (e.g. the reference's utils/training_evaluation.py next to the script) -- what an
+    engine-backed module falls back to for a name it does not define.  Raises AttributeError when there is no such module or name."""
+    if _FINDER is None or _FINDER not in sys.meta_path:
+        raise AttributeError(attr)
+    if reference_name not in _OWN:
+        own = None
+        try:
+            parent_name = reference_name.rpartition(".")[0]
+            path = None
+            if parent_name:
+                parent = importlib.import_module(parent_name)
+                path = getattr(parent, "__path__", None)
+            spec = None
+            for finder in sys.meta_path:
+                if finder is _FINDER or not hasattr(finder, "find_spec"):
+                    continue
+                spec = finder.find_spec(reference_name, path, None)
+                if spec is not None:
+                    break
+            if spec is not None and spec.origin and os.path.isfile(spec.origin):
+                # executed under a private name (sys.modules keeps the engine-backed module under the reference's), from the same file
+                private = importlib.util.spec_from_file_location("_mcpc_script_own." + reference_name, spec.origin)
+                own = importlib.util.module_from_spec(private)
+                private.loader.exec_module(own)
+        except Exception as exc:            # the script's own module does not import here (a missing dependency, a decoy): no fallback
+            own = exc
+        _OWN[reference_name] = own
+    own = _OWN[reference_name]
+    if own is None or isinstance(own, Exception):
+        why = "there is no such module next to the script" if own is None else f"importing it raised {type(own).__name__}: {own}"
+        raise AttributeError(f"{attr!r} is not one of the engine-backed names of {reference_name!r}, and the script's own {reference_name} "
+                             f"cannot supply it ({why})")
+    try:
+        return getattr(own, attr)
+    except AttributeError:
+        raise AttributeError(f"neither the engine-backed {reference_name!r} nor the script's own defines {attr!r}") from None
 
 
 def install():
@@ -109,6 +156,7 @@ def install():
 def uninstall():
     if _FINDER is not None and _FINDER in sys.meta_path:
         sys.meta_path.remove(_FINDER)
+    _OWN.clear()
 
 
 def run_script(path, argv=()):
@@ -138,4 +186,7 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    # `python -m` executes this file as `__main__`: delegate to the module under its real name, so that there is ONE finder and one
+    # table of the script's own modules (script_own_attr is reached through `montecarlopredictivecoding_amd.run`)
+    from montecarlopredictivecoding_amd.run import main as _main
+    sys.exit(_main())

@@ -17,6 +17,15 @@ import torch.nn as nn
 from ..predictive_coding.pc_layer import PCLayer
 
 
+def __getattr__(name):
+    """A name of the script's own utils/model.py that this module does not define (the reference's has none: every name of its
+    utils/model.py:8-163 is here) comes from the script's own module when it runs under the launcher (run.py: script_own_attr)."""
+    if name.startswith("__"):
+        raise AttributeError(name)
+    from ..run import script_own_attr
+    return script_own_attr("utils.model", name)
+
+
 # ---- x initialisers (reference utils/model.py:8-15) --------------------------------------------------
 def sample_x_fn(inputs):
     return inputs["mu"].detach().clone().uniform_(-10.0, 10.0)

@@ -5,6 +5,18 @@ Counterpart of /root/reference/utils/training_evaluation.py:16-70 (same config k
 import torch.optim as optim
 
 from .. import predictive_coding as pc
+# (the reference's module carries these names too -- figure_4.py:13 imports fe_fn from utils.training_evaluation)
+from .model import bernoulli_fn, bernoulli_fn_mask, fe_fn, fe_fn_mask        # noqa: F401
+
+
+def __getattr__(name):
+    """Names of the reference's utils/training_evaluation.py that are not on the hot path (train, test, MNIST_LinearClassifier, KLdivergence,
+    kl_divergence_discrete, get_paired_stat, get_fid): when a script runs under the launcher they come from the script's own module of that
+    name (montecarlopredictivecoding_amd/run.py: script_own_attr); otherwise they do not exist here."""
+    if name.startswith("__"):
+        raise AttributeError(name)
+    from ..run import script_own_attr
+    return script_own_attr("utils.training_evaluation", name)
 
 
 def get_pc_trainer(gen_pc, config, is_mcpc=False, training=True):

@@ -133,3 +133,76 @@ def test_reference_layout_cpu_built_models_run_on_the_engine(tmp_path, how):
     ideal, rw = np.sqrt(2.0 * 5.0 / 2.0 - 1.0), np.abs(ref[-50:, 1]).mean()
     assert abs(f6["abs_w0"] - ideal) < max(0.05 * ideal, 2.0 * abs(rw - ideal)), (f6, rw)      # bounds of tests/test_gpu_learning.py
     assert abs(f6["abs_w0"] - rw) < 0.1 and abs(f6["mu_w0"] - 1.0) < 0.05, (f6, rw)
+
+
+def test_off_path_names_come_from_the_scripts_own_module(tmp_path):
+    """The reference's utils/training_evaluation.py also holds helpers its scripts import from the same module and that are NOT on the hot
+    path (figure_2.py:17-19: kl_divergence_discrete, MNIST_LinearClassifier, train, test; figure_5.py:14: KLdivergence, get_paired_stat;
+    table_1.py:8: get_fid).  They are not restated in this repository: a name the engine-backed module lacks is taken from the SCRIPT'S OWN
+    module of that name -- executed with the finder active, so its own `import predictive_coding` / `from utils.model import` resolve to the
+    engine -- while every hot-path name stays the engine's."""
+    d = lay_out_reference_shaped_directory(tmp_path)
+    (d / "utils" / "training_evaluation.py").write_text(
+        "import numpy as np\n"
+        "import predictive_coding as pc\n"                                      # like the reference's module (training_evaluation.py:12-13)
+        "from utils.model import bernoulli_fn, fe_fn\n"
+        "PC_SEEN = pc.PCTrainer.__module__\n"
+        "def get_pc_trainer(*a, **k):\n    raise RuntimeError('the script\\'s own get_pc_trainer was called')\n"
+        "def kl_divergence_discrete(p, q):\n    p = np.asarray(p, dtype=np.float64); q = np.asarray(q, dtype=np.float64)\n"
+        "    return float(np.sum(np.where(p != 0, p * np.log(p / q), 0)))\n"
+        "class MNIST_LinearClassifier:\n    OWNER = 'the script\\'s own utils/training_evaluation.py'\n")
+    (d / "probe2.py").write_text(
+        "import json\n"
+        "from utils.training_evaluation import kl_divergence_discrete, MNIST_LinearClassifier\n"
+        "from utils.training_evaluation import get_pc_trainer, get_mcpc_trainer, fe_fn\n"
+        "import utils.training_evaluation as te\n"
+        "try:\n    from utils.training_evaluation import no_such_name\n    missing = 'imported'\n"
+        "except ImportError as e:\n    missing = 'ImportError'\n"
+        "print(json.dumps(dict(kl=kl_divergence_discrete([0.5, 0.5], [0.25, 0.75]), cls=MNIST_LinearClassifier.OWNER,\n"
+        "                      gpt=get_pc_trainer.__module__, fe=fe_fn.__module__, seen=te.PC_SEEN, missing=missing)))\n")
+    run = subprocess.run([sys.executable, "-m", "montecarlopredictivecoding_amd.run", str(d / "probe2.py")],
+                         capture_output=True, text=True, env=_env(), cwd=str(d), timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    out = json.loads(run.stdout.strip().splitlines()[-1])
+    assert abs(out["kl"] - (0.5 * np.log(2.0) + 0.5 * np.log(0.5 / 0.75))) < 1e-12 and out["cls"].startswith("the script")
+    assert out["gpt"] == "montecarlopredictivecoding_amd.utils.training_evaluation"           # hot-path names stay the engine's
+    assert out["fe"] == "montecarlopredictivecoding_amd.utils.model"
+    assert out["seen"] == "montecarlopredictivecoding_amd.predictive_coding.pc_trainer"      # the own module's `import predictive_coding` -> engine
+    assert out["missing"] == "ImportError"
+    # the names every reference script imports from the two modules resolve one way or the other (engine-backed, or the fallback above)
+    import re
+    import montecarlopredictivecoding_amd.utils.model as um
+    import montecarlopredictivecoding_amd.utils.training_evaluation as te
+    wanted_model = {"sample_x_fn", "sample_x_fn_normal", "sample_x_fn_cte", "fe_fn", "bernoulli_fn", "fe_fn_mask", "zero_fn", "bernoulli_fn_mask",
+                    "random_step", "get_model", "get_representations"}                         # /root/reference/utils/model.py:8-71
+    assert all(hasattr(um, n) for n in wanted_model)
+    engine_backed = {"get_pc_trainer", "get_mcpc_trainer", "get_mcpc_trainer_one_sample", "sample_pc", "get_mse_rec", "get_marginal_likelihood", "fe_fn"}
+    assert all(n in vars(te) for n in engine_backed)
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REFERENCE, "figure_6.py")), reason="the reference tree exists in the build container only")
+def test_the_references_own_figure_6_reaches_the_engine_unchanged():
+    """The real thing, as far as a container without a GPU can take it: `/root/reference/figure_6.py`, UNCHANGED and in its own directory
+    (next to the reference's predictive_coding/ and utils/ packages), started through the launcher.  Its import lines
+    (figure_6.py:11-15: predictive_coding, utils.plotting, utils.model, utils.training_evaluation), its CPU-built model
+    (figure_6.py:41-52) and its trainer factory must carry it to its first `train_on_batch` (figure_6.py:70) ON THIS PACKAGE'S TRAINER --
+    where, without a HIP device, the call fails loudly (no CPU path); with one it is staged onto the GPU (tests/test_gpu_staging.py).
+    Started directly, the same script runs the reference's own CPU loop: that difference is what the launcher is for."""
+    if __import__("torch").cuda.is_available():
+        pytest.skip("with a GPU the script would run its whole experiment (10 epochs x 25 batches x 40 noise levels)")
+    for how in ("launcher", "pythonpath"):
+        if how == "launcher":
+            cmd, env = [sys.executable, "-m", "montecarlopredictivecoding_amd.run", os.path.join(REFERENCE, "figure_6.py")], _env()
+        else:
+            cmd, env = [sys.executable, os.path.join(REFERENCE, "figure_6.py")], dict(os.environ, PYTHONPATH=os.path.join(ROOT, "compat"))
+        env["MPLBACKEND"] = "Agg"
+        run = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd="/tmp", timeout=600)
+        assert run.returncode != 0
+        err = run.stderr
+        assert "MCPCLibraryError" in err and "no HIP device is visible" in err, err[-3000:]
+        assert "figure_6.py\", line 70, in varying_langevin_noise" in err                      # its first train_on_batch
+        assert os.path.join("montecarlopredictivecoding_amd", "predictive_coding", "pc_trainer.py") in err
+        assert os.path.join(REFERENCE, "predictive_coding") not in err                         # the reference's own trainer was never entered
