@@ -90,6 +90,7 @@ class PCLayer(nn.Module):
         self._is_sample_x = False
         self._x = None
         self._ecoef_cache = "unprobed"
+        self._mcpc_sampling_only = False
         self.eval()      # like the reference: a fresh layer is in eval mode (pc_layer.py:104)
 
     # ---- accessors (names follow the reference) -------------------------------------------------
@@ -166,6 +167,11 @@ class PCLayer(nn.Module):
             drawn = self._sample_x_fn({"mu": mu, "x": self._x})
             self._x = nn.Parameter(drawn.to(mu.device), True)
             self._is_sample_x = False
+        if self._mcpc_sampling_only:
+            # the trainer's forward that only draws x for an engine call (pc_trainer._initial_state): the layer energy of this forward is
+            # never read -- the engine computes the energies of every step itself -- so it is not evaluated (27 of 89 ms of that forward at
+            # 6000 chains of cfg-M when the model lives on the CPU)
+            return self._x
         x = self._x
         if self._S is not None:
             assert mu.dim() == 2 and x.dim() == 2

@@ -62,6 +62,32 @@ _ENGINES = collections.OrderedDict()
 _ENGINE_CACHE_SIZE = 8
 
 
+class _few_cpu_threads:
+    """Scoped cap on torch's intra-op CPU threads while a STAGED call runs (a model on the CPU, round 5).
+
+    The CPU-side work of such a call -- the model's forward that draws x, the copies, the script's optimizer_p.step() -- is small, but on a
+    many-core host torch runs it on every core, and the OpenMP workers then SPIN-wait for the next parallel region (libgomp / libiomp default)
+    on all of them: the HIP runtime's completion handling starves, and the very same kernels take 52 instead of 14.5 ms per recipe iteration
+    on a 256-thread host (measured, scripts/staging_cost.py; with 8 threads 14.8).  Capped for the duration of the call, restored on exit."""
+    CAP = 8
+
+    def __init__(self, active):
+        self.active, self.saved = bool(active), None
+
+    def __enter__(self):
+        if self.active:
+            n = torch.get_num_threads()
+            if n > self.CAP:
+                self.saved = n
+                torch.set_num_threads(self.CAP)
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            torch.set_num_threads(self.saved)
+        return False
+
+
 def _take_philox_steps(n):
     base = _PHILOX_STEPS[0]
     _PHILOX_STEPS[0] += int(n)
@@ -422,17 +448,19 @@ class PCTrainer(object):
             plan["why_stepwise"] = "Adam state of optimizer_x carried over from the previous call"
         if plan["mode"] == "fused":
             self.last_call_mode = "fused"
-            return self._run_fused(plan, **common)
+            with _few_cpu_threads(plan["staged"]):
+                return self._run_fused(plan, **common)
         self.last_call_mode = "stepwise"
         # the reference warns about everything that slows a call down (utils.py:8-16); leaving the fused loop is the one that matters here
         warnings.warn(
             "In PCTrainer.train_on_batch, this call leaves the fused HIP loop and runs step by step (T kernel launches with the "
             "reference's control flow, optimizers and callbacks replayed on the host between them), this will slow down training. "
             "Reason: {}. ".format(plan["why_stepwise"]), category=RuntimeWarning)
-        return self._run_stepwise(plan, callback_after_backward=callback_after_backward,
-                                  callback_after_backward_kwargs=callback_after_backward_kwargs,
-                                  callback_after_t=callback_after_t, callback_after_t_kwargs=callback_after_t_kwargs,
-                                  is_checking_after_callback_after_t=is_checking_after_callback_after_t, **common)
+        with _few_cpu_threads(plan["staged"]):
+            return self._run_stepwise(plan, callback_after_backward=callback_after_backward,
+                                      callback_after_backward_kwargs=callback_after_backward_kwargs,
+                                      callback_after_t=callback_after_t, callback_after_t_kwargs=callback_after_t_kwargs,
+                                      is_checking_after_callback_after_t=is_checking_after_callback_after_t, **common)
 
     # ---- recognition ------------------------------------------------------------------------------------
     def _plan(self, inputs, loss_fn, loss_fn_kwargs, is_unwrap_inputs, is_optimize_inputs, callback_after_backward,
@@ -532,8 +560,11 @@ class PCTrainer(object):
             warnings.warn(
                 "In PCTrainer.train_on_batch, the model lives on {}: its parameters, latent states, inputs and targets are staged onto {} "
                 "for every call, the MCPC HIP engine runs there, and x, the results and param.grad are written back to the {} tensors "
-                "(a few MB over PCIe per call; move the model to 'cuda' to avoid the copies). ".format(
-                    plan["model_device"], plan["device"], plan["model_device"]), category=RuntimeWarning)
+                "(a few MB over PCIe per call; move the model to 'cuda' to avoid the copies).  torch's CPU work inside the call runs on at most "
+                "{} threads (all {}: their OpenMP spin-wait starves the HIP runtime); CPU work of the script between calls on many threads has the "
+                "same effect -- consider OMP_NUM_THREADS / torch.set_num_threads. ".format(
+                    plan["model_device"], plan["device"], plan["model_device"], _few_cpu_threads.CAP, torch.get_num_threads()),
+                category=RuntimeWarning)
 
     @staticmethod
     def _on_engine(plan, t):
@@ -582,8 +613,14 @@ class PCTrainer(object):
             if is_sample_x_at_batch_start:
                 for layer in layers:
                     layer.set_is_sample_x(True)
-            with torch.no_grad():
-                self._model(inputs)
+            for layer in layers:
+                layer._mcpc_sampling_only = True
+            try:
+                with torch.no_grad():
+                    self._model(inputs)
+            finally:
+                for layer in layers:
+                    layer._mcpc_sampling_only = False
         xs = []
         for layer in layers:
             x = layer.get_x()
