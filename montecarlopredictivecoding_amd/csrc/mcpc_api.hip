@@ -187,6 +187,7 @@ struct mcpc_engine {
     KPhase* phases = nullptr;
     int n_phases = 0;
     int* err = nullptr;             // device error word written by the kernels
+    int* wexp = nullptr;            // [kMaxLatent + 1] per Linear: the power of two its packed weights are scaled by (mcpc_wexp_kernel)
     unsigned long long* clk = nullptr;   // profiling: {shader cycles, 100 MHz ticks} of one wave per launch (KParams::clk)
     float* dummy = nullptr;         // 4 KiB of zeros (KParams::dummy)
     // Round schedule (setup_rounds): a shard of more 16-chain units than CUs as `rr_k` launches per cycle, each unit in `rr_m` of them
@@ -243,7 +244,7 @@ int free_all(mcpc_engine* e) {
     if (e->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(e->comm); e->comm = nullptr; e->comm_ranks = 0; }
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int l = 0; l < kMaxLatent; ++l) { F(e->x[l]); F(e->m[l]); F(e->v[l]); F(e->spill_a[l]); F(e->spill_e[l]); }
-    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ytile); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err); F(e->clk); F(e->dummy);
+    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ytile); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err); F(e->wexp); F(e->clk); F(e->dummy);
     for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (int h = 0; h < kMaxRingParts; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
@@ -423,7 +424,7 @@ int build_phases_ws2(mcpc_engine* e) {
             if (l == 0) {
                 k.flags = PHF_MU1 | PHF_WS_EPI;
             } else {
-                k.A = e->lin[l].Wf; k.kw = 16 * tiles(l - 1); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
+                k.A = e->lin[l].Wf; k.a_lin = l; k.kw = 16 * tiles(l - 1); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
                 k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
                 k.out_lds = e->lds_e[l]; k.out_ld = e->npad[l] + kLdPad;
                 k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_BWD - (l - 1);
@@ -466,7 +467,7 @@ int build_phases_ws2(mcpc_engine* e) {
         auto add_f = [&](int c) {
             KPhase f = blank();
             f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c_start[c]; f.ntiles = c_start[c + 1] - c_start[c]; f.rot = c & (kWs2Pairs - 1);
-            f.A = e->lin[L].Wf; f.kw = 16 * tiles(L - 1); f.nkb = kblocks(f.kw); f.a_tile_stride = f.nkb * kFragBlock;
+            f.A = e->lin[L].Wf; f.a_lin = L; f.kw = 16 * tiles(L - 1); f.nkb = kblocks(f.kw); f.a_tile_stride = f.nkb * kFragBlock;
             f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad;
             f.out_lds = e->lds_eo + (c % R) * chunk_floats; f.out_ld = hc * 16 + kLdPad;
             f.flags = PHF_WS_GEMM | PHF_WS_EPI; f.dep_e = REF_LAST_BWD - (L - 1);
@@ -477,7 +478,7 @@ int build_phases_ws2(mcpc_engine* e) {
         auto add_b = [&](int c) {
             KPhase b = blank();
             b.type = PH_HEADB; b.layer = L - 1; b.tile0 = 0; b.ntiles = tiles(L - 1);
-            b.A = e->lin[L].Wb; b.a_tile_stride = kblocks(e->out_pad) * kFragBlock; b.a_off0 = (c_start[c] / tq) * kFragBlock;
+            b.A = e->lin[L].Wb; b.a_lin = L; b.a_tile_stride = kblocks(e->out_pad) * kFragBlock; b.a_off0 = (c_start[c] / tq) * kFragBlock;
             b.kw = 16 * (c_start[c + 1] - c_start[c]); b.nkb = (c_start[c + 1] - c_start[c] + tq - 1) / tq;
             b.b_lds = e->lds_eo + (c % R) * chunk_floats; b.ldb = hc * 16 + kLdPad;
             b.flags = PHF_WS_GEMM; b.dep_e = idx_f[c];
@@ -507,7 +508,7 @@ int build_phases_ws2(mcpc_engine* e) {
         for (int base = 0; base < tiles(l - 1); base += span) {
             KPhase k = blank();
             k.type = PH_BWD; k.layer = l - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(l - 1) - base);
-            k.A = e->lin[l].Wb; k.kw = 16 * tiles(l); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
+            k.A = e->lin[l].Wb; k.a_lin = l; k.kw = 16 * tiles(l); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
             k.b_lds = e->lds_e[l]; k.ldb = e->npad[l] + kLdPad; k.sign = -1.0f;
             k.out_lds = e->lds_a[l - 1]; k.out_ld = e->npad[l - 1] + kLdPad;
             k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_FWD - l;
@@ -557,7 +558,7 @@ int build_phases(mcpc_engine* e) {
         for (int base = 0; base < tiles(l); base += span) {
             KPhase k{};
             k.type = PH_FWD; k.layer = l; k.tile0 = base; k.ntiles = std::min(span, tiles(l) - base);
-            k.A = e->lin[l].Wf; k.kw = 16 * tiles(l - 1); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
+            k.A = e->lin[l].Wf; k.a_lin = l; k.kw = 16 * tiles(l - 1); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
             k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
             k.flags = base + span >= tiles(l) ? PHF_SYNC : 0;
             ph.push_back(k);
@@ -568,13 +569,13 @@ int build_phases(mcpc_engine* e) {
             const int ntc = std::min(kChunkTiles, ht - c0);
             KPhase f{};
             f.type = PH_HEADF; f.layer = L - 1; f.tile0 = c0; f.ntiles = ntc;
-            f.A = e->lin[L].Wf; f.kw = 16 * tiles(L - 1); f.nkb = kblocks(f.kw); f.a_tile_stride = f.nkb * kFragBlock;
+            f.A = e->lin[L].Wf; f.a_lin = L; f.kw = 16 * tiles(L - 1); f.nkb = kblocks(f.kw); f.a_tile_stride = f.nkb * kFragBlock;
             f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad; f.flags = PHF_SYNC;
             f.out_lds = e->lds_eo; f.out_ld = kChunkTiles * 16 + kLdPad; f.dep_e = f.dep_g = -1;
             ph.push_back(f);
             KPhase b{};
             b.type = PH_HEADB; b.layer = L - 1; b.tile0 = 0; b.ntiles = tiles(L - 1);
-            b.A = e->lin[L].Wb; b.a_tile_stride = kblocks(e->out_pad) * kFragBlock; b.a_off0 = (c0 * 16 / kKB) * kFragBlock;
+            b.A = e->lin[L].Wb; b.a_lin = L; b.a_tile_stride = kblocks(e->out_pad) * kFragBlock; b.a_off0 = (c0 * 16 / kKB) * kFragBlock;
             b.kw = ntc * 16; b.nkb = (ntc * 16 + kKB - 1) / kKB;
             b.b_lds = e->lds_eo; b.ldb = kChunkTiles * 16 + kLdPad;
             b.flags = PHF_ACC_FROM_B | PHF_ACC_TO_B | PHF_SYNC;
@@ -594,7 +595,7 @@ int build_phases(mcpc_engine* e) {
         for (int base = 0; base < tiles(l - 1); base += span) {
             KPhase k{};
             k.type = PH_BWD; k.layer = l - 1; k.tile0 = base; k.ntiles = std::min(span, tiles(l - 1) - base);
-            k.A = e->lin[l].Wb; k.kw = 16 * tiles(l); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
+            k.A = e->lin[l].Wb; k.a_lin = l; k.kw = 16 * tiles(l); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
             k.b_lds = e->lds_e[l]; k.ldb = e->npad[l] + kLdPad; k.sign = -1.0f;
             ph.push_back(k);
         }
@@ -803,6 +804,8 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if ((rc = e->ws == 2 ? build_phases_ws2(e) : build_phases(e))) return bail(rc);
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
     if (hipMemset(e->err, 0, sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
+    if ((rc = dmalloc(e->wexp, kMaxLatent + 1))) return bail(rc);
+    if (hipMemset(e->wexp, 0, (kMaxLatent + 1) * sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
     if ((rc = dmalloc(e->clk, 2))) return bail(rc);
     if (hipMemset(e->clk, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
     if ((rc = dmalloc(e->dummy, 1024))) return bail(rc);
@@ -848,8 +851,10 @@ int mcpc_params_changed(mcpc_engine* e, void* stream_) {
         Lin& ln = e->lin[j];
         const size_t total = (size_t)ln.out_pad * ln.in_pad;
         const int grid = std::max(grid_for(total), (ln.out_pad + 255) / 256);
+        // the exponent the fp16 planes of this Linear are scaled by (from max |W|), then the planes themselves
+        hipLaunchKernelGGL(mcpc_wexp_kernel, dim3(1), dim3(1024), 0, stream, ln.W, (size_t)ln.n_out * ln.n_in, e->wexp + j);
         hipLaunchKernelGGL(mcpc_pack_kernel, dim3(grid), dim3(256), 0, stream, ln.W, ln.bias, ln.Wf, ln.Wb, ln.bias_pad,
-                           ln.n_out, ln.n_in, ln.out_pad / 16, ln.in_pad / 16);
+                           ln.n_out, ln.n_in, ln.out_pad / 16, ln.in_pad / 16, (const int*)(e->wexp + j));
     }
     HIP_TRY(hipGetLastError());
     return MCPC_OK;
@@ -1314,7 +1319,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         H.lds_bias = e->lds_hbias; H.lds_yw = e->lds_yw;
     }
     P.mu1 = e->mu1; P.epart = e->epart; P.epart_slots = (int)eslots;
-    P.phases = e->phases; P.n_phases = e->n_phases;
+    P.phases = e->phases; P.n_phases = e->n_phases; P.wexp = e->wexp;
     P.stagger_cycles = e->knobs.stagger;
     P.L = e->L; P.has_head = e->has_head; P.B = e->d.batch; P.Bpad = e->Bpad; P.T = r->T;
     P.xopt = r->xopt_kind; P.update_x = r->update_x ? 1 : 0;

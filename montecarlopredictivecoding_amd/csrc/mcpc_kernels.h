@@ -9,7 +9,7 @@
 //                         replaces the parameter part of overall.backward(), pc_trainer.py:862.
 #pragma once
 #include "mcpc_device.h"
-#include "mcpc_bf16x6.h"
+#include "mcpc_bf16x6.h"          // (the split of the Hebbian kernels; the GEMM core of the step kernels is mcpc_gemm_f16.h)
 #include "../../include/mcpc.h"
 
 namespace mcpc {
@@ -87,6 +87,7 @@ struct KPhase {
     int out_lds, out_ld;   // HEADF: LDS offset / row stride of the e_o chunk this phase writes
     int dep_e, dep_g;      // wave-specialised kernels: entry whose completion by all E / all G waves must precede (-1: none;
                            // in-place variant: an index above the entry's own refers to the previous step)
+    int a_lin;             // Linear whose packed weights A points into: KParams::wexp[a_lin] is the exponent they were scaled by
     int rot;               // in-place variant: pair k owns tiles tile0 + ((k + rot) & 3) + 4 i (balances uneven chunks)
     int dep_se;            // in-place variant: entry all E waves must have passed before this entry's block is STORED (its
                            // LDS rows are still read by their epilogues); dep_g is waited for at the same point
@@ -108,6 +109,7 @@ struct KParams {
     KLayer layer[kMaxLatent];
     KHead head;
     const KPhase* phases;  // [n_phases] in device memory
+    const int* wexp;       // [kMaxLatent + 1]: per Linear, the power of two its packed weights are scaled by (mcpc_wexp_kernel)
     int n_phases;
     int stagger_cycles;    // workgroups >= 256 (the second resident on a CU) start this many cycles late
     const float* mu1;      // prediction of the top latent layer [Bpad][npad_0] (inputs W0^T + b0)
@@ -214,12 +216,21 @@ __device__ __forceinline__ void issue_epilogue_loads(const KParams& P, const KPh
 }
 
 // ---- GEMM core ------------------------------------------------------------------------------------------------------------
-// fp32 products emulated in-class on the bf16 matrix pipe (mcpc_gemm6.h, mcpc_bf16x6.h): frag_t, kKB (k-depth of a fragment block),
-// kFragBlock (16-byte units per tile and block), frag_zero, load_frag, gemm_tiles, prefetch_first_blocks.  The B operand is read from
-// fp32 LDS rows.  (Rounds 1-2 ran v_mfma_f32_16x16x4_f32 here; that core left the tree in round 4 -- git history)
+// fp32 products on the fp16 matrix pipe with per-row power-of-two scaling (mcpc_gemm_f16.h): frag_t, kKB (k-depth of a fragment block),
+// kFragBlock (16-byte units per tile and block), frag_zero, load_frag, gemm_tiles, GemmScale, prefetch_first_blocks.  The B operand is read
+// from fp32 LDS rows.  (Rounds 1-2 ran v_mfma_f32_16x16x4_f32 here, rounds 3-4 six bf16 MFMAs per product: git history)
 }  // namespace mcpc
-#include "mcpc_gemm6.h"
+#include "mcpc_gemm_f16.h"
 namespace mcpc {
+
+// the weights' exponent of a phase's Linear, through the constant address space (a wave-uniform s_load like the phase descriptors)
+__device__ __forceinline__ int load_wexp(const int* wexp, int lin) {
+    typedef __attribute__((address_space(4))) const int cint;
+    return ((cint*)wexp)[lin];
+}
+// B exponent of the read-out error rows: a Bernoulli read-out's sigma(o) - y is bounded by 1 for targets in [0, 1] (2 for anything BCE
+// still makes sense of) -> a FIXED exponent, independent of how the read-out is cut into chunks; anything else: from the rows themselves
+__device__ __forceinline__ int headb_fixed_exp(int loss_kind) { return loss_kind == MCPC_LOSS_BERNOULLI ? 13 : kScaleAuto; }
 
 // guarded scalar store of a C-layout quad into an unpadded [B][n] tensor row
 __device__ __forceinline__ void st_unpadded(float* base, int chain, int n, int u0, f32x4 v) {
@@ -539,6 +550,7 @@ __global__ __launch_bounds__(NW * 64, MCPC_BARRIER_WAVES_PER_EU) void mcpc_steps
         for (int i = 0; i < NTW; ++i)
 #pragma unroll
             for (int ct = 0; ct < CTT; ++ct) accb[i][ct] = splat(0.f);
+        int accb_run = kRunNone, accb_aexp = 0;            // the units accb is in (mcpc_gemm_f16.h: GemmScale)
 
 #pragma unroll 1
         for (int p = 0; p < P.n_phases; ++p) {
@@ -585,8 +597,15 @@ __global__ __launch_bounds__(NW * 64, MCPC_BARRIER_WAVES_PER_EU) void mcpc_steps
             // operands of the epilogue (x, targets: streamed; bias, E: L2/LDS) are requested ahead of the GEMM.
             // (Requesting them after the GEMM's last fragment load was measured slower on MI355X.)
             if (ph.type != PH_HEADB) issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
-            if (nt > 0 && ph.nkb > 0)
-                gemm_tiles<NTW, CTT, NW>(acc, ph.A, aoff, nt, ph.nkb, ph.kw, lds + ph.b_lds, ph.ldb, lane, pre0, lds + P.lds_zero);
+            if (nt > 0 && ph.nkb > 0) {
+                // HEADB phases add up in accb over the chunks of the read-out, in scaled units (accb_run / accb_aexp); every other GEMM is fresh
+                GemmScale gs{load_wexp(P.wexp, ph.a_lin), ph.type == PH_HEADB ? GS_ACCUM : GS_FRESH,
+                             ph.type == PH_HEADB ? headb_fixed_exp(P.head.loss_kind) : kScaleAuto, accb_run};
+                gemm_tiles<NTW, CTT, NW>(acc, ph.A, aoff, nt, ph.nkb, ph.kw, lds + ph.b_lds, ph.ldb, lane, pre0, lds + P.lds_zero, gs);
+                if (ph.type == PH_HEADB) { accb_run = gs.run; accb_aexp = gs.a_exp; }
+            } else if ((ph.flags & PHF_ACC_FROM_B) && ph.type != PH_HEADB && accb_run != kRunNone) {
+                gemm_unscale<NTW, CTT>(acc, accb_aexp, accb_run);       // the complete back-projection of the read-out error, handed to BWD_{L-1}
+            }
             // the next phase's first weight fragments travel while this phase's epilogue runs
             if (has_next) prefetch_first_blocks<NW, NTW>(ph_next, wave, lane, nt_next, aoff_next, pre0_next);
             if (ph.flags & PHF_ACC_TO_B) {
@@ -631,11 +650,27 @@ __global__ __launch_bounds__(NW * 64, MCPC_BARRIER_WAVES_PER_EU) void mcpc_steps
 //   forward : Wf[ut][kb][plane][lane] (16 B) = W[16ut + (lane&15)][32kb + 8(lane>>4) + j], j = 0..7
 //   backward: Wb[it][ub][plane][lane] (16 B) = W[32ub + 8(lane>>4) + j][16it + (lane&15)], j = 0..7
 // in_blocks = ceil(16 in_tiles / 32), out_blocks = ceil(16 out_tiles / 32); elements beyond the matrix are zeros.
+// max |W| of a Linear -> the exponent its packed fp16 planes are scaled by (mcpc_gemm_f16.h: scale_exp_for_max).  One block.
+__global__ __launch_bounds__(1024) void mcpc_wexp_kernel(const float* __restrict__ W, size_t n, int* __restrict__ wexp_slot) {
+    __shared__ float part[16];
+    float mx = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, fabsf(W[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmaxf(mx, part[w]);
+        *wexp_slot = scale_exp_for_max(mx);
+    }
+}
+
 __global__ void mcpc_pack_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                  float* __restrict__ Wf_, float* __restrict__ Wb_, float* __restrict__ bias_pad,
-                                 int n_out, int n_in, int out_tiles, int in_tiles) {
+                                 int n_out, int n_in, int out_tiles, int in_tiles, const int* __restrict__ wexp_slot) {
     u32x4* const Wf = reinterpret_cast<u32x4*>(Wf_);
     u32x4* const Wb = reinterpret_cast<u32x4*>(Wb_);
+    const float ws = pow2i(*wexp_slot);                    // (written by mcpc_wexp_kernel on the same stream)
     const int in_blocks = (16 * in_tiles + kKB - 1) / kKB, out_blocks = (16 * out_tiles + kKB - 1) / kKB;
     const size_t n_fwd = (size_t)out_tiles * in_blocks * 64, n_bwd = (size_t)in_tiles * out_blocks * 64;
     const size_t total = n_fwd > n_bwd ? n_fwd : n_bwd;
@@ -651,8 +686,8 @@ __global__ void mcpc_pack_kernel(const float* __restrict__ W, const float* __res
                 const int k = kKB * kb + 8 * g + j;
                 v[j] = (u < n_out && k < n_in) ? W[(size_t)u * n_in + k] : 0.f;
             }
-            const frag_t f = split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
-            Wf[blk * kFragBlock + lane] = f.h; Wf[blk * kFragBlock + 64 + lane] = f.m; Wf[blk * kFragBlock + 128 + lane] = f.l;
+            const frag_t f = split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, ws);
+            Wf[blk * kFragBlock + lane] = f.h; Wf[blk * kFragBlock + 64 + lane] = f.m;
         }
         if (idx < n_bwd) {   // blk = it * out_blocks + ub
             const int it = blk / out_blocks, ub = blk % out_blocks;
@@ -663,8 +698,8 @@ __global__ void mcpc_pack_kernel(const float* __restrict__ W, const float* __res
                 const int u = kKB * ub + 8 * g + j;
                 v[j] = (u < n_out && i < n_in) ? W[(size_t)u * n_in + i] : 0.f;
             }
-            const frag_t f = split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
-            Wb[blk * kFragBlock + lane] = f.h; Wb[blk * kFragBlock + 64 + lane] = f.m; Wb[blk * kFragBlock + 128 + lane] = f.l;
+            const frag_t f = split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, ws);
+            Wb[blk * kFragBlock + lane] = f.h; Wb[blk * kFragBlock + 64 + lane] = f.m;
         }
     }
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
