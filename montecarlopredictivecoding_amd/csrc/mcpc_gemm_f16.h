@@ -2,10 +2,10 @@
 //
 // Every contraction of a Langevin step is out^T[unit][chain] = W[unit][k] . act^T[k][chain] in fp32.  Rounds 3-4 emulated the fp32 product
 // with three bf16 pieces per operand and six v_mfma_f32_16x16x32_bf16 per 32-deep block ("bf16x6": 24 significant bits per operand).  This
-// core uses TWO fp16 pieces per operand (11 + 11 = 22 significant bits) and FOUR v_mfma_f32_16x16x32_f16 -- same issue rate per instruction,
-// two thirds of the instructions, two fragment planes instead of three (4 B per weight instead of 6 through the CU's vector-memory path)
-// and a split of 24 instead of 47 VALU instructions per 8 values:
-//      a b  ~  a_m b_m + (a_m b_h + a_h b_m) + a_h b_h,          a = (a_h + a_m) 2^-sa,  b = (b_h + b_m) 2^-sb.
+// core uses TWO fp16 pieces per operand (11 + 11 = 22 significant bits) and THREE v_mfma_f32_16x16x32_f16 (four in GEMMs with K <= 64) --
+// same issue rate per instruction, half the instructions, two fragment planes instead of three (4 B per weight instead of 6 through the
+// CU's vector-memory path) and a split of 24 instead of 47 VALU instructions per 8 values:
+//      a b  ~  [a_m b_m] + (a_m b_h + a_h b_m) + a_h b_h,        a = (a_h + a_m) 2^-sa,  b = (b_h + b_m) 2^-sb.
 // fp16 has 5 exponent bits, so both operands are SCALED BY POWERS OF TWO (exact) before the split: the weights of a Linear by one
 // exponent chosen when they are packed (max |W| -> [2^14, 2^15)), the B operand PER CHAIN ROW by an exponent the GEMM wave takes from
 // the row's own maximum in a pre-pass over the row (rows of one chain never share a scale with another chain's: chains stay
@@ -96,7 +96,10 @@ __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned
 //   run       GS_ACCUM: the B exponent the accumulators are in (kRunNone before the first chunk); per lane = per chain.
 enum : int { GS_FRESH = 0, GS_ACCUM = 1 };
 constexpr int kScaleAuto = -1000, kRunNone = 1000;
-struct GemmScale { int a_exp; int mode; int fixed_b; int run; };
+//   short_k   1: the whole contraction has K <= 64 and keeps the a_m b_m term (gemm_fixed: MM); 0: it does not; -1: decided from this GEMM's own
+//             k-blocks.  A sum over several GEMMs (GS_ACCUM) must be told: its chunks may be short where the contraction is long, and how
+//             the contraction is cut into chunks must not change its arithmetic.
+struct GemmScale { int a_exp; int mode; int fixed_b; int run; int short_k; };
 
 #ifdef MCPC_EXP_NOLOAD   // timing experiment only (wrong results): every fragment load re-reads k-block 0 -> L1 hits
 #define MCPC_KSEL(k_) 0
@@ -119,7 +122,12 @@ struct GemmScale { int a_exp; int mode; int fixed_b; int run; };
 // (Two chain tiles per fragment -- CTT = 2 -- were measured in rounds 4 and 5 and dropped: profiles/r04_k1_bounds.txt, r05_k1_decomp.txt.)
 //
 // bscale = 2^sb of this lane's chain row (gemm_row_exp below, or the caller's fixed exponent).
-template <int NT, int NTT, int CTT, int NW>
+// MM: with the a_m b_m term (2^-22 of the leading one).  GEMMs of at most kShortK k-blocks (K <= 64) keep it: there are too few terms there
+// for the rounding errors of the 22-bit operands to average out (K = 32: max 1.6e-7 / rms 3.1e-8 of sum |terms| without it against 1.2e-7 /
+// 2.6e-8 with it; fp32 MFMA chain 1.0e-7 / 2.1e-8).  From K = 96 on the term changes neither figure (profiles/r05_f16x4_study.txt) and longer
+// GEMMs run THREE MFMAs per product.
+constexpr int kShortK = 2;
+template <int NT, int NTT, int CTT, int NW, bool MM>
 __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nkb, int kw,
                                            const float* B, int ldb, int lane, frag_t (&pre)[NTT], const float* zeros, float bscale) {
     static_assert(CTT == 1, "one chain tile per workgroup (two were measured and dropped in rounds 4 and 5: DESIGN.md section 4)");
@@ -167,7 +175,8 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
     do { MCPC_M4(s_, G_, ct_, m, h); MCPC_M4(s_, G_, ct_, h, h); } while (0)
 #else
 #define MCPC_SUB(s_, G_, ct_)                                                                       \
-    do { MCPC_M4(s_, G_, ct_, m, m); MCPC_M4(s_, G_, ct_, m, h); MCPC_M4(s_, G_, ct_, h, m); MCPC_M4(s_, G_, ct_, h, h); } while (0)
+    do { if constexpr (MM) { MCPC_M4(s_, G_, ct_, m, m); }                                           \
+         MCPC_M4(s_, G_, ct_, m, h); MCPC_M4(s_, G_, ct_, h, m); MCPC_M4(s_, G_, ct_, h, h); } while (0)
 #endif
 #define MCPC_SPLIT1(ct_) bs[ct_] = split8(bC[ct_][0], bC[ct_][1], bscale)
     // One k-block: the chain tile's planes are read by both sub-steps, so the next block's split goes into a second copy beside
@@ -196,10 +205,12 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
     MCPC_LOAD_B(1);
     int k = 0;
     // steady state: three k-blocks per round (the rotation's period); every request is for an existing block or clamped to the last
-    for (; k + 3 <= nkb; k += 3) {
-        MCPC_BLOCK(s0, s1, s2, k);          // (k, G0) = s0, (k, G1) = s1;  s2 <- (k+1, G0), s0 <- (k+1, G1)
-        MCPC_BLOCK(s2, s0, s1, k + 1);      // s1 <- (k+2, G0), s2 <- (k+2, G1)
-        MCPC_BLOCK(s1, s2, s0, k + 2);      // s0 <- (k+3, G0), s1 <- (k+3, G1): the round's starting assignment again
+    if constexpr (!MM) {                    // (MM: at most kShortK = 2 blocks, the tail below)
+        for (; k + 3 <= nkb; k += 3) {
+            MCPC_BLOCK(s0, s1, s2, k);          // (k, G0) = s0, (k, G1) = s1;  s2 <- (k+1, G0), s0 <- (k+1, G1)
+            MCPC_BLOCK(s2, s0, s1, k + 1);      // s1 <- (k+2, G0), s2 <- (k+2, G1)
+            MCPC_BLOCK(s1, s2, s0, k + 2);      // s0 <- (k+3, G0), s1 <- (k+3, G1): the round's starting assignment again
+        }
     }
     const int rem = nkb - k;
     if (rem == 2) {
@@ -251,14 +262,14 @@ __device__ __forceinline__ void gemm_unscale(f32x4 (&acc)[NTT][CTT], int a_exp, 
 }
 
 // nt (wave-uniform, 1..NTT) selects a straight-line instantiation: no per-tile branches in the loop
-template <int N, int NTT, int CTT, int NW>
+template <int N, int NTT, int CTT, int NW, bool MM>
 __device__ __forceinline__ void gemm_dispatch(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nt, int nkb, int kw,
                                               const float* B, int ldb, int lane, frag_t (&pre0)[NTT], const float* zeros, float bscale) {
     if constexpr (N >= NTT) {
-        gemm_fixed<NTT, NTT, CTT, NW>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0, zeros, bscale);
+        gemm_fixed<NTT, NTT, CTT, NW, MM>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0, zeros, bscale);
     } else {
-        if (nt == N) gemm_fixed<N, NTT, CTT, NW>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0, zeros, bscale);
-        else gemm_dispatch<N + 1, NTT, CTT, NW>(acc, A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, bscale);
+        if (nt == N) gemm_fixed<N, NTT, CTT, NW, MM>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0, zeros, bscale);
+        else gemm_dispatch<N + 1, NTT, CTT, NW, MM>(acc, A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, bscale);
     }
 }
 // kw: valid k width of the B rows (a multiple of 16, 32 (nkb - 1) < kw <= 32 nkb); zeros: 16 floats of LDS that stay zero for the launch.
@@ -282,7 +293,9 @@ __device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const void* A
         }
         gs.run = b_exp;
     }
-    gemm_dispatch<1, NTT, CTT, NW>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, pow2i(b_exp));
+    const bool mm = gs.short_k >= 0 ? gs.short_k != 0 : nkb <= kShortK;
+    if (mm && nkb <= kShortK) gemm_dispatch<1, NTT, CTT, NW, true>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, pow2i(b_exp));
+    else gemm_dispatch<1, NTT, CTT, NW, false>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, pow2i(b_exp));
     if (gs.mode == GS_FRESH) gemm_unscale<NTT, CTT>(acc, gs.a_exp, b_exp);
 }
 
