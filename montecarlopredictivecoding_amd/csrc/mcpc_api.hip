@@ -188,6 +188,9 @@ struct mcpc_engine {
     int n_phases = 0;
     int* err = nullptr;             // device error word written by the kernels
     int* wexp = nullptr;            // [kMaxLatent + 1] per Linear: the power of two its packed weights are scaled by (mcpc_wexp_kernel)
+    unsigned* spillmax = nullptr;   // [kMaxRingParts][kSpillTensors]: per ring part, the largest |value| per spilled tensor of the segment
+                                    // that filled it (bit patterns; written by the step kernels, read by the Hebbian GEMMs of that part)
+    int lds_spillmax = 0;
     unsigned long long* clk = nullptr;   // profiling: {shader cycles, 100 MHz ticks} of one wave per launch (KParams::clk)
     float* dummy = nullptr;         // 4 KiB of zeros (KParams::dummy)
     // Round schedule (setup_rounds): a shard of more 16-chain units than CUs as `rr_k` launches per cycle, each unit in `rr_m` of them
@@ -244,7 +247,7 @@ int free_all(mcpc_engine* e) {
     if (e->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(e->comm); e->comm = nullptr; e->comm_ranks = 0; }
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int l = 0; l < kMaxLatent; ++l) { F(e->x[l]); F(e->m[l]); F(e->v[l]); F(e->spill_a[l]); F(e->spill_e[l]); }
-    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ytile); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err); F(e->wexp); F(e->clk); F(e->dummy);
+    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ytile); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err); F(e->wexp); F(e->spillmax); F(e->clk); F(e->dummy);
     for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (int h = 0; h < kMaxRingParts; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
@@ -315,7 +318,8 @@ int plan_lds(mcpc_engine* e) {
     for (int l = 1; l < e->L; ++l) { e->lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
     e->lds_e[0] = 0;
     e->lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
-    e->lds_zero = off; off += 16;            // (mcpc_gemm6.h: what lanes beyond a ragged k range read)
+    e->lds_zero = off; off += 16;            // (mcpc_gemm_f16.h: what lanes beyond a ragged k range read)
+    e->lds_spillmax = off; off += kSpillTensors;     // the workgroup's largest |value| per spilled tensor (mcpc_kernels.h: spill_track)
     e->lds_bytes = off * (int)sizeof(float);
     if (e->lds_bytes > 160 * 1024)
         return fail(MCPC_ENOMEM, "network needs %d bytes of LDS per workgroup (> 163840): latent widths too large for the fused kernel", e->lds_bytes);
@@ -368,6 +372,7 @@ int plan_lds_ws2(mcpc_engine* e, bool allow_xl = true) {
     // multiple of 32 read THESE 16 floats instead of what lies behind the row (mcpc_gemm6.h): zero-filled at launch, never written.
     e->lds_zero = off;
     off += 16;
+    e->lds_spillmax = off; off += kSpillTensors;     // the workgroup's largest |value| per spilled tensor (mcpc_kernels.h: spill_track)
     // with room to spare (16-chain plans: 45 KB at cfg-M) the lean epilogues keep what they read every step in LDS: the state rows
     // X_l (layout of FX_l), the bias rows, the mu_1 rows (layout of FX_0), the read-out bias and the bit-packed target rows
     e->xl = false;
@@ -804,6 +809,8 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if ((rc = e->ws == 2 ? build_phases_ws2(e) : build_phases(e))) return bail(rc);
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
     if (hipMemset(e->err, 0, sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
+    if ((rc = dmalloc(e->spillmax, (size_t)kMaxRingParts * kSpillTensors))) return bail(rc);
+    if (hipMemset(e->spillmax, 0, (size_t)kMaxRingParts * kSpillTensors * sizeof(unsigned)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
     if ((rc = dmalloc(e->wexp, kMaxLatent + 1))) return bail(rc);
     if (hipMemset(e->wexp, 0, (kMaxLatent + 1) * sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
     if ((rc = dmalloc(e->clk, 2))) return bail(rc);
@@ -1007,7 +1014,7 @@ int launch_heb(const HebArgs& a, hipStream_t stream) {
 template <int TE, int RA, bool SW = false>
 int launch_heb7(const HebArgs& a, hipStream_t stream) {
     // two plane buffers + the bias sums + every wave's transpose scratch for one activation tile (2 row tiles x 4 x 17 float4)
-    constexpr int lds_bytes = 2 * 3 * 16 * TE * kHeb7LD * 2 + 16 * TE * (int)sizeof(float) + 8 * 2 * 272 * (int)sizeof(float);
+    constexpr int lds_bytes = 2 * 2 * 16 * TE * kHeb7LD * 2 + 16 * TE * (int)sizeof(float) + 8 * 2 * 272 * (int)sizeof(float);
     static bool attr_set[16] = {false};      // per device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1083,7 +1090,9 @@ int ensure_spill(mcpc_engine* e, hipStream_t stream) {
 
 // One Hebbian flush: fold `n_slots` spilled steps into the gradient sums of every Linear j >= 1.  Every Linear has its own
 // slab region, so the GEMMs of a flush are independent launches and ONE reduction launch follows them.
-int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
+static inline int spill_id_a_host(int l) { return l; }                  // (mcpc_kernels.h: spill_id_a)
+int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream, int part) {
+    const unsigned* const smax = e->spillmax + (size_t)part * kSpillTensors;      // largest |value| per spilled tensor of this segment
     const int rows = n_slots * e->Bpad;
     const int nlin = e->L + (e->has_head ? 1 : 0);
     ReduceJobs jobs{};
@@ -1105,6 +1114,7 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
         const float* E = (j < e->L ? e->spill_e[j] : e->spill_eo) + (size_t)slot0 * e->Bpad * ne;
         const float* A = e->spill_a[j - 1] + (size_t)slot0 * e->Bpad * na;
         const HebPlan h = plan_hebbian(e, ne, na, rows);
+        const int e_id = j < e->L ? kMaxLatent + j : kSpillIdEo;          // (mcpc_kernels.h: spill_id_e / kSpillIdEo)
         float* slab = e->slab + ln.slab_off;
         float* slab_b = slab + (size_t)h.ksplit * ne * na;
         if ((size_t)h.ksplit * ((size_t)ne * na + ne) > ln.slab_floats)
@@ -1112,7 +1122,7 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
         if (h.swapped) {
             stream = next_stream((double)ne * na);
             // transposed product: the activations take the E slot, the errors the A slot; slab = [split][na][ne]
-            HebArgs a{A, E, slab, slab_b, rows, na, ne, h.rps, 1, 1, h.ksplit, 0};
+            HebArgs a{A, E, slab, slab_b, rows, na, ne, h.rps, 1, 1, h.ksplit, 0, smax + spill_id_a_host(j - 1), smax + e_id};
             int rc = 0;
             if (!e->knobs.heb_fp32) {
                 if (h.te[0] == 1) rc = launch_heb7<1, 2, true>(a, stream);
@@ -1127,7 +1137,7 @@ int flush_spill(mcpc_engine* e, int n_slots, int slot0, hipStream_t stream) {
             int col = 0;
             for (int part = 0; part < 2; ++part) {
                 if (h.n_mt[part] == 0) continue;
-                HebArgs a{E, A, slab, slab_b, rows, ne, na, h.rps, h.n_mt[part], h.n_nt, h.ksplit, col};
+                HebArgs a{E, A, slab, slab_b, rows, ne, na, h.rps, h.n_mt[part], h.n_nt, h.ksplit, col, smax + e_id, smax + spill_id_a_host(j - 1)};
                 stream = next_stream((double)h.n_mt[part] * h.te[part] * 16 * na);
                 int rc = 0;
                 const int te = h.te[part];
@@ -1319,7 +1329,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         H.lds_bias = e->lds_hbias; H.lds_yw = e->lds_yw;
     }
     P.mu1 = e->mu1; P.epart = e->epart; P.epart_slots = (int)eslots;
-    P.phases = e->phases; P.n_phases = e->n_phases; P.wexp = e->wexp;
+    P.phases = e->phases; P.n_phases = e->n_phases; P.wexp = e->wexp; P.spillmax = nullptr; P.lds_spillmax = e->lds_spillmax;
     P.stagger_cycles = e->knobs.stagger;
     P.L = e->L; P.has_head = e->has_head; P.B = e->d.batch; P.Bpad = e->Bpad; P.T = r->T;
     P.xopt = r->xopt_kind; P.update_x = r->update_x ? 1 : 0;
@@ -1444,6 +1454,11 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             if (e->has_head) P.head.spill_e = e->spill_eo + (size_t)slot0 * e->Bpad * e->out_pad;
             // this half of the ring may still be read by the flush that was started two segments ago
             if (overlap && e->flush_pending[half]) { HIP_TRY(hipStreamWaitEvent(stream, e->ev_flush[half], 0)); e->flush_pending[half] = false; }
+            // the segment's largest |value| per spilled tensor: starts at zero, raised by the step kernel's workgroups, read by the flush
+            P.spillmax = e->spillmax + (size_t)(overlap ? half : 0) * kSpillTensors;
+            HIP_TRY(hipMemsetAsync(P.spillmax, 0, kSpillTensors * sizeof(unsigned), stream));
+        } else {
+            P.spillmax = nullptr;
         }
         if (rr_q >= 1) {
             const int rc = run_round_cycle(P, t, rr_q);
@@ -1511,13 +1526,13 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
                 // the Hebbian GEMMs of this half run on the low-priority stream while the next segment steps
                 HIP_TRY(hipEventRecord(e->ev_steps[half], stream));
                 HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_steps[half], 0));
-                int rc = flush_spill(e, n, slot0, e->aux);
+                int rc = flush_spill(e, n, slot0, e->aux, half);
                 if (rc) return rc;
                 HIP_TRY(hipEventRecord(e->ev_flush[half], e->aux));
                 e->flush_pending[half] = true;
                 half = (half + 1) % n_parts;
             } else {
-                int rc = flush_spill(e, n, 0, stream);
+                int rc = flush_spill(e, n, 0, stream, 0);
                 if (rc) return rc;
             }
         }

@@ -121,6 +121,23 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Maximum over the 64 lanes of a non-negative value, returned wave-uniform (the DPP steps of wave_sum with v_max_f32; NaN inputs are
+// skipped by v_max).
+__device__ __forceinline__ float wave_max(float v) {
+    auto dpp_max = [](float x, auto ctrl, auto row_mask) {
+        const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, true);
+        return fmaxf(x, __builtin_bit_cast(float, moved));
+    };
+    using std::integral_constant;
+    v = dpp_max(v, integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});      // row_shr:1   (lanes shifted in from outside read 0: v >= 0)
+    v = dpp_max(v, integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});      // row_shr:2
+    v = dpp_max(v, integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});      // row_shr:4
+    v = dpp_max(v, integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});      // row_shr:8  -> lane 15 of a row: its maximum
+    v = dpp_max(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});      // row_bcast:15 into rows 1 and 3
+    v = dpp_max(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});      // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

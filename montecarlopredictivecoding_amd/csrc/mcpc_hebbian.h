@@ -34,6 +34,8 @@ struct HebArgs {
     int rows_per_split;              // multiple of 32
     int n_mt, n_nt, ksplit;          // error-tile groups, activation-tile groups, K splits: grid = n_mt * n_nt * ksplit workgroups
     int e_col_base;                  // first E column of this launch (a Linear may be covered by launches of different TE)
+    const unsigned* e_max;           // mcpc_heb7_kernel: bit pattern of the largest |value| in the E image of this segment, and in the A image:
+    const unsigned* a_max;           //   the powers of two its fp16 operands are scaled by (written by the step kernels: KParams::spillmax)
 };
 
 #ifndef MCPC_HEB_LD_AUX
@@ -194,10 +196,17 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
     }
 }
 
-// ---- bf16x6 form of the tiled kernel, round 4: mcpc_heb7_kernel (the default; tuning heb_fp32=1 selects the fp32-MFMA kernel above) -----
-// The same GEMM with the spilled fp32 operands split into three bf16 pieces (the six products whose magnitude is above 2^-24 of the
-// leading one, fp32 accumulation, small terms first; mcpc_bf16x6.h) on v_mfma_f32_16x16x32_bf16: against an fp64 sum its error is that
-// of the fp32-MFMA kernel (max 2.7e-7 / rms 3.1e-8 of sum|terms| against 2.1e-7 / 2.7e-8 at K = 4096, scripts/heb_bf16_ubench.hip).
+// ---- fp16 form of the tiled kernel: mcpc_heb7_kernel (the default; tuning heb_fp32=1 selects the fp32-MFMA kernel above) ---------------------
+// Round 4 ran this GEMM with the spilled fp32 operands split into three bf16 pieces and six v_mfma_f32_16x16x32_bf16 per product.  Round 5:
+// TWO fp16 pieces per operand (22 significant bits) and THREE v_mfma_f32_16x16x32_f16 -- a_m b_h + a_h b_m + a_h b_h; the a_m b_m term,
+// 2^-22 of the leading one, changes neither the maximal nor the rms error of a sum over this many rows (profiles/r05_f16x4_study.txt) --
+// as in the step kernels' GEMM core (mcpc_gemm_f16.h), with the operands SCALED BY POWERS OF TWO so that they fit fp16's five exponent bits.
+// Here the sum runs over the spilled ROWS, so a scale must be the same for every row: one exponent per operand IMAGE, taken from the largest
+// |value| the step kernel spilled of that tensor in this segment (KParams::spillmax: every epilogue wave keeps the maximum of what it
+// spills; HebArgs::e_max / a_max).  Values within 2^16 of their image's maximum keep all 22 bits; smaller ones keep an absolute error below
+// 2^-39 of the maximum -- invisible in a sum that holds terms of the maximum's size.  The accumulators are un-scaled (exact) when the
+// partial sums are written.  Against an fp64 sum the error is that of the fp32-MFMA kernel and of round 4's bf16x6 form (the tests'
+// fp64 windows hold at unchanged tolerances).
 //
 // Round 3's form (mcpc_heb6_kernel) kept the planes of BOTH panels of a 32-row stage in LDS (126 KB: no second buffer), so every stage
 // was "all threads split -> barrier -> all waves MFMA -> barrier": MFMA busy 58 %, LDS bank conflicts 0.41 of the LDS-active cycles
@@ -208,8 +217,8 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb_kernel(const HebArgs 
 //   * the ACTIVATION operand never touches LDS: wave w owns activation tiles RA w .. RA w + RA - 1 and no other wave needs them, so
 //     lane (m, g) gathers its eight values (unit m, rows 4g..4g+3 of both row tiles of the stage) straight from global memory
 //     (8 dwords per tile, the same 16 cache lines for all eight) and splits them in registers;
-//   * the ERROR panel (all waves need all TE tiles) goes through LDS as three bf16 planes [unit][32 rows] in rows of 80 B, now
-//     DOUBLE-BUFFERED (2 x 65 KB at TE = 17): the split of stage s+1 and the MFMAs of stage s run in the same barrier interval, waves
+//   * the ERROR panel (all waves need all TE tiles) goes through LDS as two fp16 planes [unit][32 rows] in rows of 80 B,
+//     DOUBLE-BUFFERED (2 x 43 KB at TE = 17): the split of stage s+1 and the MFMAs of stage s run in the same barrier interval, waves
 //     0-3 splitting first and waves 4-7 multiplying first, so that on every SIMD one wave's conversion sits beside the other's MFMAs;
 //   * a thread of the split pass holds (row c, row 16 + c) x 4 units -- the same lane of the two row tiles of one unit tile, two
 //     coalesced float4 loads -- and writes one dword per unit and plane: k-slot pair (2c, 2c+1) = rows (c, 16 + c).  The MFMA's k order
@@ -224,7 +233,8 @@ template <int TE, int RA, bool SWAPPED = false>
 __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb7_kernel(const HebArgs P) {
     constexpr int TPW = (TE + 7) / 8;                   // error tiles a wave converts per stage (tile j = w + 8 i)
     constexpr int PLANE = 16 * TE * kHeb7LD;            // bf16 elements per plane
-    extern __shared__ __attribute__((aligned(16))) unsigned short lds7[];       // [2 buffers][3 planes][16 TE units][40] bf16
+    constexpr int NPL = 2;                              // planes per buffer: the two fp16 pieces
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds7[];       // [2 buffers][2 planes][16 TE units][40] fp16
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, g = lane >> 4;             // MFMA view: unit m of a tile, k group g
@@ -242,6 +252,9 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb7_kernel(const HebArgs
     const int r1 = min(P.rows, r0 + P.rows_per_split);
     const int n_stage = (r1 - r0) / kHeb7KB;
     const size_t rt_base = (size_t)r0 / 16;             // first row tile of this split (rows_per_split is a multiple of 32)
+    // the powers of two the two operand images are scaled by: from the largest |value| the step kernels spilled of each in this segment
+    const int e_exp = scale_exp_for_max(__uint_as_float(*P.e_max)), a_exp = scale_exp_for_max(__uint_as_float(*P.a_max));
+    const float e_scale = pow2i(e_exp), a_scale = pow2i(a_exp);
 
     // ---- what this thread loads per stage ------------------------------------------------------------------------------------
     // Addresses = a wave-uniform 64-bit base (scalar registers, advanced by the scalar ALU) + ONE 32-bit byte offset per lane that never
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb7_kernel(const HebArgs
     // wave's own lgkmcnt): written as float4s, read back as 8 dwords per tile.  Quad q's 16 rows start 17 float4 slots apart, so
     // that the 32 lanes of a ds_read_b32 group ((q, g mod 2, m mod 4): dword 68 q + 16 g + 4 i + m mod 4) hit 32 different banks.
     // (Gathering the 8 dwords straight from global memory cost 7 % of the kernel: each such wave instruction touches 16 cache lines.)
-    float* const a_scr = reinterpret_cast<float*>(lds7 + 2 * 3 * PLANE) + 16 * TE + (size_t)w * (2 * 272);     // (one tile's two row tiles: reused tile after tile)
+    float* const a_scr = reinterpret_cast<float*>(lds7 + 2 * NPL * PLANE) + 16 * TE + (size_t)w * (2 * 272);     // (one tile's two row tiles: reused tile after tile)
     const int a_wr = 4 * (17 * q + c);                                                          // float offset of this lane's float4 in a tile image
     const int a_rd = 4 * (17 * (m >> 2) + 4 * g) + (m & 3);                                     // ... of (unit m, row 4 g)
     // (no load under a branch: hipcc joins the paths behind s_waitcnt vmcnt(0) -- a stage past the end re-reads the last one, a tile
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb7_kernel(const HebArgs
     // (E panel: per stage the 16 rows-pairs of a unit quad are summed across their DPP row and ONE lane adds the quad's four sums to a
     // running fp32 value in LDS -- a fixed lane, stage after stage: the same order in every run -- instead of 4 TPW accumulator registers
     // per thread in a kernel that has none to spare)
-    float* const bias_lds = reinterpret_cast<float*>(lds7 + 2 * 3 * PLANE);          // [16 TE] behind the two plane buffers
+    float* const bias_lds = reinterpret_cast<float*>(lds7 + 2 * NPL * PLANE);          // [16 TE] behind the two plane buffers
     float asum[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) asum[j] = 0.f;
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb7_kernel(const HebArgs
 #if defined(MCPC_HEB_EXP) && MCPC_HEB_EXP == 2      // timing experiment only (wrong sums): no conversion, no plane stores
         if (P.rows >= 0) return;
 #endif
-        unsigned short* const base = lds7 + (size_t)buf * 3 * PLANE + (size_t)(4 * q) * kHeb7LD + 2 * c;
+        unsigned short* const base = lds7 + (size_t)buf * NPL * PLANE + (size_t)(4 * q) * kHeb7LD + 2 * c;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             if ((w + 8 * i) >= TE) continue;
@@ -334,16 +347,15 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb7_kernel(const HebArgs
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                unsigned h, mm, ll;
-                split3_pair_fast(f32x2{v0[u], v1[u]}, h, mm, ll);
+                unsigned h, mm;
+                split2_pair(f32x2{v0[u], v1[u]}, e_scale, h, mm);
                 unsigned short* const dst = base + (size_t)(16 * (w + 8 * i) + u) * kHeb7LD;
                 *reinterpret_cast<unsigned*>(dst) = h;
                 *reinterpret_cast<unsigned*>(dst + PLANE) = mm;
-                *reinterpret_cast<unsigned*>(dst + 2 * PLANE) = ll;
             }
         }
     };
-    struct Op { u32x4 h, m, l; };
+    struct Op { u32x4 h, m; };
     auto make_a = [&](int j) {
         // registers -> the wave's scratch -> (unit m, rows 4g+i of both row tiles)
 #pragma unroll
@@ -354,10 +366,10 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb7_kernel(const HebArgs
         Op o;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            unsigned h, mm, ll;
+            unsigned h, mm;
             const float a0 = a_scr[a_rd + 4 * i], a1 = a_scr[272 + a_rd + 4 * i];
-            split3_pair_fast(f32x2{a0, a1}, h, mm, ll);
-            o.h[i] = h; o.m[i] = mm; o.l[i] = ll;
+            split2_pair(f32x2{a0, a1}, a_scale, h, mm);
+            o.h[i] = h; o.m[i] = mm;
             if (a_bias) asum[j] += a0 + a1;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the next tile's stores come after these reads)
@@ -371,40 +383,24 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb7_kernel(const HebArgs
 #pragma unroll
         for (int j = 0; j < RA; ++j) acc[i][j] = splat(0.f);
 
-    // The six products of an error tile, small terms first: (l h) (m m) (h l) | (m h) (h m) | (h h).  A plane of the error operand is
-    // re-read for the NEXT tile as soon as its last product of this tile has been issued (l after the first, m after the fourth; only
-    // the h plane, used by the last product, needs a second register set): the LDS round trip of the next tile's operands hides
-    // behind this tile's MFMAs at 4 extra registers instead of 12.
+    // The three products of an error tile, small terms first: (m h) (h m) (h h).  Both planes of the NEXT tile are requested at the head of
+    // this one (a second register set of 8): their LDS round trip hides behind this tile's 3 RA MFMAs and the partner wave's work.
     auto mfma_stage = [&](int buf, const Op (&ao)[RA]) {
 #if defined(MCPC_HEB_EXP) && MCPC_HEB_EXP == 5      // timing experiment only: no MFMA phase
         if (P.rows >= 0) return;
 #endif
-        const unsigned short* const rd = lds7 + (size_t)buf * 3 * PLANE + (size_t)m * kHeb7LD + 8 * g;     // lane (m, g): plane[p][16 t + m][8 g ..]
-        u32x4 eh = *reinterpret_cast<const u32x4*>(rd), em = *reinterpret_cast<const u32x4*>(rd + PLANE),
-              el = *reinterpret_cast<const u32x4*>(rd + 2 * PLANE);
+        const unsigned short* const rd = lds7 + (size_t)buf * NPL * PLANE + (size_t)m * kHeb7LD + 8 * g;     // lane (m, g): plane[p][16 t + m][8 g ..]
+        u32x4 eh = *reinterpret_cast<const u32x4*>(rd), em = *reinterpret_cast<const u32x4*>(rd + PLANE);
 #pragma unroll
         for (int i = 0; i < TE; ++i) {
             const unsigned short* const nx = rd + (size_t)(16 * (i + 1 < TE ? i + 1 : i)) * kHeb7LD;
             __builtin_amdgcn_sched_barrier(0);
-            const u32x4 ehn = *reinterpret_cast<const u32x4*>(nx);
-#define H7(e_, ap_) _Pragma("unroll") for (int j = 0; j < RA; ++j) acc[i][j] = mfma6(e_, ao[j].ap_, acc[i][j])
-            H7(el, h);
-            __builtin_amdgcn_sched_barrier(0);
-            el = *reinterpret_cast<const u32x4*>(nx + 2 * PLANE);
-#if defined(MCPC_HEB_EXP) && MCPC_HEB_EXP == 6      // timing experiment: the m plane is free (and re-read) one product earlier
-            H7(em, m); H7(em, h);
-            __builtin_amdgcn_sched_barrier(0);
-            em = *reinterpret_cast<const u32x4*>(nx + PLANE);
-            H7(eh, l); H7(eh, m); H7(eh, h);
-#else
-            H7(em, m); H7(eh, l); H7(em, h);
-            __builtin_amdgcn_sched_barrier(0);
-            em = *reinterpret_cast<const u32x4*>(nx + PLANE);
-            H7(eh, m); H7(eh, h);
-#endif
+            const u32x4 ehn = *reinterpret_cast<const u32x4*>(nx), emn = *reinterpret_cast<const u32x4*>(nx + PLANE);
+#define H7(e_, ap_) _Pragma("unroll") for (int j = 0; j < RA; ++j) acc[i][j] = mfma4(e_, ao[j].ap_, acc[i][j])
+            H7(em, h); H7(eh, m); H7(eh, h);
 #undef H7
             __builtin_amdgcn_sched_barrier(0);
-            eh = ehn;
+            eh = ehn; em = emn;
         }
     };
 
@@ -448,7 +444,8 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb7_kernel(const HebArgs
         }
     }
 
-    // C layout of tile (i, j): row 4 g + reg -> error unit, column m -> activation unit
+    // C layout of tile (i, j): row 4 g + reg -> error unit, column m -> activation unit; the sums leave their scaled units here (exact)
+    const float unscale = pow2i(-e_exp) * pow2i(-a_exp);
     float* out = P.slab + (size_t)split * P.ne * P.na;
 #pragma unroll
     for (int i = 0; i < TE; ++i) {
@@ -459,7 +456,7 @@ __global__ __launch_bounds__(kHebThreads, 2) void mcpc_heb7_kernel(const HebArgs
             const int a = a_col0 + 16 * (RA * w + j) + m;
             if (a >= P.na) continue;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) out[(size_t)(u0 + reg) * P.na + a] = acc[i][j][reg];
+            for (int reg = 0; reg < 4; ++reg) out[(size_t)(u0 + reg) * P.na + a] = acc[i][j][reg] * unscale;
         }
     }
     if (e_bias) {

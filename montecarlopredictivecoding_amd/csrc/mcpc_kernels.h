@@ -110,6 +110,9 @@ struct KParams {
     KHead head;
     const KPhase* phases;  // [n_phases] in device memory
     const int* wexp;       // [kMaxLatent + 1]: per Linear, the power of two its packed weights are scaled by (mcpc_wexp_kernel)
+    unsigned* spillmax;    // [kSpillTensors] bit patterns of the largest |value| spilled per tensor in this Hebbian segment (null: no spill):
+                           // the fp16 Hebbian GEMM scales its operands by powers of two taken from them (mcpc_hebbian.h)
+    int lds_spillmax;      // LDS float offset of the workgroup's own maxima (kSpillTensors words, zero at launch)
     int n_phases;
     int stagger_cycles;    // workgroups >= 256 (the second resident on a CU) start this many cycles late
     const float* mu1;      // prediction of the top latent layer [Bpad][npad_0] (inputs W0^T + b0)
@@ -170,6 +173,29 @@ __device__ __forceinline__ size_t spill_offset(int tm, size_t row, int u0, int n
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// ---- largest |value| per spilled tensor (for the Hebbian GEMM's operand scaling) ---------------------------------------------------------
+// tensor ids: activations A_l = l, errors E_l = kMaxLatent + l, read-out errors E_o = 2 kMaxLatent
+constexpr int kSpillTensors = 16;
+__device__ __forceinline__ int spill_id_a(int l) { return l; }
+__device__ __forceinline__ int spill_id_e(int l) { return kMaxLatent + l; }
+constexpr int kSpillIdEo = 2 * kMaxLatent;
+__device__ __forceinline__ float absmax4(float m, f32x4 v) {
+    return fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+}
+// the lanes' maxima over what an epilogue call spilled of one tensor -> the workgroup's running maximum of that tensor in LDS
+// (non-negative floats order like their bit patterns)
+__device__ __forceinline__ void spill_track(float* lds_max, int id, float lane_max, int lane) {
+    const float m = wave_max(lane_max);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(lds_max) + id, __float_as_uint(m));
+}
+// a wave that has finished its steps adds the workgroup's maxima (as far as they are known) to the segment's
+__device__ __forceinline__ void spill_max_publish(unsigned* gmax, const float* lds_max, int lane) {
+    if (gmax != nullptr && lane < kSpillTensors) {
+        const unsigned bits = reinterpret_cast<const volatile unsigned*>(lds_max)[lane];
+        if (bits != 0u) atomicMax(gmax + lane, bits);
+    }
+}
+
 // streamed once per step (state, targets, spills): nontemporal, so the per-XCD L2 (4 MiB) keeps the
 // 2.2 MB of packed weights every workgroup re-reads instead of cycling 4 MB of chain data through it
 __device__ __forceinline__ f32x4 ld4s(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
@@ -296,6 +322,7 @@ __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph
     float* const spill_e = Ly.spill_e;
     float* const rec = (rec_idx >= 0 && Ly.rec != nullptr) ? Ly.rec + (size_t)rec_idx * B * n : nullptr;
     float esum = 0.f;
+    float amx = 0.f, emx = 0.f;            // largest |value| this call spills of A_l / E_l (spill_track)
     // unrolled over the wave's tiles: independent quads give the scheduler ILP to cover the
     // transcendental / LDS / global latencies of a single wave (a rolled loop serialises them)
 #pragma unroll
@@ -320,8 +347,10 @@ __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph
                 const f32x4 z = splat(0.f);
                 const size_t srow = (size_t)slot * Bpad + chain;
                 st4s(spill_a + spill_offset(Ly.spill_a_tm, srow, u0, npad), live ? fx : z);
+                amx = absmax4(amx, live ? fx : z);
                 if (l > 0) {
                     st4s(spill_e + spill_offset(Ly.spill_e_tm, srow, u0, npad), live ? e : z);
+                    emx = absmax4(emx, live ? e : z);
                 } else if (live) {    // Linear 0 sees a constant input: only sum_t e_1 is needed
                     float* sp = spill_e + (size_t)chain * npad + u0;
                     st4s(sp, ld4s(sp) + e);
@@ -331,6 +360,10 @@ __device__ __forceinline__ float fwd_epilogue(const KParams& P, const KPhase& ph
             const f32x4 dd = d * d;
             esum += live ? 0.5f * ecoef * (dd.x + dd.y + dd.z + dd.w) : 0.0f;
         }
+    }
+    if (slot >= 0) {
+        spill_track(lds + P.lds_spillmax, spill_id_a(l), amx, lane);
+        if (l > 0) spill_track(lds + P.lds_spillmax, spill_id_e(l), emx, lane);
     }
     return esum;
 }
@@ -348,6 +381,7 @@ __device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& 
     float* const spill = H.spill_e;
     float* const rec = (rec_idx >= 0 && H.rec_out != nullptr) ? H.rec_out + (size_t)rec_idx * B * n : nullptr;
     float lsum = 0.f;
+    float omx = 0.f;                       // largest |value| this call spills of E_o (spill_track)
     // unrolled over the wave's tiles: independent quads give the scheduler ILP to cover the
     // transcendental / LDS / global latencies of a single wave (a rolled loop serialises them)
 #pragma unroll
@@ -395,10 +429,11 @@ __device__ __forceinline__ float headf_epilogue(const KParams& P, const KPhase& 
                 e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
             }
             st4(eo_lds + cl * ld + (u0 - 16 * ph.tile0), e);
-            if (slot >= 0) st4s(spill + spill_offset(H.spill_tm, (size_t)slot * Bpad + chain, u0, npad), e);
+            if (slot >= 0) { st4s(spill + spill_offset(H.spill_tm, (size_t)slot * Bpad + chain, u0, npad), e); omx = absmax4(omx, e); }
             if (rec != nullptr && live) st_unpadded(rec, chain, n, u0, o);
         }
     }
+    if (slot >= 0) spill_track(lds + P.lds_spillmax, kSpillIdEo, omx, lane);
     return lsum;
 }
 
@@ -639,6 +674,7 @@ __global__ __launch_bounds__(NW * 64, MCPC_BARRIER_WAVES_PER_EU) void mcpc_steps
         // pass, which only writes FX_0 and the other copy of red[]) orders this step's readers of
         // E_l / e_o before their next writers.
     }
+    spill_max_publish(P.spillmax, lds + P.lds_spillmax, lane);     // what this workgroup spilled at most, per tensor (every wave, when it is through)
 #ifdef MCPC_STAMPS
     if (lane == 0)
         for (int i = 0; i < 16; ++i) P.dbg[((size_t)blockIdx.x * NW + wave) * 16 + i] = st_sum[i];
@@ -647,7 +683,8 @@ __global__ __launch_bounds__(NW * 64, MCPC_BARRIER_WAVES_PER_EU) void mcpc_steps
 
 // ------------------------------------------------------------------------------------------------
 // Weight packing into MFMA fragment order (run once per parameter change).
-// bf16x6 core (mcpc_gemm6.h): every weight is split into three bf16 pieces, stored as three planes per (tile, 32-deep block):
+// f16 core (mcpc_gemm_f16.h): every weight, scaled by the Linear's power of two, is split into two fp16 pieces, stored as two planes per
+// (tile, 32-deep block):
 //   forward : Wf[ut][kb][plane][lane] (16 B) = W[16ut + (lane&15)][32kb + 8(lane>>4) + j], j = 0..7
 //   backward: Wb[it][ub][plane][lane] (16 B) = W[32ub + 8(lane>>4) + j][16it + (lane&15)], j = 0..7
 // in_blocks = ceil(16 in_tiles / 32), out_blocks = ceil(16 out_tiles / 32); elements beyond the matrix are zeros.

@@ -199,6 +199,7 @@ __device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPha
     const int spill_tm = vreg(H.spill_tm);
     float* const rec = (rec_idx >= 0 && H.rec_out != nullptr) ? H.rec_out + (size_t)rec_idx * P.B * H.n : nullptr;
     float lsum = 0.f;
+    float omx = 0.f;                       // largest |value| this call spills of E_o (mcpc_kernels.h: spill_track)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         if (i >= nt) continue;
@@ -240,10 +241,11 @@ __device__ __forceinline__ float ws2_headf_epilogue(const KParams& P, const KPha
                 e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
             }
             st4(lds + eo_off + cl * ld + (u0 - tile0x16), e);
-            if (slot >= 0) st4s(spill + spill_offset(spill_tm, (size_t)chain, u0, npad), e);
+            if (slot >= 0) { st4s(spill + spill_offset(spill_tm, (size_t)chain, u0, npad), e); omx = absmax4(omx, e); }
             if (rec != nullptr && live) st_unpadded(rec, chain, H.n, u0, o);
         }
     }
+    if (slot >= 0) spill_track(lds + P.lds_spillmax, kSpillIdEo, omx, lane);
     return lsum;
 }
 

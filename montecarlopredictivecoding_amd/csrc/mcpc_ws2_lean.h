@@ -157,6 +157,7 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
     const uint32_t img_bytes = (uint32_t)P.Bpad * npad4;               // one [Bpad][npad] image (lean_ok: < 4 GiB)
     const bool sys = P.spill_sys != 0;
     float esum = 0.f;
+    float amx = 0.f, emx = 0.f;            // largest |value| this call spills of A_l / E_l (mcpc_kernels.h: spill_track)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         if (i >= nt) continue;
@@ -177,7 +178,8 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
                 // tile-major image: (chain's row tile, unit tile) is one contiguous KiB, lane (c, q) its float4 number c + 16 q
                 const uint32_t sb_tm = mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q);
                 spill_st4(spill_a, img_bytes, Ly.spill_a_tm ? sb_tm : sb, mask4(act4<ACT>(x), L.livem[ct]), sys);
-                if (l > 0) spill_st4(spill_e, img_bytes, Ly.spill_e_tm ? sb_tm : sb, mask4(e, L.livem[ct]), sys);
+                amx = absmax4(amx, mask4(act4<ACT>(x), L.livem[ct]));
+                if (l > 0) { spill_st4(spill_e, img_bytes, Ly.spill_e_tm ? sb_tm : sb, mask4(e, L.livem[ct]), sys); emx = absmax4(emx, mask4(e, L.livem[ct])); }
                 else if (e0_in_regs) e0acc[ct] = e0acc[ct] + e;                          // (one tile per wave: i == 0 only)
                 else gst4s(spill_e, rowb[ct] + tb, gld4s(spill_e, rowb[ct] + tb) + e);   // Linear 0: only sum_t e_1 is needed
             }
@@ -185,6 +187,10 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
             const f32x4 dd = d * d;
             esum += L.livem[ct] ? 0.5f * ecoef * (dd.x + dd.y + dd.z + dd.w) : 0.f;          // (a select, not a product: whatever a padding chain holds)
         }
+    }
+    if (slot >= 0) {
+        spill_track(lds + P.lds_spillmax, spill_id_a(l), amx, L.c + 16 * L.q);
+        if (l > 0) spill_track(lds + P.lds_spillmax, spill_id_e(l), emx, L.c + 16 * L.q);
     }
     return esum;
 }
@@ -435,6 +441,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
     float* const spill = slot >= 0 ? H.spill_e + (size_t)slot * P.Bpad * H.npad : nullptr;
     float* const rec = (rec_idx >= 0 && H.rec_out != nullptr) ? H.rec_out + (size_t)rec_idx * P.B * H.n : nullptr;
     float lsum = 0.f;
+    float omx = 0.f;                       // largest |value| this call spills of E_o
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         if (i >= nt) continue;
@@ -494,13 +501,17 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
 #ifdef MCPC_EXP_SPILL_LINEAR
             if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q), mask4(e, L.livem[ct]), P.spill_sys != 0);
 #else
-            if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4,
-                                     H.spill_tm ? mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q) : rowb[ct] + tb,
-                                     mask4(e, L.livem[ct]), P.spill_sys != 0);
+            if (slot >= 0) {
+                spill_st4(spill, (uint32_t)P.Bpad * npad4,
+                          H.spill_tm ? mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q) : rowb[ct] + tb,
+                          mask4(e, L.livem[ct]), P.spill_sys != 0);
+                omx = absmax4(omx, mask4(e, L.livem[ct]));
+            }
 #endif
             if (rec != nullptr && L.livem[ct]) st_unpadded(rec, (int)L.chain[ct], H.n, 16 * tile + 4 * L.q, o);
         }
     }
+    if (slot >= 0) spill_track(lds + P.lds_spillmax, kSpillIdEo, omx, L.c + 16 * L.q);
     return lsum;
 }
 
