@@ -19,7 +19,7 @@ One bench "step" = ONE CALL of the hot path in BASELINE.json's configuration (cf
 
 Everything in the timed region goes through the C ABI (libmcpc.so); inputs are resident in HBM before the clock starts.
 `roofline` is computed from HIP events the library records on its launch stream (mcpc_set_profiling) during the timed
-calls; its `peak` is the ceiling of the pipe the kernel computes on (fp32 products as six bf16 MFMA products: dense bf16 peak / 6),
+calls; its `peak` is the ceiling of the pipe the kernel computes on (fp32 products as three fp16 MFMA products: dense fp16 peak / 3),
 the fp32 MFMA peak SURVEY 8(d) names is carried beside it; `traffic` comes from the tracked PMC summary of the same command
 (profiles/, separate --pmc passes: counters cannot be read inside this run) and is printed only when those passes ran THIS program --
 same kernel sources (mcpc_build_info's csrc hash), batch, T, kernel and launch count -- else null with the reason.  `cpu_baseline` (rank 0, N = 1 only) times oracle/torch_port.py -- a torch-autograd port with the reference's op
@@ -44,12 +44,12 @@ S_MACS = 30 * 256 + 256 * 256 + 256 * 784          # 273 920 MACs per chain per 
 PEAK_FP32_TFLOPS = 157.3                           # MI355X_MICROARCH.md: fp32 MFMA = vector peak
 PEAK_HBM_GBS = 8000.0
 PEAK_L2_GBS = 34500.0                              # MI355X_MICROARCH.md, L2 (per XCD): ~34.5 TB/s aggregate
-# packed Wf + Wb of the three GEMM Linears (padded), three bf16 planes per fp32 weight (csrc/mcpc_gemm6.h): 3.29 MB
-FRAG_BYTES_PER_WG_STEP = 2 * 6 * (32 * 256 + 256 * 256 + 256 * 784)
-# The step kernel computes its fp32 products as six bf16 MFMA products with fp32 accumulation: the ceiling of THAT pipe for
-# fp32-class work is the dense bf16 peak / 6 (MI355X_MICROARCH.md: 2516 TFLOP/s dense bf16).  `roofline.peak` stays the fp32 MFMA
-# peak -- the dense MFMA peak of the dtype the path computes in -- and the line carries this second ceiling beside it.
-PEAK_BF16X6_TFLOPS = 2516.0 / 6.0
+# packed Wf + Wb of the three GEMM Linears (padded), two fp16 planes per fp32 weight (csrc/mcpc_gemm_f16.h): 2.19 MB
+FRAG_BYTES_PER_WG_STEP = 2 * 4 * (32 * 256 + 256 * 256 + 256 * 784)
+# The step kernel computes every fp32 product as THREE fp16 MFMA products with fp32 accumulation (two fp16 pieces per operand, 22
+# significant bits, scaled by powers of two; four products in contractions with K <= 64): the ceiling of THAT pipe for fp32-class work is
+# the dense fp16 peak / 3 (MI355X_MICROARCH.md: 2516 TFLOP/s dense fp16 / bf16).  The fp32 MFMA peak SURVEY 8(d) names is carried beside it.
+PEAK_F16X3_TFLOPS = 2516.0 / 3.0
 # What binds a 16-chain workgroup of the step kernel with this core: the packed weights it streams out of L2 once per step through its
 # CU's vector-memory return path, 64 B per clock (MI355X_MICROARCH.md) -- at the shader clock the chip holds under THIS load, which the
 # library measures during the timed launches (mcpc_last_shader_clock_ghz: 1.8-2.0 GHz; the 2.4 GHz peak only as a fallback).
@@ -347,10 +347,10 @@ def main():
             l1_peak = L1_FILL_BYTES_PER_CLK * clk
             l1_ach = FRAG_BYTES_PER_WG_STEP * spl * n_wg / wg_per_launch / avg_s / 1e9
             pmc, pmc_why = pmc_traffic(mode, kernel, build["csrc"], B, T, round(n / K) if K else 0)
-            line = {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": PEAK_BF16X6_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / PEAK_BF16X6_TFLOPS,
-                    "peak_is": "the ceiling of the pipe this kernel computes on: every fp32 product is six v_mfma_f32_16x16x32_bf16 products "
-                               "(fp32 accumulate), so dense bf16 peak 2516 / 6; the kernel issues no fp32 MFMA (SQ_INSTS_VALU_MFMA_F32 = 0)",
+            line = {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": PEAK_F16X3_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / PEAK_F16X3_TFLOPS,
+                    "peak_is": "the ceiling of the pipe this kernel computes on: every fp32 product is three v_mfma_f32_16x16x32_f16 products "
+                               "(two fp16 pieces per operand, fp32 accumulate), so dense fp16 peak 2516 / 3; the kernel issues no fp32 MFMA",
                     "fp32_mfma": {"peak": PEAK_FP32_TFLOPS, "frac": tf / PEAK_FP32_TFLOPS,
                                   "note": "the fp32 MFMA peak SURVEY 8(d) prescribes for dtype f32; not a ceiling of this kernel"},
                     # HBM bytes per launch from the PMC counters (separate passes of the same command, tracked summary)
@@ -374,8 +374,8 @@ def main():
                                                   % ("%.3f GHz" % ghz if ghz and ghz > 0.5 else "not measured: 2.4 GHz peak"),
                                        "workgroups_per_launch": wg_per_launch,
                                        "note": "the fragment stream of a workgroup on its CU's vector-memory return path: one of the serial terms "
-                                               "of a 16-chain step (MFMAs 11.3 us, fragment returns ~7.5, operand split 3.3, table skeleton 4.8 of "
-                                               "~35; timing builds in profiles/r04_k1_bounds.txt, DESIGN section 4)"},
+                                               "of a 16-chain step (MFMAs 5.6 us, fragment requests 4.2, operand split 3.9, table skeleton 4.8 of "
+                                               "~30; timing builds in profiles/r05_k1_bounds.txt, DESIGN section 4)"},
                     "note": note}
             return line
 
@@ -413,10 +413,12 @@ def main():
                             "bench step = ONE CALL of T = %d Langevin steps (%d mixing + %d sampling), energies every step, "
                             "x every 100 steps; value = n_gpus * steps * T / wall; ms_per_step = ms per call" % (B, T, mixing, T - mixing),
                 "T": T, "batch": B, "mixing": mixing, "sampling": T - mixing, "steps_are": "calls",
-                # `dtype` f32: state, weights, energies and sums are fp32; every contraction multiplies fp32 operands as six bf16 MFMA
-                # products (hi/mid/lo pieces, all terms above 2^-24 of the leading one) with fp32 accumulation -- error against fp64 that
-                # of an fp32 MFMA chain, parity tolerances unchanged
-                "arithmetic": "fp32 operands, products as 6 bf16 MFMA terms (bf16x6), fp32 accumulate: fp32-class accuracy",
+                # `dtype` f32: state, weights, energies and sums are fp32; every contraction multiplies its fp32 operands as two fp16 pieces
+                # each (22 significant bits; rows scaled by powers of two into fp16's range) in three MFMA terms with fp32 accumulation --
+                # error of the dot products against fp64 that of an fp32 MFMA chain (profiles/r05_f16x4_study.txt, DESIGN section 4: what
+                # limits both is the fp32 accumulation), parity tolerances unchanged
+                "arithmetic": "fp32 operands as two fp16 pieces (22 bits, power-of-two row scaling), products as 3 fp16 MFMA terms, fp32 "
+                              "accumulate: the accuracy of an fp32 MFMA chain (profiles/r05_f16x4_study.txt)",
                 "timed_mode": ("learning call: Hebbian sums over the sampling steps + normalised grad read-out"
                                + (" + 1 RCCL all-reduce of %d floats" % n_params if world > 1 else "")) if primary_learning
                               else "inference-only call (no Hebbian sums)",
@@ -428,14 +430,14 @@ def main():
                     "steps_per_s": world * K * T / dt_inf, "us_per_langevin_step": dt_inf / (K * T) * 1e6, "calls": K,
                     "achieved_tflops": flops_inf * K * T / dt_inf / 1e12,
                     "frac_of_fp32_peak": flops_inf * K * T / dt_inf / 1e12 / PEAK_FP32_TFLOPS,
-                    "frac_of_bf16x6_pipe": flops_inf * K * T / dt_inf / 1e12 / PEAK_BF16X6_TFLOPS,
+                    "frac_of_f16x3_pipe": flops_inf * K * T / dt_inf / 1e12 / PEAK_F16X3_TFLOPS,
                     # the packed weights every workgroup streams out of L2 once per step (wall clock of the calls)
                     "l2_fragment_stream_gbs": q["n_workgroups"] * FRAG_BYTES_PER_WG_STEP * K * T / dt_inf / 1e9,
                     "l2_fragment_stream_frac_of_peak": q["n_workgroups"] * FRAG_BYTES_PER_WG_STEP * K * T / dt_inf / 1e9 / PEAK_L2_GBS},
                 "learning_call_flops": None if not primary_learning else {
                     "achieved_tflops": (flops_inf * T + flops_heb * (T - mixing)) * K / dt / 1e12,
                     "frac_of_fp32_peak": (flops_inf * T + flops_heb * (T - mixing)) * K / dt / 1e12 / PEAK_FP32_TFLOPS,
-                    "frac_of_bf16x6_pipe": (flops_inf * T + flops_heb * (T - mixing)) * K / dt / 1e12 / PEAK_BF16X6_TFLOPS,
+                    "frac_of_f16x3_pipe": (flops_inf * T + flops_heb * (T - mixing)) * K / dt / 1e12 / PEAK_F16X3_TFLOPS,
                     "note": "whole call, wall clock: 4S per chain-step + 2S on the accumulating steps"},
                 "lds_bytes_per_wg": q["lds_bytes"], "chains_per_wg": q["chains_per_wg"],
                 "workgroups": q["n_workgroups"], "spill_slots": q["spill_slots"],

@@ -90,7 +90,7 @@ typedef struct mcpc_net_desc {
                                           * fallback and the independent form parity checks replay the default against; 2: the in-place
                                           * wave-specialised kernel, the default), no_overlap=1, slot_cap=N, spill_gb=N, ring_parts=N,
                                           * flush_tail=N, flush_streams=1|2, cu_slack=N, dw_ksplit=N, ws_prio=0|1|2, stagger=N, no_lean=1,
-                                          * no_ybits=1, overlay16=1, heb_fp32=1 (the Hebbian GEMM on the fp32 MFMA instead of its bf16x6
+                                          * no_ybits=1, overlay16=1, heb_fp32=1 (the Hebbian GEMM on the fp32 MFMA instead of its fp16
                                           * form), rr=0 (shards of more 16-chain units than CUs as ONE launch in hardware rounds instead of
                                           * the round schedule), rr_qmax=N (most steps per launch of the round schedule), no_xl=1 (state and
                                           * per-step constants of a workgroup's chains in global memory instead of LDS).  Unknown keys are

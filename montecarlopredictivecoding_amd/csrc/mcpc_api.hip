@@ -56,7 +56,7 @@ struct Lin {
     float* G = nullptr;            // gradient sums [out_pad][g_ld]
     float* Gb = nullptr;           // [out_pad]
     int g_ld = 0;
-    bool spill_tm = false;         // its Hebbian operands are spilled tile-major (the bf16x6 kernel mcpc_heb7_kernel reads them)
+    bool spill_tm = false;         // its Hebbian operands are spilled tile-major (the fp16 kernel mcpc_heb7_kernel reads them)
     size_t slab_off = 0;           // float offset of this Linear's split-K slabs inside mcpc_engine::slab
     size_t slab_floats = 0;        // ... and their size
 };
@@ -86,7 +86,7 @@ struct Knobs {
     int rr = 1;               // 0: shards of more 16-chain units than CUs run as one launch in hardware rounds instead of the round schedule (setup_rounds)
     int rr_qmax = 100;        // round schedule: most steps per launch in stretches without Hebbian accumulation
     int heb171 = 0;           // 1: the 17-tile group of a read-out on <17, 1> with twice the activation groups instead of <17, 2> (A/B)
-    int heb_fp32 = 0;         // 1: the tiled Hebbian GEMM runs on the fp32 MFMA (mcpc_heb_kernel) instead of the bf16x6 form (A/B, parity tests)
+    int heb_fp32 = 0;         // 1: the tiled Hebbian GEMM runs on the fp32 MFMA (mcpc_heb_kernel) instead of the fp16x6 form (A/B, parity tests)
 };
 
 int parse_tuning(const char* str, Knobs& k) {
@@ -368,8 +368,8 @@ int plan_lds_ws2(mcpc_engine* e, bool allow_xl = true) {
         if (L >= 2 && fits_apart(hc, nb) && !e->knobs.overlay16) { e->ws2_overlay = false; e->lds_eo = off + e_sum; }
     }
     off += e->ws2_overlay ? std::max(ring_floats, e_sum) : ring_floats + e_sum;
-    // The bf16x6 core reads the LDS operand in whole 32-deep k-blocks; the lanes whose k values lie beyond a row whose width is not a
-    // multiple of 32 read THESE 16 floats instead of what lies behind the row (mcpc_gemm6.h): zero-filled at launch, never written.
+    // The GEMM core reads the LDS operand in whole 32-deep k-blocks; the lanes whose k values lie beyond a row whose width is not a
+    // multiple of 32 read THESE 16 floats instead of what lies behind the row (mcpc_gemm_f16.h): zero-filled at launch, never written.
     e->lds_zero = off;
     off += 16;
     e->lds_spillmax = off; off += kSpillTensors;     // the workgroup's largest |value| per spilled tensor (mcpc_kernels.h: spill_track)
@@ -799,7 +799,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     else if (e->slots >= kn.ring_parts) { e->half_slots = e->slots / kn.ring_parts; e->slots = e->half_slots * kn.ring_parts; }
     else { e->slots &= ~1; e->half_slots = e->slots / 2; }                   // fewer slots than parts: two halves
     // (the ring itself is allocated by the first run that accumulates Hebbian sums: ensure_spill)
-    // layout of the spilled operands per Linear: tile-major for the bf16x6 tiled kernel, row-major for the others (plan_hebbian's
+    // layout of the spilled operands per Linear: tile-major for the fp16 tiled kernel, row-major for the others (plan_hebbian's
     // choice of kernel depends on the shapes only)
     for (int j = 1; j < nlin; ++j) {
         const int et = e->lin[j].out_pad / 16, at = e->lin[j].in_pad / 16;

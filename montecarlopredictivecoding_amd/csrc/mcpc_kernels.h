@@ -32,7 +32,7 @@ struct KLayer {
     float* rec;            // trajectory records [rec_count][B][n] (unpadded) or null
     float* spill_e;        // l>=1: [slots][Bpad][npad] errors;  l==0: running sum of e_1 [Bpad][npad]
     float* spill_a;        // [slots][Bpad][npad] activations f(x_l)
-    int spill_e_tm, spill_a_tm;   // 1: that image is TILE-MAJOR (spill_offset): what the bf16x6 Hebbian kernel reads (mcpc_heb7_kernel); 0: row-major
+    int spill_e_tm, spill_a_tm;   // 1: that image is TILE-MAJOR (spill_offset): what the fp16 Hebbian kernel reads (mcpc_heb7_kernel); 0: row-major
     const float* ext_noise;// [n_steps][B][n] or null
     const f32x4* Wf;       // l>=1: packed forward weights of Linear l  [ntiles][nkb_in][64]
     const f32x4* Wb;       // l>=1: packed backward weights of Linear l [ntiles(l-1)][ntiles][64]
@@ -144,9 +144,9 @@ struct KParams {
     int xl;                          // in-place kernel, 16-chain plans whose LDS has the room: the state x_l, the biases, mu_1 and the bit-packed
                                      // target of the workgroup's chains live in LDS for the whole launch (mcpc_ws2_lean.h: XL)
     int spill_sys;                   // Hebbian spill stores at system scope (write-through): shards whose spill per step is far beyond the L2s
-    int lds_floats;                  // floats of dynamic LDS of this plan (cleared once per launch: see mcpc_gemm6.h, k ranges)
+    int lds_floats;                  // floats of dynamic LDS of this plan (cleared once per launch: see mcpc_gemm_f16.h, k ranges)
     int lds_zero;                    // float offset of 16 floats of the plan that nothing writes after that: what the GEMM core's lanes beyond a
-                                     // ragged k range read (mcpc_gemm6.h)
+                                     // ragged k range read (mcpc_gemm_f16.h)
     unsigned long long* clk;         // profiling only (else null): [0] += shader cycles (s_memtime), [1] += 100 MHz wall ticks (s_memrealtime)
                                      // of one wave of workgroup 0 over the launch -- their ratio is the shader clock under THIS load
 #ifdef MCPC_STAMPS

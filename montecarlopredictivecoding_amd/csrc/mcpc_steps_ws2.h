@@ -42,7 +42,7 @@ constexpr int kWs2Pairs = MCPC_WS2_PAIRS;          // (G, E) pairs per workgroup
 constexpr int kWs2NT = MCPC_WS2_SPAN / kWs2Pairs;   // unit tiles per pair per table entry: an entry hands out 16 tiles
 // Tiles per pair and entry (build-time knob).  Measured: 6 (a third group of two tiles in the register rotation) and 5 against 4 --
 // 50.7 / 50.0 / 51.4 us per step at 4096 chains in round 2, 34.9 against 34.4 with the bf16x6 core in round 3: the hand-over count is
-// not what a step pays for, and the default stays 4 (one table layout; mcpc_gemm6.h's rotation is written for at most four).
+// not what a step pays for, and the default stays 4 (one table layout; mcpc_gemm_f16.h's rotation is written for at most four).
 #ifndef MCPC_WS2_NT16
 #define MCPC_WS2_NT16 kWs2NT
 #endif

@@ -93,7 +93,7 @@ def test_headline_call_matches_serial_plain_schedule_bitwise(problem, default_ru
 
 
 def test_headline_call_bucket_of_both_hebbian_kernels_agrees(problem, default_run):
-    """The tiled Hebbian GEMM runs the bf16x6 form by default (mcpc_hebbian.h: mcpc_heb6_kernel) and the fp32-MFMA form under
+    """The tiled Hebbian GEMM runs the fp16 form by default (mcpc_hebbian.h: mcpc_heb7_kernel; rounds 3-4: bf16x6) and the fp32-MFMA form under
     `heb_fp32=1`: same trajectories bitwise (the flush never writes state), buckets equal to fp32 summation-order noise --
     both carry about 2e-7 of sum|terms| against fp64 (scripts/heb_bf16_ubench.hip), the window test below holds either to it."""
     W, b, y, xs = problem
@@ -116,7 +116,7 @@ def test_headline_call_bucket_of_both_hebbian_kernels_agrees(problem, default_ru
             off += n
 
 
-@pytest.mark.parametrize("tuning", [None, "heb_fp32=1"], ids=["bf16x6", "fp32"])
+@pytest.mark.parametrize("tuning", [None, "heb_fp32=1"], ids=["f16x3", "fp32"])
 def test_headline_call_hebbian_window_matches_fp64_recomputation(problem, default_run, tuning):
     W, b, y, xs = problem
     _, out_d, _, _ = default_run
