@@ -76,7 +76,7 @@ struct Knobs {
                               // halves the step kernel waited at every boundary for a flush that takes as long as its own segment
                               // (96.8 -> 95.2 us per step of the learning call; parts of 64 steps beat 48, 96 and 128)
     int dw_ksplit = 0;        // > 0: K-splits per workgroup tile of the Hebbian GEMM (0: one wave of workgroups over the chip)
-    int ws_prio = 0;          // 1: epilogue waves at raised priority, 2: GEMM waves, 0: neither (the bf16x6 GEMM waves need most of the issue port
+    int ws_prio = 0;          // 1: epilogue waves at raised priority, 2: GEMM waves, 0: neither (the GEMM waves need most of the issue port
                               // themselves: with the epilogue waves at raised priority a step of cfg-M took 94.2 us against 87.7, round 3)
     int stagger = 0;          // barrier kernel: start cycles of the second workgroup of a CU
     int no_lean = 0;          // 1: the in-place kernel's E waves use the generic epilogues everywhere (A/B, parity tests)
@@ -191,6 +191,7 @@ struct mcpc_engine {
     unsigned* spillmax = nullptr;   // [kMaxRingParts][kSpillTensors]: per ring part, the largest |value| per spilled tensor of the segment
                                     // that filled it (bit patterns; written by the step kernels, read by the Hebbian GEMMs of that part)
     int lds_spillmax = 0;
+    int lds_rowexp = 0;             // in-place plan: kRowExpFloats words of row exponents (mcpc_kernels.h: rowexp_track)
     unsigned long long* clk = nullptr;   // profiling: {shader cycles, 100 MHz ticks} of one wave per launch (KParams::clk)
     float* dummy = nullptr;         // 4 KiB of zeros (KParams::dummy)
     // Round schedule (setup_rounds): a shard of more 16-chain units than CUs as `rr_k` launches per cycle, each unit in `rr_m` of them
@@ -351,10 +352,11 @@ int plan_lds_ws2(mcpc_engine* e, bool allow_xl = true) {
         const int ht = std::max(e->out_pad / 16, 1);
         const int span = kWs2Pairs * ws2_nt<1>();     // tiles a table entry hands out
         auto ring_of = [&](int hc, int nb) { return nb * CT * (hc * 16 + kLdPad); };
-        // (+16: the slack added behind the operand regions below -- a plan within 64 B of the limit takes a smaller chunk or ring here
+        // (+ tail: what is added behind the operand regions below -- a plan that close to the limit takes a smaller chunk or ring here
         // instead of failing the final size check)
-        auto fits = [&](int hc, int nb) { return (off + 16 + std::max(ring_of(hc, nb), e_sum)) * (int)sizeof(float) <= 160 * 1024; };
-        auto fits_apart = [&](int hc, int nb) { return (off + 16 + ring_of(hc, nb) + e_sum) * (int)sizeof(float) <= 160 * 1024; };
+        constexpr int tail = 16 + kSpillTensors + kRowExpFloats;      // (zero region, spill maxima, row exponents: added below)
+        auto fits = [&](int hc, int nb) { return (off + tail + std::max(ring_of(hc, nb), e_sum)) * (int)sizeof(float) <= 160 * 1024; };
+        auto fits_apart = [&](int hc, int nb) { return (off + tail + ring_of(hc, nb) + e_sum) * (int)sizeof(float) <= 160 * 1024; };
         // (chunks are whole k-blocks of the back-projection GEMM: tq tiles)
         const int tq = kKB / 16, hb = (ht + tq - 1) / tq;
         int hcb_fit = 0;
@@ -373,6 +375,7 @@ int plan_lds_ws2(mcpc_engine* e, bool allow_xl = true) {
     e->lds_zero = off;
     off += 16;
     e->lds_spillmax = off; off += kSpillTensors;     // the workgroup's largest |value| per spilled tensor (mcpc_kernels.h: spill_track)
+    e->lds_rowexp = off; off += kRowExpFloats;       // per B operand and chain row: generation and exponent of the row's maximum (rowexp_track)
     // with room to spare (16-chain plans: 45 KB at cfg-M) the lean epilogues keep what they read every step in LDS: the state rows
     // X_l (layout of FX_l), the bias rows, the mu_1 rows (layout of FX_0), the read-out bias and the bit-packed target rows
     e->xl = false;
@@ -420,7 +423,7 @@ int build_phases_ws2(mcpc_engine* e) {
     const int L = e->L;
     const int span = kWs2Pairs * ws2_nt<1>();     // tiles per table entry
     auto tiles = [&](int l) { return e->npad[l] / 16; };
-    auto blank = [&]() { KPhase k{}; k.dep_e = -1; k.dep_g = -1; k.dep_se = -1; return k; };
+    auto blank = [&]() { KPhase k{}; k.dep_e = -1; k.dep_g = -1; k.dep_se = -1; k.b_row = -1; k.o_row = -1; return k; };
     enum { REF_LAST_BWD = -1000, REF_LAST_FWD = -2000, REF_LAST_HB = -3000, REF_LAST_BWD_GEMM = -4000, REF_LAST_BWD_ANY = -5000 };   // symbolic deps
     auto fwd_entries = [&](int l, std::vector<KPhase>& out) {
         for (int base = 0; base < tiles(l); base += span) {
@@ -432,6 +435,7 @@ int build_phases_ws2(mcpc_engine* e) {
                 k.A = e->lin[l].Wf; k.a_lin = l; k.kw = 16 * tiles(l - 1); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
                 k.b_lds = e->lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
                 k.out_lds = e->lds_e[l]; k.out_ld = e->npad[l] + kLdPad;
+                k.b_row = rowexp_fx(l - 1); k.o_row = rowexp_e(l);
                 k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_BWD - (l - 1);
                 if (e->has_head && e->ws2_overlay) k.dep_g = REF_LAST_HB;       // E_l shares LDS with the ring
                 else if (e->has_head) {
@@ -475,6 +479,7 @@ int build_phases_ws2(mcpc_engine* e) {
             f.A = e->lin[L].Wf; f.a_lin = L; f.kw = 16 * tiles(L - 1); f.nkb = kblocks(f.kw); f.a_tile_stride = f.nkb * kFragBlock;
             f.b_lds = e->lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad;
             f.out_lds = e->lds_eo + (c % R) * chunk_floats; f.out_ld = hc * 16 + kLdPad;
+            f.b_row = rowexp_fx(L - 1); f.o_row = rowexp_ring(c % R);
             f.flags = PHF_WS_GEMM | PHF_WS_EPI; f.dep_e = REF_LAST_BWD - (L - 1);
             if (c >= R) f.dep_g = idx_b[c - R];
             else if (e->ws2_overlay && (c % R) * chunk_floats < e_sum) { f.dep_g = REF_LAST_BWD_GEMM; f.dep_se = REF_LAST_BWD_ANY; }   // slot overlaps the E_l
@@ -486,6 +491,7 @@ int build_phases_ws2(mcpc_engine* e) {
             b.A = e->lin[L].Wb; b.a_lin = L; b.a_tile_stride = kblocks(e->out_pad) * kFragBlock; b.a_off0 = (c_start[c] / tq) * kFragBlock;
             b.kw = 16 * (c_start[c + 1] - c_start[c]); b.nkb = (c_start[c + 1] - c_start[c] + tq - 1) / tq;
             b.b_lds = e->lds_eo + (c % R) * chunk_floats; b.ldb = hc * 16 + kLdPad;
+            b.b_row = rowexp_ring(c % R);
             b.flags = PHF_WS_GEMM; b.dep_e = idx_f[c];
             idx_b[c] = (int)ph.size(); ph.push_back(b);
             if (nf < fill.size()) ph.push_back(fill[nf++]);      // one forward entry behind every back-projection
@@ -507,6 +513,7 @@ int build_phases_ws2(mcpc_engine* e) {
         k.flags = PHF_WS_EPI | (e->has_head ? PHF_WS2_HANDOFF : 0);
         k.sign = e->has_head ? 1.0f : 0.0f;
         k.out_lds = e->lds_a[L - 1]; k.out_ld = e->npad[L - 1] + kLdPad;
+        k.o_row = rowexp_fx(L - 1);
         ph.push_back(k);
     }
     for (int l = 1; l <= L - 1; ++l)
@@ -516,6 +523,7 @@ int build_phases_ws2(mcpc_engine* e) {
             k.A = e->lin[l].Wb; k.a_lin = l; k.kw = 16 * tiles(l); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
             k.b_lds = e->lds_e[l]; k.ldb = e->npad[l] + kLdPad; k.sign = -1.0f;
             k.out_lds = e->lds_a[l - 1]; k.out_ld = e->npad[l - 1] + kLdPad;
+            k.b_row = rowexp_e(l); k.o_row = rowexp_fx(l - 1);
             k.flags = PHF_WS_GEMM | PHF_WS_EPI; k.dep_e = REF_LAST_FWD - l;
             ph.push_back(k);
         }
@@ -1329,7 +1337,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         H.lds_bias = e->lds_hbias; H.lds_yw = e->lds_yw;
     }
     P.mu1 = e->mu1; P.epart = e->epart; P.epart_slots = (int)eslots;
-    P.phases = e->phases; P.n_phases = e->n_phases; P.wexp = e->wexp; P.spillmax = nullptr; P.lds_spillmax = e->lds_spillmax;
+    P.phases = e->phases; P.n_phases = e->n_phases; P.wexp = e->wexp; P.spillmax = nullptr; P.lds_spillmax = e->lds_spillmax; P.lds_rowexp = e->lds_rowexp;
     P.stagger_cycles = e->knobs.stagger;
     P.L = e->L; P.has_head = e->has_head; P.B = e->d.batch; P.Bpad = e->Bpad; P.T = r->T;
     P.xopt = r->xopt_kind; P.update_x = r->update_x ? 1 : 0;

@@ -11,7 +11,7 @@
 #if defined(MCPC_EXP_NOLOAD) || defined(MCPC_EXP_NOSPLIT) || defined(MCPC_EXP_NOTAILMASK) || defined(MCPC_EXP_HALFMFMA) || \
     defined(MCPC_EXP_FULLFENCE) || defined(MCPC_EXP_NOGEMM) || defined(MCPC_EXP_NOSPILL) || defined(MCPC_EXP_NOX) || \
     defined(MCPC_EXP_NOELOAD) || defined(MCPC_EXP_SPILL_LINEAR) || defined(MCPC_EXP_NOY) || defined(MCPC_EXP_NOLEAN) || \
-    defined(MCPC_EXP_NOEPI) || defined(MCPC_HEB_EXP)
+    defined(MCPC_EXP_NOEPI) || defined(MCPC_EXP_NOROWEXP) || defined(MCPC_HEB_EXP)
 #define MCPC_TIMING_BUILD 1
 #else
 #define MCPC_TIMING_BUILD 0

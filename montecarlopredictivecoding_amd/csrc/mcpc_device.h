@@ -8,6 +8,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // same vector in the global address space: loads through it are global_load_* (counted on vmcnt only);
 // a generic pointer read from a descriptor in memory would compile to flat_load_* and force full drains
 typedef __attribute__((address_space(1))) f32x4 gf32x4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));       // 8 fp16 of an MFMA operand (mcpc_gemm_f16.h)
+typedef __attribute__((address_space(1))) u32x4 gu32x4;
 
 namespace mcpc {
 

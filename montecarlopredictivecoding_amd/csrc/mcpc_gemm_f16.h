@@ -7,9 +7,11 @@
 // CU's vector-memory path) and a split of 24 instead of 47 VALU instructions per 8 values:
 //      a b  ~  [a_m b_m] + (a_m b_h + a_h b_m) + a_h b_h,        a = (a_h + a_m) 2^-sa,  b = (b_h + b_m) 2^-sb.
 // fp16 has 5 exponent bits, so both operands are SCALED BY POWERS OF TWO (exact) before the split: the weights of a Linear by one
-// exponent chosen when they are packed (max |W| -> [2^14, 2^15)), the B operand PER CHAIN ROW by an exponent the GEMM wave takes from
-// the row's own maximum in a pre-pass over the row (rows of one chain never share a scale with another chain's: chains stay
-// independent, and a diverged chain cannot cost its neighbours precision).  The fp32 accumulators are un-scaled by 2^-(sa + sb) (exact)
+// exponent chosen when they are packed (max |W| -> [2^14, 2^15)), the B operand PER CHAIN ROW by an exponent taken from the row's own
+// maximum (rows of one chain never share a scale with another chain's: chains stay independent, and a diverged chain cannot cost its
+// neighbours precision) -- by a pre-pass of the GEMM wave over the row (gemm_row_exp), or, in the in-place kernel's lean path, from a word
+// the epilogue waves that WROTE the row keep (mcpc_kernels.h: rowexp_track; the caller passes it as GemmScale::fixed_b): the same
+// exponent either way, so the kernel forms agree bitwise, without 2.8 us of row scans on the step's critical path.  The fp32 accumulators are un-scaled by 2^-(sa + sb) (exact)
 // when the GEMM ends.  Against an fp64 dot product, relative to sum |terms|, this is in the class of the fp32 MFMA chain and of bf16x6 on
 // every operand distribution tried (K = 32 / 256 / 784; activations, errors, rows of mixed scale, heavy tails: max 0.6-1.8e-7, rms
 // 0.9-3.6e-8 -- scripts/f16x4_study.py): what limits all three is the fp32 accumulation, not the 22 or 24 operand bits,
@@ -76,15 +78,18 @@ __device__ __forceinline__ f32x4 mfma4(u32x4 a, u32x4 b, f32x4 c) {
 constexpr int kScaleTop = 141;          // a maximum with biased fp32 exponent e is scaled by 2^(141 - e): into [2^14, 2^15) (fp16: < 65 504)
 constexpr int kScaleClamp = 60;         // |exponent| of any scale: 2^-(sa + sb) stays a normal fp32
 // exponent that brings |v| <= mx into fp16's range with its two pieces normal for everything within 2^16 of mx
+__device__ __host__ __forceinline__ int scale_exp_for_field(int biased_exponent) {
+    int e = kScaleTop - biased_exponent;
+    e = e > kScaleClamp ? kScaleClamp : (e < -kScaleClamp ? -kScaleClamp : e);
+    return e;
+}
 __device__ __host__ __forceinline__ int scale_exp_for_max(float mx) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned bits = __float_as_uint(mx);
 #else
     unsigned bits; __builtin_memcpy(&bits, &mx, 4);
 #endif
-    int e = kScaleTop - (int)((bits >> 23) & 0xffu);
-    e = e > kScaleClamp ? kScaleClamp : (e < -kScaleClamp ? -kScaleClamp : e);
-    return e;
+    return scale_exp_for_field((int)((bits >> 23) & 0xffu));
 }
 __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }      // |e| <= 126
 
@@ -278,7 +283,11 @@ __device__ __forceinline__ void gemm_dispatch(f32x4 (&acc)[NTT][CTT], const gu32
 template <int NTT, int CTT, int NW>
 __device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const void* A, const int (&aoff)[NTT], int nt, int nkb, int kw,
                                            const float* B, int ldb, int lane, frag_t (&pre0)[NTT], const float* zeros, GemmScale& gs) {
+#ifdef MCPC_EXP_NOROWEXP    // timing experiment only (wrong results): no pre-pass over the row, a constant exponent
+    int b_exp = gs.fixed_b != kScaleAuto ? gs.fixed_b : 8;
+#else
     int b_exp = gs.fixed_b != kScaleAuto ? gs.fixed_b : gemm_row_exp(B, ldb, nkb, kw, lane, zeros);
+#endif
     if (gs.mode == GS_ACCUM) {
         if (gs.run != kRunNone && b_exp != gs.run) {
             if (b_exp < gs.run) {                       // this chunk's row is larger than any before: bring the sum down to its units

@@ -9,7 +9,6 @@
 //                         replaces the parameter part of overall.backward(), pc_trainer.py:862.
 #pragma once
 #include "mcpc_device.h"
-#include "mcpc_bf16x6.h"          // (the split of the Hebbian kernels; the GEMM core of the step kernels is mcpc_gemm_f16.h)
 #include "../../include/mcpc.h"
 
 namespace mcpc {
@@ -91,6 +90,8 @@ struct KPhase {
     int rot;               // in-place variant: pair k owns tiles tile0 + ((k + rot) & 3) + 4 i (balances uneven chunks)
     int dep_se;            // in-place variant: entry all E waves must have passed before this entry's block is STORED (its
                            // LDS rows are still read by their epilogues); dep_g is waited for at the same point
+    int b_row, o_row;      // in-place variant: id of the B operand's / of the produced operand's row-exponent words (KParams::lds_rowexp;
+                           // -1: none -- the GEMM wave scans the row itself)
 };
 
 // Phase descriptors are fetched through the constant address space: wave-uniform s_load_* on the scalar cache.
@@ -145,6 +146,8 @@ struct KParams {
                                      // target of the workgroup's chains live in LDS for the whole launch (mcpc_ws2_lean.h: XL)
     int spill_sys;                   // Hebbian spill stores at system scope (write-through): shards whose spill per step is far beyond the L2s
     int lds_floats;                  // floats of dynamic LDS of this plan (cleared once per launch: see mcpc_gemm_f16.h, k ranges)
+    int lds_rowexp;                  // float offset of kRowExpIds x 16 words: per B operand and chain row, (generation << 8) | biased exponent of
+                                     // the row's largest |value|, kept by the epilogue waves that WRITE the rows (rowexp_track below)
     int lds_zero;                    // float offset of 16 floats of the plan that nothing writes after that: what the GEMM core's lanes beyond a
                                      // ragged k range read (mcpc_gemm_f16.h)
     unsigned long long* clk;         // profiling only (else null): [0] += shader cycles (s_memtime), [1] += 100 MHz wall ticks (s_memrealtime)
@@ -257,6 +260,29 @@ __device__ __forceinline__ int load_wexp(const int* wexp, int lin) {
 // B exponent of the read-out error rows: a Bernoulli read-out's sigma(o) - y is bounded by 1 for targets in [0, 1] (2 for anything BCE
 // still makes sense of) -> a FIXED exponent, independent of how the read-out is cut into chunks; anything else: from the rows themselves
 __device__ __forceinline__ int headb_fixed_exp(int loss_kind) { return loss_kind == MCPC_LOSS_BERNOULLI ? 13 : kScaleAuto; }
+
+// ---- row exponents kept by the producers (in-place kernel, lean epilogues) ------------------------------------------------------------
+// The GEMM core scales every chain row of its LDS operand by a power of two taken from the row's largest |value| (mcpc_gemm_f16.h).
+// Scanning the row for it in front of the GEMM (gemm_row_exp) sits on the step's critical path -- the row is complete only when the
+// GEMM may start -- and cost 2.8 of 30 us per step at cfg-M (profiles/r05_k1_bounds.txt).  The epilogue waves that WRITE the rows know
+// the values: each lane keeps the maximum of what it stores of its chain's row in an entry and adds it with ONE ds_max_u32 to the
+// row's word of the operand, as (generation << 8) | biased exponent: a newer generation of the operand (the step it is written in;
+// the entry for a ring slot, which is reused inside a step) supersedes the older one without a reset, the same generation's writers
+// -- the four epilogue waves, several entries of a wide layer -- combine to the row's maximum.  The word is complete when the
+// consumer's dependency on the producing entries is (the atomic precedes the wave's progress-counter store in LDS order), and it is
+// protected against the next generation's writers exactly as the rows are.  The exponent is the one gemm_row_exp computes (the field of
+// the maximum is the maximum of the fields; v_max skips NaN in both), so kernel forms with and without it agree bitwise.
+constexpr int kRowExpIds = 16;                         // FX_0..5, E_0..5, ring slots 0..3
+constexpr int kRowExpFloats = kRowExpIds * 16;
+__device__ __host__ __forceinline__ int rowexp_fx(int l) { return l; }
+__device__ __host__ __forceinline__ int rowexp_e(int l) { return kMaxLatent + l; }
+__device__ __host__ __forceinline__ int rowexp_ring(int r) { return 2 * kMaxLatent + r; }
+__device__ __forceinline__ void rowexp_track(float* lds_rowexp, int id, int row, float lane_max, unsigned gen) {
+    atomicMax(reinterpret_cast<unsigned*>(lds_rowexp) + 16 * id + row, (gen << 8) | (__float_as_uint(lane_max) >> 23));
+}
+__device__ __forceinline__ int rowexp_read(const float* lds_rowexp, int id, int row) {
+    return scale_exp_for_field((int)(reinterpret_cast<const unsigned*>(lds_rowexp)[16 * id + row] & 0xffu));
+}
 
 // guarded scalar store of a C-layout quad into an unpadded [B][n] tensor row
 __device__ __forceinline__ void st_unpadded(float* base, int chain, int n, int u0, f32x4 v) {

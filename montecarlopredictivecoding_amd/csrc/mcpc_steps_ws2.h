@@ -135,7 +135,8 @@ __device__ __forceinline__ void ws2_prefetch(const KPhase& ph, int k, int lane, 
 }
 
 template <int ACT>
-__device__ __forceinline__ void ws2_fill_fx(const KLayer& Ly, float* lds, int chain0, int tid, int ct_rows, bool keep_x) {
+__device__ __forceinline__ void ws2_fill_fx(const KLayer& Ly, float* lds, int chain0, int tid, int ct_rows, bool keep_x,
+                                            float* lds_rowexp = nullptr, int row_id = 0) {
     const int qpr = Ly.npad / 4;                            // quads per row
     for (int idx = tid; idx < ct_rows * qpr; idx += kWs2Threads) {
         const int r = idx / qpr, u0 = 4 * (idx - r * qpr);
@@ -144,6 +145,8 @@ __device__ __forceinline__ void ws2_fill_fx(const KLayer& Ly, float* lds, int ch
         fx.x = actf<ACT>(x.x); fx.y = actf<ACT>(x.y); fx.z = actf<ACT>(x.z); fx.w = actf<ACT>(x.w);
         st4(lds + Ly.lds_a + r * Ly.ld + u0, fx);
         if (keep_x) st4(lds + Ly.lds_x + r * Ly.ld + u0, x);
+        // generation 0 of the row's exponent word (mcpc_kernels.h: rowexp_track; the words were zeroed with the plan)
+        if (lds_rowexp != nullptr && r < 16) rowexp_track(lds_rowexp, row_id, r, absmax4(0.f, fx), 0u);
     }
 }
 

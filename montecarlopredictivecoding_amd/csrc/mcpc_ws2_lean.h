@@ -95,7 +95,7 @@ template <int ACT> __device__ __forceinline__ f32x4 act4(f32x4 x) {
 template <int CTT, int NW, int NTW, int ACT, bool XL = false>
 __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
                                           int slot, int rec_idx, const int* prog_g, int need, int* err, int& dead,
-                                          f32x4 (&e0acc)[CTT], bool e0_in_regs) {
+                                          f32x4 (&e0acc)[CTT], bool e0_in_regs, float* rx = nullptr, unsigned row_gen = 0u) {
     if (nt <= 0) return 0.f;                  // (a layer with fewer tiles than waves: nothing to load, nothing to wait for)
     const KLayer& Ly = P.layer[ph.layer];
     const int l = ph.layer;
@@ -158,6 +158,7 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
     const bool sys = P.spill_sys != 0;
     float esum = 0.f;
     float amx = 0.f, emx = 0.f;            // largest |value| this call spills of A_l / E_l (mcpc_kernels.h: spill_track)
+    float rmx = 0.f;                       // largest |value| this lane writes of its chain's E_l row (rowexp_track)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         if (i >= nt) continue;
@@ -168,7 +169,7 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
             const f32x4 x = xv[i][ct];
             const f32x4 d = x - (av[i][ct] + bv[i][ct]);                  // x - mu
             const f32x4 e = d * ecoef;
-            if (l > 0) *reinterpret_cast<f32x4*>(e_lds + lrowb[ct] + tb) = e;
+            if (l > 0) { *reinterpret_cast<f32x4*>(e_lds + lrowb[ct] + tb) = e; rmx = absmax4(rmx, e); }
             if (slot >= 0) {
 #ifdef MCPC_EXP_SPILL_LINEAR      // timing experiment only (rows permuted inside the workgroup's block): one contiguous KiB per store
                 const uint32_t sb = mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q);
@@ -192,6 +193,7 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
         spill_track(lds + P.lds_spillmax, spill_id_a(l), amx, L.c + 16 * L.q);
         if (l > 0) spill_track(lds + P.lds_spillmax, spill_id_e(l), emx, L.c + 16 * L.q);
     }
+    if (CTT == 1 && rx != nullptr && ph.o_row >= 0) rowexp_track(rx, ph.o_row, L.c, rmx, row_gen);
     return esum;
 }
 
@@ -242,7 +244,8 @@ __device__ __forceinline__ void lean_store_x(const KParams& P, const float* lds,
 // table).
 template <int CTT, int NW, int NTW, int ACT, bool NOISE, bool ADAM = false, bool XL = false>
 __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
-                                         int t, const int* prog_g, int need, int* err, int& dead, int s_tab = 0) {
+                                         int t, const int* prog_g, int need, int* err, int& dead, int s_tab = 0, float* rx = nullptr,
+                                         unsigned row_gen = 0u) {
     static_assert(!(NOISE && ADAM), "Adam with the fused kick takes the generic epilogue");
     if (nt <= 0) return;
     const KLayer& Ly = P.layer[ph.layer];
@@ -310,6 +313,7 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
     const float sign = ph.sign, lr = P.lr, nscale = P.noise_scale;
     const uint64_t seed = P.seed, step = P.step_base + (uint64_t)t, chain_base = P.chain_base;
     char* const fx_lds = reinterpret_cast<char*>(lds + Ly.lds_a);
+    float rmx = 0.f;                       // largest |value| this lane writes of its chain's FX_l row (rowexp_track)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         if (i >= nt) continue;
@@ -364,9 +368,12 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
             gst4s(Ly.x, rowb[ct] + tb, xn);
 #endif
             }
-            *reinterpret_cast<f32x4*>(fx_lds + lrowb[ct] + tb) = act4<ACT>(xn);      // the next step's GEMMs read f(x_new) from FX_l
+            const f32x4 fxn = act4<ACT>(xn);
+            *reinterpret_cast<f32x4*>(fx_lds + lrowb[ct] + tb) = fxn;                // the next step's GEMMs read f(x_new) from FX_l
+            rmx = absmax4(rmx, fxn);
         }
     }
+    if (CTT == 1 && rx != nullptr && ph.o_row >= 0) rowexp_track(rx, ph.o_row, L.c, rmx, row_gen);
 }
 
 // ---- HEADF entry (read-out chunk): out = acc + bias, e_o = dL/dout -> ring slot (LDS), loss, spills, output records -----
@@ -375,7 +382,7 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
 template <int CTT, int NW, int NTW, bool XL = false, bool YB = false>
 __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
                                             int slot, int rec_idx, bool do_energy, const int* prog_g, int need, int* err, int& dead,
-                                            bool ybin) {
+                                            bool ybin, float* rx = nullptr) {
     if (nt <= 0) return 0.f;
     const KHead& H = P.head;
     const int kind = H.loss_kind, n = H.n, mask_start = H.mask_start;
@@ -442,6 +449,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
     float* const rec = (rec_idx >= 0 && H.rec_out != nullptr) ? H.rec_out + (size_t)rec_idx * P.B * H.n : nullptr;
     float lsum = 0.f;
     float omx = 0.f;                       // largest |value| this call spills of E_o
+    float rmx = 0.f;                       // largest |value| this lane writes of its chain's row of the chunk (rowexp_track)
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         if (i >= nt) continue;
@@ -498,6 +506,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                 e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
             }
             *reinterpret_cast<f32x4*>(eo + orowb[ct] + cb) = e;
+            rmx = absmax4(rmx, e);
 #ifdef MCPC_EXP_SPILL_LINEAR
             if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q), mask4(e, L.livem[ct]), P.spill_sys != 0);
 #else
@@ -512,6 +521,8 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
         }
     }
     if (slot >= 0) spill_track(lds + P.lds_spillmax, kSpillIdEo, omx, L.c + 16 * L.q);
+    // (a ring slot is reused inside a step: its generation is the entry, `need` = entries completed so far)
+    if (CTT == 1 && rx != nullptr && ph.o_row >= 0) rowexp_track(rx, ph.o_row, L.c, rmx, (unsigned)need);
     return lsum;
 }
 

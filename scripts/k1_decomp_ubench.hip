@@ -13,7 +13,7 @@
 //   (three ds_read_b128 per chain tile, no split in the GEMM wave).
 // Calibration: CT = 1, NE = 1 must land near the product's measured 33-36 us per workgroup-step (and its NOEPI / NOGEMM builds near
 // 34.8 / 19.6: profiles/r04_k1_bounds.txt) for the CT = 2 lines to mean anything -- EW is chosen for that.
-//   hipcc --offload-arch=gfx950 -O3 -Imontecarlopredictivecoding_amd/csrc scripts/k1_decomp_ubench.hip -o scripts/bin/k1_decomp_ubench
+//   hipcc --offload-arch=gfx950 -O3 -Imontecarlopredictivecoding_amd/csrc -Iscripts scripts/k1_decomp_ubench.hip -o scripts/bin/k1_decomp_ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

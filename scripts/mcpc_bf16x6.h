@@ -6,7 +6,8 @@
 // accumulated in fp32 small terms first, give a dot product whose error against fp64 is that of the fp32 MFMA chain (measured on
 // the Hebbian GEMM's shapes, K = 4096, relative to sum|terms|: max 2.7e-7 / rms 3.1e-8 against 2.1e-7 / 2.7e-8,
 // scripts/heb_bf16_ubench.hip) at 6 x 16 cycles per 32-deep block of a 16 x 16 tile instead of 8 x 32.
-// Used by the Hebbian GEMM (mcpc_hebbian.h: mcpc_heb7_kernel) and by the step kernels' GEMM core (mcpc_gemm6.h).
+// Rounds 3-4: the arithmetic of the Hebbian GEMM and of the step kernels' GEMM core.  Round 5 moved both to two scaled fp16 pieces
+// (csrc/mcpc_gemm_f16.h); this header left the product and stays here for scripts/k1_decomp_ubench.hip, which models the bf16x6 kernel.
 #pragma once
 
 namespace mcpc {

@@ -263,11 +263,13 @@ def test_two_engines_on_two_streams_run_concurrently():
 
 
 def test_gemm_core_accuracy_against_fp64():
-    """The step kernel multiplies fp32 operands as six bf16 MFMA products with fp32 accumulation (csrc/mcpc_gemm6.h).  ONE step with
+    """The step kernel multiplies fp32 operands as products of scaled fp16 pieces with fp32 accumulation (csrc/mcpc_gemm_f16.h: three
+    MFMAs per product, four in contractions of at most 64 terms; rounds 3-4: six bf16 MFMAs).  ONE step with
     lr = 1 and no noise exposes every contraction of a step -- three forward GEMMs, the read-out and four back-projections, K = 32 ..
     784 -- in x_new = x - g.  Against an fp64 evaluation of the same step (reference pc_layer.py:266-300 for the errors,
     pc_trainer.py:862 for dF/dx) every element must sit within 1e-6 of the sum of the ABSOLUTE values of the terms that make it up:
-    what a chain of two fp32 dot products may lose (the core alone: max 2.7e-7 of sum|terms| at K = 4096, the fp32 MFMA 2.1e-7)."""
+    what a chain of two fp32 dot products may lose (the core alone: max 0.5-2.1e-7 of sum|terms| for K = 32 .. 784, the fp32 MFMA chain
+    0.8-2.2e-7: profiles/r05_f16x4_study.txt)."""
     from montecarlopredictivecoding_amd import _lib as L
     from montecarlopredictivecoding_amd.engine import Engine
     dev = _dev()

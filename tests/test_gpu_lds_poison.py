@@ -1,10 +1,10 @@
 """No result of the step kernels depends on LDS content they did not produce.
 
-Round 3's intermittent NaN: the bf16x6 GEMM core reads its LDS operand in whole 32-deep k-blocks, 12 floats beyond a row whose width
+Round 3's intermittent NaN: the GEMM core (bf16x6 then, fp16 x 3 now) reads its LDS operand in whole 32-deep k-blocks, 12 floats beyond a row whose width
 is 16 mod 32; zero weights made those products zero only while the over-read values were FINITE, and for the last row of a plan the
 over-read left the plan and returned whatever another kernel had left in the CU's LDS (scripts/nan_repro.py reproduces it on the old
 builds; profiles/r04_nan_repro.txt).  Since round 4 the over-reading lanes take their address from a zero region of the plan
-(csrc/mcpc_gemm6.h, KParams::lds_zero): the products are zeros whatever lies behind the row.  This file pins that by construction: the LDS of EVERY compute unit is filled with a poison
+(csrc/mcpc_gemm_f16.h, KParams::lds_zero; the fp16 core of round 5 reads its operand the same way, in the GEMM and in the row pre-pass): the products are zeros whatever lies behind the row.  This file pins that by construction: the LDS of EVERY compute unit is filled with a poison
 pattern (mcpc_debug_poison_lds: signalling NaN, +Inf, a huge finite value, zeros) immediately before each engine call, on networks
 whose widths are not multiples of 32 (200, 33, 17, 21, 40 ...), on every kernel form and LDS plan the library has; results must match
 the NumPy oracle AND be bitwise independent of the pattern.
