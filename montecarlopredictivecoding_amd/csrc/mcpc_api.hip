@@ -191,6 +191,7 @@ struct mcpc_engine {
     unsigned* spillmax = nullptr;   // [kMaxRingParts][kSpillTensors]: per ring part, the largest |value| per spilled tensor of the segment
                                     // that filled it (bit patterns; written by the step kernels, read by the Hebbian GEMMs of that part)
     int lds_spillmax = 0;
+    int g_first = -1;               // in-place table: first entry with work for the GEMM waves (build_phases_ws2)
     int lds_rowexp = 0;             // in-place plan: kRowExpFloats words of row exponents (mcpc_kernels.h: rowexp_track)
     unsigned long long* clk = nullptr;   // profiling: {shader cycles, 100 MHz ticks} of one wave per launch (KParams::clk)
     float* dummy = nullptr;         // 4 KiB of zeros (KParams::dummy)
@@ -545,6 +546,18 @@ int build_phases_ws2(mcpc_engine* e) {
         return d;
     };
     for (auto& k : ph) { k.dep_e = resolve(k.dep_e); k.dep_g = resolve(k.dep_g); k.dep_se = resolve(k.dep_se); }
+    // the GEMM waves walk only the entries they have work in (a GEMM, or the hand-off of the read-out's back-projection): FWD_0, the
+    // energy entry and x updates without a back-projection cost them a table round each for nothing
+    auto g_works = [&](const KPhase& k) { return (k.flags & (PHF_WS_GEMM | PHF_WS2_HANDOFF)) != 0; };
+    e->g_first = -1;
+    for (size_t i = 0; i < ph.size(); ++i) if (g_works(ph[i])) { e->g_first = (int)i; break; }
+    for (size_t i = 0; i < ph.size(); ++i) {
+        ph[i].next_g = e->g_first;
+        for (size_t d = 1; d <= ph.size(); ++d) {
+            const size_t j = (i + d) % ph.size();
+            if (g_works(ph[j])) { ph[i].next_g = (int)j; break; }
+        }
+    }
     int rc = dmalloc(e->phases, ph.size());
     if (rc) return rc;
     if (hipMemcpy(e->phases, ph.data(), ph.size() * sizeof(KPhase), hipMemcpyHostToDevice) != hipSuccess)
@@ -1337,7 +1350,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         H.lds_bias = e->lds_hbias; H.lds_yw = e->lds_yw;
     }
     P.mu1 = e->mu1; P.epart = e->epart; P.epart_slots = (int)eslots;
-    P.phases = e->phases; P.n_phases = e->n_phases; P.wexp = e->wexp; P.spillmax = nullptr; P.lds_spillmax = e->lds_spillmax; P.lds_rowexp = e->lds_rowexp;
+    P.phases = e->phases; P.n_phases = e->n_phases; P.wexp = e->wexp; P.spillmax = nullptr; P.lds_spillmax = e->lds_spillmax; P.lds_rowexp = e->lds_rowexp; P.g_first = e->g_first;
     P.stagger_cycles = e->knobs.stagger;
     P.L = e->L; P.has_head = e->has_head; P.B = e->d.batch; P.Bpad = e->Bpad; P.T = r->T;
     P.xopt = r->xopt_kind; P.update_x = r->update_x ? 1 : 0;

@@ -90,6 +90,7 @@ struct KPhase {
     int rot;               // in-place variant: pair k owns tiles tile0 + ((k + rot) & 3) + 4 i (balances uneven chunks)
     int dep_se;            // in-place variant: entry all E waves must have passed before this entry's block is STORED (its
                            // LDS rows are still read by their epilogues); dep_g is waited for at the same point
+    int next_g;            // in-place variant: the next entry (cyclic) in which the GEMM waves have work -- they visit no other
     int b_row, o_row;      // in-place variant: id of the B operand's / of the produced operand's row-exponent words (KParams::lds_rowexp;
                            // -1: none -- the GEMM wave scans the row itself)
 };
@@ -146,6 +147,7 @@ struct KParams {
                                      // target of the workgroup's chains live in LDS for the whole launch (mcpc_ws2_lean.h: XL)
     int spill_sys;                   // Hebbian spill stores at system scope (write-through): shards whose spill per step is far beyond the L2s
     int lds_floats;                  // floats of dynamic LDS of this plan (cleared once per launch: see mcpc_gemm_f16.h, k ranges)
+    int g_first;                     // in-place variant: first table entry with work for the GEMM waves (-1: none)
     int lds_rowexp;                  // float offset of kRowExpIds x 16 words: per B operand and chain row, (generation << 8) | biased exponent of
                                      // the row's largest |value|, kept by the epilogue waves that WRITE the rows (rowexp_track below)
     int lds_zero;                    // float offset of 16 floats of the plan that nothing writes after that: what the GEMM core's lanes beyond a

@@ -24,7 +24,7 @@ b = [((torch.rand(dims[j + 1], generator=g) * 2 - 1) / dims[j] ** 0.5).to(dev) f
 for B in batches:
     y = (torch.rand(B, n_out, generator=g) < 0.13).float().to(dev)
     xs = [((torch.rand(B, n, generator=g) * 2 - 1)).to(dev) for n in sizes]
-    eng = Engine(sizes, [L.ACT_RELU] * 3, 20, n_out, B, device=dev)
+    eng = Engine(sizes, [L.ACT_RELU] * 3, 20, n_out, B, device=dev, tuning=os.environ.get("SMALL_TUNING"))
     eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
     out = []
     for name, kw in (("mcpc", dict(noise_mode=L.NOISE_PHILOX, lr=0.03)), ("map-adam", dict(noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.1)),
