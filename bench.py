@@ -374,8 +374,8 @@ def main():
                                                   % ("%.3f GHz" % ghz if ghz and ghz > 0.5 else "not measured: 2.4 GHz peak"),
                                        "workgroups_per_launch": wg_per_launch,
                                        "note": "the fragment stream of a workgroup on its CU's vector-memory return path: one of the serial terms "
-                                               "of a 16-chain step (MFMAs 5.6 us, fragment requests 4.2, operand split 3.9, table skeleton 4.8 of "
-                                               "~30; timing builds in profiles/r05_k1_bounds.txt, DESIGN section 4)"},
+                                               "of a 16-chain step (MFMAs 5.6 us, fragment requests 4.2, operand split ~1.5, table skeleton ~4 of "
+                                               "~27; timing builds in profiles/r05_k1_bounds.txt, DESIGN section 4)"},
                     "note": note}
             return line
 
