@@ -307,3 +307,85 @@ def test_gemm_core_accuracy_against_fp64():
         assert float((err / bound).max()) < 1e-6, (l, float((err / bound).max()))
         assert float((err / bound).max()) > 0                      # (not vacuous: the step did change x)
         assert float(gl.abs().max()) > 0.1
+
+
+def _mixed_scale_problem(dev, act, seed=43):
+    """cfg-M's widths, 64 chains whose states (and targets) differ in scale by 10^(c mod 7 - 3), no biases: every B row of every GEMM has a
+    scale of its own."""
+    sizes, n_in, n_out, B = [30, 256, 256], 30, 784, 64
+    g = torch.Generator().manual_seed(seed)
+    dims = [n_in] + sizes + [n_out]
+    W = [((torch.rand(dims[j + 1], dims[j], generator=g) * 2 - 1) * (3.0 / dims[j] ** 0.5)).to(dev) for j in range(4)]
+    b = [torch.zeros(dims[j + 1], device=dev) for j in range(4)]
+    scale = (10.0 ** (torch.arange(B) % 7 - 3).float()).unsqueeze(1)
+    xs = [((torch.rand(B, n, generator=g) * 2 - 1) * 1.5 * scale).to(dev) for n in sizes]
+    inputs = ((torch.rand(B, n_in, generator=g) * 2 - 1) * scale).to(dev)
+    y = ((torch.rand(B, n_out, generator=g) * 2 - 1) * scale).to(dev)
+    return sizes, n_in, n_out, B, W, b, xs, inputs, y, scale.to(dev)
+
+
+@pytest.mark.parametrize("tuning", [None, "ws=0"], ids=["in-place kernel (row words)", "barrier kernel (row scans)"])
+def test_rows_of_mixed_scale_keep_their_own_precision(tuning):
+    """The fp16 GEMM core scales every CHAIN ROW of its LDS operand by a power of two of its own (csrc/mcpc_gemm_f16.h; in the in-place
+    kernel the exponent comes from the epilogue waves that wrote the row: mcpc_kernels.h, rowexp_track).  Chains whose values differ by six
+    orders of magnitude sit side by side in one 16-chain tile here; ONE step with lr = 1 against an fp64 evaluation, every element within
+    1e-6 of the sum of the absolute values of ITS OWN terms -- a scale shared by the tile would leave the small chains a few bits
+    (profiles/r05_f16x4_study.txt: ten times the error on rows of mixed scale, and that with a spread of 1e6 instead of 1e3)."""
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    dev = _dev()
+    sizes, n_in, n_out, B, W, b, xs, inputs, y, scale = _mixed_scale_problem(dev, "identity")
+    var = 0.8
+    eng = Engine(sizes, [L.ACT_IDENTITY] * 3, n_in, n_out, B, device=dev, tuning=tuning)
+    eng.bind_params(W, b); eng.bind_inputs(inputs); eng.bind_target(y)
+    eng.load_state(xs)
+    eng.run(1, loss_kind=L.LOSS_GAUSSIAN, loss_var=var, lr=1.0, noise_mode=L.NOISE_NONE)
+    out = [torch.empty_like(x) for x in xs]
+    eng.store_state(out)
+    eng.sync_check()
+    eng.close()
+    Wd, xd = [w.double() for w in W], [x.double() for x in xs]
+    pre = [inputs.double()] + xd
+    mu = [pre[j] @ Wd[j].T for j in range(4)]
+    amu = [pre[j].abs() @ Wd[j].abs().T for j in range(4)]
+    e = [xd[l] - mu[l] for l in range(3)] + [(mu[3] - y.double()) / var]
+    ae = [xd[l].abs() + amu[l] for l in range(3)] + [(amu[3] + y.double().abs()) / var]
+    worst = 0.0
+    for l in range(3):
+        sign = 1.0 if l == 2 else -1.0
+        gl = e[l] + sign * (e[l + 1] @ Wd[l + 1])
+        bound = ae[l] + ae[l + 1] @ Wd[l + 1].abs()
+        err = (out[l].double() - (xd[l] - gl)).abs()
+        rel = err / bound
+        worst = max(worst, float(rel.max()))
+        # the bound of a chain follows the chain's own scale (six orders of magnitude between the chains of a tile) ...
+        per_chain = bound.max(dim=1).values / scale[:, 0].double()
+        assert float(per_chain.max() / per_chain.min()) < 50.0
+        # ... and every chain meets it, the smallest like the largest
+        assert float(rel.max()) < 1e-6, (l, float(rel.max()), int(rel.max(dim=1).values.argmax()))
+    assert worst > 0
+
+
+def test_row_words_equal_row_scans_over_many_steps():
+    """The in-place kernel takes a row's exponent from the word its producers keep, the barrier kernel scans the row: the same exponent,
+    so the trajectories of rows of mixed scale agree BITWISE after 40 steps (noise included) -- any word that was stale, early, or short of
+    a tile would change a scale and with it the bits."""
+    from montecarlopredictivecoding_amd import _lib as L
+    from montecarlopredictivecoding_amd.engine import Engine
+    dev = _dev()
+    sizes, n_in, n_out, B, W, b, xs, inputs, y, scale = _mixed_scale_problem(dev, "relu", seed=44)
+    y01 = (y > 0).float()
+    res = []
+    for tuning in (None, "ws=0"):
+        eng = Engine(sizes, [L.ACT_RELU] * 3, n_in, n_out, B, device=dev, tuning=tuning)
+        eng.bind_params(W, b); eng.bind_inputs(inputs); eng.bind_target(y01)
+        eng.load_state(xs)
+        eng.run(40, loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, noise_var=2.0, seed=5, step_base=0, energy_mode=L.ENERGY_ALL)
+        out = [torch.empty_like(x) for x in xs]
+        eng.store_state(out)
+        eng.sync_check()
+        res.append((out, None, eng.query()["step_kernel"]))
+        eng.close()
+    assert "ws2" in res[0][2] and "ws2" not in res[1][2], (res[0][2], res[1][2])
+    for a, c in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, c)
