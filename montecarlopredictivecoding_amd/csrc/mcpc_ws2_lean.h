@@ -49,15 +49,23 @@ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umu
 // XL): system-scope stores -- sc1, with or without sc0 / nt -- take the learning call of cfg-M from 80.4-81.1 to 77.6-78.0 us
 // per step, nt alone or sc0 nt do not; not issuing the stores at all: 71.7.  A shard of 256 chains, whose spill never leaves the
 // L2, loses 6 % with them (24.4 -> 25.8 us per step of a learning call): `sys` (KParams::spill_sys, wave-uniform) chooses.
+// Round 5 (the step kernel 1.3 x faster, the same stores per step): measured again, one gpurun call, learning call at 6000 / 4096 chains,
+// us per step -- write-back 59.1-60.2 / 40.1-40.3, sc1 57.0-57.2 / 38.2-38.4, sc0 sc1 56.6-57.4 / 37.8, sc1 nt 55.9-56.2 / 37.8-38.2, sc0 sc1 nt
+// (round 3's choice) 56.6 / 38.2-38.6, and a plain GLOBAL nontemporal store (no buffer descriptor) **55.1-55.5 / 37.3-37.4**: the default now.
 #ifndef MCPC_SPILL_AUX
-#define MCPC_SPILL_AUX 19          // gfx950 cache-policy bits of the store: 1 = sc0, 2 = nt, 16 = sc1; 0 = plain write-back; < 0: global nontemporal store
+#define MCPC_SPILL_AUX -1          // < 0: global nontemporal store; else the gfx950 cache-policy bits of a buffer store: 1 = sc0, 2 = nt, 16 = sc1; 0 = plain write-back
 #endif
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void spill_st4(float* base, uint32_t image_bytes, uint32_t boff, f32x4 v, bool sys = true) {
 #ifdef MCPC_EXP_NOSPILL        // timing experiment only (wrong Hebbian sums): the spill stores are not issued
     (void)base; (void)image_bytes; (void)boff; (void)v; (void)sys;
 #elif MCPC_SPILL_AUX < 0
-    gst4s(base, boff, v); (void)sys;
+    if (sys) {
+        gst4s(base, boff, v); (void)image_bytes;
+    } else {          // (a small shard's spill stays in the L2: plain write-back stores)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)image_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)boff, 0, 0);
+    }
 #else
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)image_bytes, 0x00020000);
     if (sys) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)boff, 0, MCPC_SPILL_AUX);
