@@ -97,14 +97,16 @@ __device__ __forceinline__ float pow2i(int e) { return __uint_as_float((unsigned
 //   a_exp     exponent the packed weights were scaled by (per Linear, written by the pack kernels);
 //   mode      GS_FRESH: the accumulators start at zero and come back UN-SCALED;  GS_ACCUM: they carry the sum of earlier GEMMs in units of
 //             2^(a_exp + run) and stay scaled (the caller un-scales with gemm_unscale when the sum is complete);
-//   fixed_b   >= -kScaleClamp: the B rows take this exponent (bounded operand: no pre-pass);  kScaleAuto: from the row's maximum;
+//   scan      (wave-uniform) 1: the B rows' exponents come from a pre-pass over the rows (gemm_row_exp);  0: from fixed_b;
+//   fixed_b   scan == 0: the exponent of this lane's B row -- a constant for a bounded operand, or the word the row's producers keep (then
+//             a per-lane value that may still be in flight from LDS: nothing branches on it before the first B block has been requested);
 //   run       GS_ACCUM: the B exponent the accumulators are in (kRunNone before the first chunk); per lane = per chain.
 enum : int { GS_FRESH = 0, GS_ACCUM = 1 };
 constexpr int kScaleAuto = -1000, kRunNone = 1000;
 //   short_k   1: the whole contraction has K <= 64 and keeps the a_m b_m term (gemm_fixed: MM); 0: it does not; -1: decided from this GEMM's own
 //             k-blocks.  A sum over several GEMMs (GS_ACCUM) must be told: its chunks may be short where the contraction is long, and how
 //             the contraction is cut into chunks must not change its arithmetic.
-struct GemmScale { int a_exp; int mode; int fixed_b; int run; int short_k; };
+struct GemmScale { int a_exp; int mode; int fixed_b; int run; int short_k; int scan; };
 
 #ifdef MCPC_EXP_NOLOAD   // timing experiment only (wrong results): every fragment load re-reads k-block 0 -> L1 hits
 #define MCPC_KSEL(k_) 0
@@ -126,7 +128,7 @@ struct GemmScale { int a_exp; int mode; int fixed_b; int run; int short_k; };
 // u - 1 has just freed.  Static register names need the rotation unrolled over three k-blocks.
 // (Two chain tiles per fragment -- CTT = 2 -- were measured in rounds 4 and 5 and dropped: profiles/r04_k1_bounds.txt, r05_k1_decomp.txt.)
 //
-// bscale = 2^sb of this lane's chain row (gemm_row_exp below, or the caller's fixed exponent).
+// b_exp: 2^b_exp scales this lane's chain row (gemm_row_exp below, or the caller's fixed exponent).
 // MM: with the a_m b_m term (2^-22 of the leading one).  GEMMs of at most kShortK k-blocks (K <= 64) keep it: there are too few terms there
 // for the rounding errors of the 22-bit operands to average out (K = 32: max 1.6e-7 / rms 3.1e-8 of sum |terms| without it against 1.2e-7 /
 // 2.6e-8 with it; fp32 MFMA chain 1.0e-7 / 2.1e-8).  From K = 96 on the term changes neither figure (profiles/r05_f16x4_study.txt) and longer
@@ -134,9 +136,10 @@ struct GemmScale { int a_exp; int mode; int fixed_b; int run; int short_k; };
 constexpr int kShortK = 2;
 template <int NT, int NTT, int CTT, int NW, bool MM>
 __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nkb, int kw,
-                                           const float* B, int ldb, int lane, frag_t (&pre)[NTT], const float* zeros, float bscale) {
+                                           const float* B, int ldb, int lane, frag_t (&pre)[NTT], const float* zeros, int b_exp) {
     static_assert(CTT == 1, "one chain tile per workgroup (two were measured and dropped in rounds 4 and 5: DESIGN.md section 4)");
     constexpr int N0 = NT < 2 ? NT : 2, N1 = NT - N0;            // tiles of group 0 / group 1
+    if (nkb <= 0) return;
     const int c = lane & 15, g = lane >> 4;
     const float* bp = B + c * ldb + 8 * g;
     // the LAST block: lanes whose eight k values lie beyond kw (g >= 2 when kw % 32 == 16) read the plan's zero region instead
@@ -200,31 +203,48 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
         bs[0] = bsn_;                                                                               \
     } while (0)
 #define MCPC_BLOCK(sa_, sb_, sc_, k_) MCPC_BLOCK1(sa_, sb_, sc_, k_)
+    // The LAST block of a GEMM requests, reads and splits nothing: there is no next block.  (Until round 5 every block ran MCPC_BLOCK1 with
+    // its requests clamped to the last block: 8 fragment loads, 2 LDS reads and a 24-instruction split per GEMM for nothing -- ~400 of the
+    // ~2000 cycles a table entry costs a GEMM wave beyond its k-blocks, 13 entries per step.)
+#define MCPC_BLOCK_LAST(sa_, sb_)                                                                   \
+    do {                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        MCPC_SUB(sa_, 0, 0);                                                                        \
+        MCPC_SUB(sb_, 1, 0);                                                                        \
+    } while (0)
     // block 0 arrives in `pre`: tiles 0, 1 -> set 0, tiles 2, 3 -> set 1
 #pragma unroll
     for (int i = 0; i < N0; ++i) s0[i] = pre[i];
 #pragma unroll
     for (int i = 0; i < N1; ++i) s1[i] = pre[2 + i];
     MCPC_LOAD_B(0);
+    // (the exponent may still be on its way from LDS -- the row word of the in-place kernel -- : first used here, behind the B reads)
+    const float bscale = pow2i(b_exp);
     MCPC_SPLIT1(0);
     MCPC_LOAD_B(1);
     int k = 0;
-    // steady state: three k-blocks per round (the rotation's period); every request is for an existing block or clamped to the last
+    // steady state: three k-blocks per round (the rotation's period) while a block FOLLOWS the round; then up to two more full blocks and
+    // the last one, which prefetches nothing (the LDS read of k + 2 in the block before it is clamped to the last block: harmless)
     if constexpr (!MM) {                    // (MM: at most kShortK = 2 blocks, the tail below)
-        for (; k + 3 <= nkb; k += 3) {
+        for (; k + 3 < nkb; k += 3) {
             MCPC_BLOCK(s0, s1, s2, k);          // (k, G0) = s0, (k, G1) = s1;  s2 <- (k+1, G0), s0 <- (k+1, G1)
             MCPC_BLOCK(s2, s0, s1, k + 1);      // s1 <- (k+2, G0), s2 <- (k+2, G1)
             MCPC_BLOCK(s1, s2, s0, k + 2);      // s0 <- (k+3, G0), s1 <- (k+3, G1): the round's starting assignment again
         }
     }
-    const int rem = nkb - k;
-    if (rem == 2) {
+    const int rem = nkb - k;                // 1 .. 3 blocks left (MM: 1 .. 2)
+    if (rem == 3) {
         MCPC_BLOCK(s0, s1, s2, k);
         MCPC_BLOCK(s2, s0, s1, k + 1);
-    } else if (rem == 1) {
+        MCPC_BLOCK_LAST(s1, s2);
+    } else if (rem == 2) {
         MCPC_BLOCK(s0, s1, s2, k);
+        MCPC_BLOCK_LAST(s2, s0);
+    } else {
+        MCPC_BLOCK_LAST(s0, s1);
     }
 #undef MCPC_BLOCK
+#undef MCPC_BLOCK_LAST
 #undef MCPC_BLOCK1
 #undef MCPC_SPLIT1
 #undef MCPC_SUB
@@ -269,12 +289,12 @@ __device__ __forceinline__ void gemm_unscale(f32x4 (&acc)[NTT][CTT], int a_exp, 
 // nt (wave-uniform, 1..NTT) selects a straight-line instantiation: no per-tile branches in the loop
 template <int N, int NTT, int CTT, int NW, bool MM>
 __device__ __forceinline__ void gemm_dispatch(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nt, int nkb, int kw,
-                                              const float* B, int ldb, int lane, frag_t (&pre0)[NTT], const float* zeros, float bscale) {
+                                              const float* B, int ldb, int lane, frag_t (&pre0)[NTT], const float* zeros, int b_exp) {
     if constexpr (N >= NTT) {
-        gemm_fixed<NTT, NTT, CTT, NW, MM>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0, zeros, bscale);
+        gemm_fixed<NTT, NTT, CTT, NW, MM>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0, zeros, b_exp);
     } else {
-        if (nt == N) gemm_fixed<N, NTT, CTT, NW, MM>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0, zeros, bscale);
-        else gemm_dispatch<N + 1, NTT, CTT, NW, MM>(acc, A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, bscale);
+        if (nt == N) gemm_fixed<N, NTT, CTT, NW, MM>(acc, A, aoff, nkb, kw, B, ldb, lane, pre0, zeros, b_exp);
+        else gemm_dispatch<N + 1, NTT, CTT, NW, MM>(acc, A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, b_exp);
     }
 }
 // kw: valid k width of the B rows (a multiple of 16, 32 (nkb - 1) < kw <= 32 nkb); zeros: 16 floats of LDS that stay zero for the launch.
@@ -284,9 +304,9 @@ template <int NTT, int CTT, int NW>
 __device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const void* A, const int (&aoff)[NTT], int nt, int nkb, int kw,
                                            const float* B, int ldb, int lane, frag_t (&pre0)[NTT], const float* zeros, GemmScale& gs) {
 #ifdef MCPC_EXP_NOROWEXP    // timing experiment only (wrong results): no pre-pass over the row, a constant exponent
-    int b_exp = gs.fixed_b != kScaleAuto ? gs.fixed_b : 8;
+    int b_exp = gs.scan ? 8 : gs.fixed_b;
 #else
-    int b_exp = gs.fixed_b != kScaleAuto ? gs.fixed_b : gemm_row_exp(B, ldb, nkb, kw, lane, zeros);
+    int b_exp = gs.scan ? gemm_row_exp(B, ldb, nkb, kw, lane, zeros) : gs.fixed_b;
 #endif
     if (gs.mode == GS_ACCUM) {
         if (gs.run != kRunNone && b_exp != gs.run) {
@@ -303,8 +323,8 @@ __device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const void* A
         gs.run = b_exp;
     }
     const bool mm = gs.short_k >= 0 ? gs.short_k != 0 : nkb <= kShortK;
-    if (mm && nkb <= kShortK) gemm_dispatch<1, NTT, CTT, NW, true>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, pow2i(b_exp));
-    else gemm_dispatch<1, NTT, CTT, NW, false>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, pow2i(b_exp));
+    if (mm && nkb <= kShortK) gemm_dispatch<1, NTT, CTT, NW, true>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, b_exp);
+    else gemm_dispatch<1, NTT, CTT, NW, false>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, b_exp);
     if (gs.mode == GS_FRESH) gemm_unscale<NTT, CTT>(acc, gs.a_exp, b_exp);
 }
 

@@ -662,9 +662,9 @@ __global__ __launch_bounds__(NW * 64, MCPC_BARRIER_WAVES_PER_EU) void mcpc_steps
             if (ph.type != PH_HEADB) issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
             if (nt > 0 && ph.nkb > 0) {
                 // HEADB phases add up in accb over the chunks of the read-out, in scaled units (accb_run / accb_aexp); every other GEMM is fresh
-                GemmScale gs{load_wexp(P.wexp, ph.a_lin), ph.type == PH_HEADB ? GS_ACCUM : GS_FRESH,
-                             ph.type == PH_HEADB ? headb_fixed_exp(P.head.loss_kind) : kScaleAuto, accb_run,
-                             ph.type == PH_HEADB ? (P.head.npad <= kShortK * kKB ? 1 : 0) : -1};
+                const int hb_exp = ph.type == PH_HEADB ? headb_fixed_exp(P.head.loss_kind) : kScaleAuto;
+                GemmScale gs{load_wexp(P.wexp, ph.a_lin), ph.type == PH_HEADB ? GS_ACCUM : GS_FRESH, hb_exp, accb_run,
+                             ph.type == PH_HEADB ? (P.head.npad <= kShortK * kKB ? 1 : 0) : -1, hb_exp == kScaleAuto ? 1 : 0};
                 gemm_tiles<NTW, CTT, NW>(acc, ph.A, aoff, nt, ph.nkb, ph.kw, lds + ph.b_lds, ph.ldb, lane, pre0, lds + P.lds_zero, gs);
                 if (ph.type == PH_HEADB) { accb_run = gs.run; accb_aexp = gs.a_exp; }
             } else if ((ph.flags & PHF_ACC_FROM_B) && ph.type != PH_HEADB && accb_run != kRunNone) {
