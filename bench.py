@@ -364,7 +364,7 @@ def main():
                     # the same launches against the HBM roofline (north_star asks for both): algorithmic streaming bytes, SURVEY 8(d)
                     "hbm_side": {"achieved": bytes_per_step * spl / avg_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": bytes_per_step * spl / avg_s / 1e9 / PEAK_HBM_GBS, "bytes_per_chain_step": 7472},
-                    # every workgroup streams the packed weights (Wf + Wb as three bf16 planes, 3.29 MB) out of its XCD's L2 once per step
+                    # every workgroup streams the packed weights (Wf + Wb as two fp16 planes, 2.19 MB) out of its XCD's L2 once per step
                     "l2_fragment_stream": {"achieved": n_wg * FRAG_BYTES_PER_WG_STEP * spl / avg_s / 1e9, "peak": PEAK_L2_GBS,
                                            "unit": "GB/s", "frac": n_wg * FRAG_BYTES_PER_WG_STEP * spl / avg_s / 1e9 / PEAK_L2_GBS,
                                            "workgroups": n_wg, "bytes_per_workgroup_step": FRAG_BYTES_PER_WG_STEP},
