@@ -53,13 +53,7 @@ __device__ __forceinline__ void ws_wait_one(const int* p, int need, int* err, in
     MCPC_WS_FENCE(__ATOMIC_ACQUIRE);
 }
 __device__ __forceinline__ void ws_publish(int* p, int v) {
-#ifdef MCPC_WS_RELEASE_IN_ORDER
-    // LDS performs one wave's operations in the order it issued them: the counter's store lands behind the block's stores without
-    // waiting for them (a compiler barrier keeps the order of issue)
-    asm volatile("" ::: "memory");
-#else
     MCPC_WS_FENCE(__ATOMIC_RELEASE);     // LDS writes of this wave before the counter
-#endif
     ws_st(p, v);
 }
 
