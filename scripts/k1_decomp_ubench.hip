@@ -21,6 +21,26 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include "mcpc_bf16x6.h"
 using namespace mcpc;
+// F16 = 1 (default since the product moved to the fp16 pipe in the second half of round 5): two fp16 planes per fragment, a 24-instruction
+// split, three v_mfma_f32_16x16x32_f16 per tile and k-block;  -DF16=0: the bf16x6 arithmetic the go / no-go of profiles/r05_k1_decomp.txt
+// was measured with (three planes, six MFMAs).
+#ifndef F16
+#define F16 1
+#endif
+constexpr int kPlanes = F16 ? 2 : 3;
+constexpr int kFragStride = 64 * kPlanes;                        // u32x4 units per (tile, k-block)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2_pair_f16(f32x2 x, float sc, unsigned& h, unsigned& m) {
+    const f32x2 xs = x * sc;
+    const f16x2_t hh = __builtin_convertvector(xs, f16x2_t);
+    const f32x2 r = xs - __builtin_convertvector(hh, f32x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+}
+__device__ __forceinline__ f32x4 mfma3(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
 
 struct Entry { int base; int nkb; int tiles; int items; };      // base: u32x4 offset of the entry's fragments; items: float4s per chain tile
 constexpr int kEntries = 12;
@@ -31,6 +51,15 @@ constexpr int RING = 3;
 struct Frag { u32x4 h, m, l; };
 __device__ __forceinline__ Frag split8(f32x4 x0, f32x4 x1) {
     unsigned h[4], m[4], l[4];
+#if F16
+    const float sc = 4096.f;                                      // (the product takes the row's scale from a word its producers keep)
+    split2_pair_f16(f32x2{x0.x, x0.y}, sc, h[0], m[0]); split2_pair_f16(f32x2{x0.z, x0.w}, sc, h[1], m[1]);
+    split2_pair_f16(f32x2{x1.x, x1.y}, sc, h[2], m[2]); split2_pair_f16(f32x2{x1.z, x1.w}, sc, h[3], m[3]);
+    l[0] = l[1] = l[2] = l[3] = 0u;
+    Frag f16f;
+    f16f.h = u32x4{h[0], h[1], h[2], h[3]}; f16f.m = u32x4{m[0], m[1], m[2], m[3]}; f16f.l = u32x4{0u, 0u, 0u, 0u};
+    return f16f;
+#endif
     split3_pair_fast(f32x2{x0.x, x0.y}, h[0], m[0], l[0]);
     split3_pair_fast(f32x2{x0.z, x0.w}, h[1], m[1], l[1]);
     split3_pair_fast(f32x2{x1.x, x1.y}, h[2], m[2], l[2]);
@@ -54,11 +83,12 @@ __device__ __forceinline__ void gemm_entry(f32x4 (&acc)[4][CT], const gu32x4* A,
     f32x4 bP[CT][3], bQ[CT][3];
     int aoff[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) aoff[t] = base + (tile0 + t) * nkb * 192 + lane;
+    for (int t = 0; t < NT; ++t) aoff[t] = base + (tile0 + t) * nkb * kFragStride + lane;
 #define LOADSET(a_, b_, k_)                                                                                    \
     do {                                                                                                       \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                       \
-            a_[t].h = A[aoff[t] + (k_) * 192]; a_[t].m = A[aoff[t] + (k_) * 192 + 64]; a_[t].l = A[aoff[t] + (k_) * 192 + 128]; } \
+            a_[t].h = A[aoff[t] + (k_) * kFragStride]; a_[t].m = A[aoff[t] + (k_) * kFragStride + 64];         \
+            if (!F16) a_[t].l = A[aoff[t] + (k_) * kFragStride + 128]; }                                       \
         _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) {                                                    \
             const float* r_ = lds_b + (16 * ct + c) * LDB + ((k_) & 7) * 32 + 8 * g;                           \
             b_[ct][0] = *(const f32x4*)r_; b_[ct][1] = *(const f32x4*)(r_ + 4);                                \
@@ -71,12 +101,18 @@ __device__ __forceinline__ void gemm_entry(f32x4 (&acc)[4][CT], const gu32x4* A,
             if (PRE) { B_[ct].h = __builtin_bit_cast(u32x4, b_[ct][0]); B_[ct].m = __builtin_bit_cast(u32x4, b_[ct][1]);      \
                        B_[ct].l = __builtin_bit_cast(u32x4, b_[ct][2]); }                                      \
             else B_[ct] = split8(b_[ct][0], b_[ct][1]); }                                                      \
+        if (F16) {                                                                                             \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) acc[t][ct] = mfma3(a_[t].m, B_[ct].h, acc[t][ct]); \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) acc[t][ct] = mfma3(a_[t].h, B_[ct].m, acc[t][ct]); \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) acc[t][ct] = mfma3(a_[t].h, B_[ct].h, acc[t][ct]); \
+        } else {                                                                                               \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) acc[t][ct] = mfma6(a_[t].m, B_[ct].m, acc[t][ct]); \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) acc[t][ct] = mfma6(a_[t].l, B_[ct].h, acc[t][ct]); \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) acc[t][ct] = mfma6(a_[t].h, B_[ct].l, acc[t][ct]); \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) acc[t][ct] = mfma6(a_[t].m, B_[ct].h, acc[t][ct]); \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) acc[t][ct] = mfma6(a_[t].h, B_[ct].m, acc[t][ct]); \
         _Pragma("unroll") for (int t = 0; t < NT; ++t) _Pragma("unroll") for (int ct = 0; ct < CT; ++ct) acc[t][ct] = mfma6(a_[t].h, B_[ct].h, acc[t][ct]); \
+        }                                                                                                      \
     } while (0)
     LOADSET(aP, bP, 0);
     int kb = 0;
@@ -181,7 +217,7 @@ static Table make_table(size_t* frag_units) {
         t.e[p].base = (int)off; t.e[p].nkb = spec[p].nkb;
         t.e[p].tiles = spec[p].tiles;
         t.e[p].items = spec[p].tiles * 64;                            // 16 x 16 outputs per tile = 64 float4
-        off += (size_t)spec[p].tiles * spec[p].nkb * 192;
+        off += (size_t)spec[p].tiles * spec[p].nkb * kFragStride;
     }
     // HB entries carry no epilogue of their own beyond the hand-off (the back-projection stays in registers): a token amount
     for (int p : {3, 5, 6, 7}) t.e[p].items = 64;
@@ -218,7 +254,7 @@ int main(int argc, char** argv) {
     u32x4* A; float* out;
     hipMalloc(&A, units * 16); hipMemset(A, 0x3c, units * 16);
     hipMalloc(&out, (size_t)256 * 1024 * 4);
-    printf("fragment stream per workgroup-step: %.2f MB (product: 3.29 MB)\n", units * 16 / 1e6);
+    printf("F16 = %d: fragment stream per workgroup-step: %.2f MB (product: %s MB)\n", F16, units * 16 / 1e6, F16 ? "2.19" : "3.29");
     // --- calibration: today's form.  The product measures 35.2 (all), 34.8 (NOEPI), 19.6 (NOGEMM), 4.8 (neither) us per workgroup-step
     for (int ew : {96, 160, 224}) {
         run<1, 1, false, 3>("16 chains, 4 G + 4 E (today's form)", 256, ew, A, tab, out);
