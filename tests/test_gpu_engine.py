@@ -298,6 +298,13 @@ def test_gemm_core_accuracy_against_fp64():
     amu = [pre[j].abs() @ Wd[j].abs().T + bd[j].abs() for j in range(4)]        # sum of |terms| of each prediction
     e = [xd[l] - mu[l] for l in range(3)] + [(mu[3] - y.double()) / var]
     ae = [xd[l].abs() + amu[l] for l in range(3)] + [(amu[3] + y.double().abs()) / var]
+    # the same step in torch's fp32 on this GPU (rocBLAS / hipBLASLt fp32 GEMMs: what the reference's loop would run here), for scale
+    f32 = [torch.tanh(x) for x in xs]
+    fp32 = [1.0 - t * t for t in f32]
+    pre32 = [inputs] + f32
+    mu32 = [pre32[j] @ W[j].T + b[j] for j in range(4)]
+    e32 = [xs[l] - mu32[l] for l in range(3)] + [(mu32[3] - y) / var]
+    worst_engine, worst_torch = 0.0, 0.0
     for l in range(3):
         sign = 1.0 if l == 2 else -1.0
         back = e[l + 1] @ Wd[l + 1]
@@ -307,6 +314,12 @@ def test_gemm_core_accuracy_against_fp64():
         assert float((err / bound).max()) < 1e-6, (l, float((err / bound).max()))
         assert float((err / bound).max()) > 0                      # (not vacuous: the step did change x)
         assert float(gl.abs().max()) > 0.1
+        out32 = xs[l] - (e32[l] + sign * fp32[l] * (e32[l + 1] @ W[l + 1]))
+        worst_engine = max(worst_engine, float((err / bound).max()))
+        worst_torch = max(worst_torch, float(((out32.double() - (xd[l] - gl)).abs() / bound).max()))
+    # the fp16-piece arithmetic is in the error class of the fp32 GEMMs torch runs on the same device: within a factor of two of them
+    print(f"[gemm core] max error / sum|terms| against fp64: engine {worst_engine:.3e}, torch fp32 on this GPU {worst_torch:.3e}")
+    assert worst_engine <= max(2.0 * worst_torch, 3e-7), (worst_engine, worst_torch)
 
 
 def _mixed_scale_problem(dev, act, seed=43):
