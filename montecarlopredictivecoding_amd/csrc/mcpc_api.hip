@@ -65,7 +65,8 @@ struct Lin {
 // ("key=value,key=value"; see include/mcpc.h).  The library itself reads no environment variables.
 constexpr int kMaxRingParts = 8;
 struct Knobs {
-    int ws = -1;              // -1: automatic; 0: barrier kernel; 2: in-place wave-specialised kernel
+    int ws = -1;              // -1: automatic; 0: barrier kernel; 2: in-place wave-specialised kernel everywhere; 3: insist on the unified-wave
+                              // kernel (mcpc_steps_u.h) for the runs it serves (create fails when its LDS plan does not fit)
     int no_overlap = 0;       // 1: Hebbian flushes run serially on the caller's stream (one ring segment = the whole ring)
     int slot_cap = 384;       // spill-ring slots at most (3 parts of 128 steps)
     int spill_gb = 0;         // > 0: spill budget in GiB (overrides mcpc_net_desc::spill_budget_bytes)
@@ -113,7 +114,7 @@ int parse_tuning(const char* str, Knobs& k) {
             if (key == t.name) { *t.dst = val; found = true; }
         if (!found) return fail(MCPC_EINVAL, "unknown tuning key '%s' in mcpc_net_desc::tuning", key.c_str());
     }
-    if (k.ws != -1 && k.ws != 0 && k.ws != 2) return fail(MCPC_EINVAL, "tuning ws=%d: 0 (barrier kernel) or 2 (in-place kernel)", k.ws);
+    if (k.ws != -1 && k.ws != 0 && k.ws != 2 && k.ws != 3) return fail(MCPC_EINVAL, "tuning ws=%d: 0 (barrier kernel), 2 (in-place kernel) or 3 (unified-wave kernel)", k.ws);
     if (k.slot_cap < 2) k.slot_cap = 2;
     if (k.cu_slack < 0) k.cu_slack = 0;
     if (k.ring_parts < 2 || k.ring_parts > kMaxRingParts) return fail(MCPC_EINVAL, "tuning ring_parts=%d: 2..%d", k.ring_parts, kMaxRingParts);
@@ -121,6 +122,17 @@ int parse_tuning(const char* str, Knobs& k) {
 }
 
 }  // namespace
+
+// LDS plan and step table of the unified-wave kernel (mcpc_steps_u.h), kept BESIDE the engine's main plan: mcpc_run picks the kernel per
+// run (lean runs: fused SGD update with or without the Philox kick, Adam without noise), everything else stays on the main plan's kernel.
+struct UPlan {
+    bool ok = false;                // the plan fits the LDS (whole read-out error + state rows resident)
+    bool on = false;                // ... and the engine uses it (tuning ws=3, or the automatic choice: choose_unified)
+    int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_ws_sync = 0, lds_zero = 0, lds_spillmax = 0, lds_rowexp = 0;
+    int lds_x[kMaxLatent]{}, lds_bias[kMaxLatent]{}, lds_hbias = 0, lds_yw = 0, lds_bytes = 0;
+    KPhase* phases = nullptr;
+    int n_phases = 0;
+};
 
 struct mcpc_engine {
     mcpc_net_desc d{};
@@ -192,6 +204,7 @@ struct mcpc_engine {
                                     // that filled it (bit patterns; written by the step kernels, read by the Hebbian GEMMs of that part)
     int lds_spillmax = 0;
     int g_first = -1;               // in-place table: first entry with work for the GEMM waves (build_phases_ws2)
+    UPlan u;                        // unified-wave kernel: its own LDS plan and table
     int lds_rowexp = 0;             // in-place plan: kRowExpFloats words of row exponents (mcpc_kernels.h: rowexp_track)
     unsigned long long* clk = nullptr;   // profiling: {shader cycles, 100 MHz ticks} of one wave per launch (KParams::clk)
     float* dummy = nullptr;         // 4 KiB of zeros (KParams::dummy)
@@ -199,6 +212,7 @@ struct mcpc_engine {
     bool rr = false;
     int rr_k = 0, rr_m = 0;
     std::string rr_name;                 // mcpc_step_kernel_name of an engine on the round schedule
+    std::string u_rr_name;               // ... when its fused calls run on the unified-wave kernel
     std::vector<int> rr_count, rr_off;   // per launch of a cycle: workgroups, offset of its [ids][rel] rows in rr_tab
     int* rr_tab = nullptr;
     // profiling
@@ -249,7 +263,7 @@ int free_all(mcpc_engine* e) {
     if (e->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy(e->comm); e->comm = nullptr; e->comm_ranks = 0; }
     auto F = [](auto*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } };
     for (int l = 0; l < kMaxLatent; ++l) { F(e->x[l]); F(e->m[l]); F(e->v[l]); F(e->spill_a[l]); F(e->spill_e[l]); }
-    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ytile); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err); F(e->wexp); F(e->spillmax); F(e->clk); F(e->dummy);
+    F(e->e0sum); F(e->mu1); F(e->ypad); F(e->ytile); F(e->ybits); F(e->y_binary); F(e->spill_eo); F(e->slab); F(e->epart); F(e->adam_coef); F(e->phases); F(e->err); F(e->wexp); F(e->spillmax); F(e->clk); F(e->dummy); F(e->u.phases);
     for (auto& ln : e->lin) { F(ln.Wf); F(ln.Wb); F(ln.bias_pad); F(ln.G); F(ln.Gb); }
     for (auto& ev : e->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (int h = 0; h < kMaxRingParts; ++h) { if (e->ev_steps[h]) (void)hipEventDestroy(e->ev_steps[h]); if (e->ev_flush[h]) (void)hipEventDestroy(e->ev_flush[h]); e->ev_steps[h] = e->ev_flush[h] = nullptr; }
@@ -566,6 +580,206 @@ int build_phases_ws2(mcpc_engine* e) {
     return 0;
 }
 
+
+// ---- unified-wave kernel (mcpc_steps_u.h) ---------------------------------------------------------------------------------------------
+// LDS plan: FX_l, E_l, the WHOLE read-out error e_o [16][out_pad], the state rows X_l and the per-step constants of the workgroup's 16
+// chains.  No plan (u.ok == false, not an error) when that does not fit 160 KiB: such networks run on the in-place kernel.
+int plan_lds_u(mcpc_engine* e) {
+    UPlan& u = e->u;
+    u.ok = false;
+    const int CT = e->ct, L = e->L;
+    int off = 0;
+    for (int l = 0; l < L; ++l) { u.lds_a[l] = off; off += CT * (e->npad[l] + kLdPad); }
+    u.lds_e[0] = 0;
+    for (int l = 1; l < L; ++l) { u.lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
+    u.lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
+    u.lds_ws_sync = off; off += 16;
+    u.lds_eo = off;
+    if (e->has_head) off += CT * (e->out_pad + kLdPad);
+    u.lds_zero = off; off += 16;
+    u.lds_spillmax = off; off += kSpillTensors;
+    u.lds_rowexp = off; off += kRowExpFloats;
+    for (int l = 0; l < L; ++l) { u.lds_x[l] = off; off += CT * (e->npad[l] + kLdPad); }
+    for (int l = 0; l < L; ++l) { u.lds_bias[l] = off; off += l >= 1 ? e->npad[l] : CT * (e->npad[0] + kLdPad); }
+    if (e->has_head) {
+        const int ywords = (e->out_pad + 31) / 32;
+        u.lds_hbias = off; off += e->out_pad;
+        u.lds_yw = off; off += (CT * ywords + 3) / 4 * 4;
+    }
+    u.lds_bytes = off * (int)sizeof(float);
+    u.ok = u.lds_bytes <= 160 * 1024;
+    return 0;
+}
+
+// Tables of the unified-wave kernel: every wave walks its OWN rows (u.phases[w * n_phases + p]).  One step = two levels, each opened by a
+// workgroup barrier:
+//   forward:  read-out tiles (HEADF: out, loss error -> e_o), FWD_{L-1} .. FWD_1 (prediction errors E_l), FWD_0 -- they read the FX_l the
+//             previous step's x updates left and write e_o / E_l;
+//   updates:  BWD_{L-1} (GEMM over the whole e_o), BWD_{L-2} .. BWD_0 (GEMM over E_{l+1}) -- they read e_o / E_l and write X_l, FX_l.
+// Inside a level the jobs are independent, and with a barrier on either side no tile belongs to a wave: a JOB is up to four consecutive
+// unit tiles of one entry (one GEMM call + one epilogue call of a wave), and the jobs of a level are dealt to the eight waves by cost,
+// longest first (a cost model in cycles: fixed cost per row, k-blocks x (operand split + MFMAs per tile), epilogue per tile).  Why four
+// tiles where the work allows: the operand split (24 VALU instructions per k-block) and the row's fixed costs are shared by the job's
+// tiles -- a GEMM of 8 tiles as 2 jobs of 4 splits its B operand twice, as 8 jobs of 1 eight times -- and heavy entries (the read-out's
+// back-projection: K = n_out) are cut finer only as far as the level's balance needs.  (The one exception: the running sum of e_1 lives in
+// registers of wave w for tile w of the top layer -- lean_load_e0 -- so FWD_0's tiles are pinned when that layer has at most 8.)
+int build_phases_u(mcpc_engine* e) {
+    UPlan& u = e->u;
+    const int L = e->L;
+    auto tiles = [&](int l) { return e->npad[l] / 16; };
+    auto blank = [&]() { KPhase k{}; k.dep_e = -1; k.dep_g = -1; k.dep_se = -1; k.b_row = -1; k.o_row = -1; k.next_g = -1; k.rot = 1; return k; };
+    struct Job { KPhase k; double cost; int pin; };
+    // cost model (shader cycles per wave; calibrated on profiles/r06_small_net.txt).  Per k-block of a row's GEMM: 1 tile ~400, 2 tiles ~470,
+    // 4 tiles ~600 -- the B split, the fragment requests and, with one tile, three dependent MFMAs -- and ~200 less when the operand arrives
+    // in planes (`ps`: the read-out's back-projection; the table is built before the loss is known and assumes the Bernoulli read-out the
+    // reference trains with); ~1200 before the first block; per row ~2000 for its descriptor, the next row's fragment requests and the
+    // epilogue's fixed part; per tile of an epilogue: read-out ~1000, x update with the Philox kick ~1300, prediction error ~500.
+    auto gemm_cost = [](int nt, int nkb, bool ps) { return nkb > 0 ? 1200.0 + nkb * ((ps ? 130.0 : 330.0) + 68.0 * nt) : 0.0; };
+    const double row_cost = 2000.0;
+    auto make_jobs = [&](const KPhase& proto, int nt_total, double epi_tile, int g, std::vector<Job>& out, bool pinned, bool ps) {
+        if (pinned) g = 1;
+        for (int t = 0; t < nt_total; t += g) {
+            Job j; j.k = proto; j.k.tile0 = t; j.k.ntiles = std::min(g, nt_total - t); j.k.rot = 1;
+            if (proto.type == PH_HEADF) j.k.out_lds = proto.out_lds + 16 * t;       // (the epilogue writes columns relative to its row's first tile)
+            j.cost = row_cost + gemm_cost(j.k.ntiles, (proto.flags & PHF_WS_GEMM) ? proto.nkb : 0, ps) + j.k.ntiles * epi_tile;
+            j.pin = pinned ? t : -1;
+            out.push_back(j);
+        }
+    };
+    struct Entry { KPhase k; int ntiles; double epi_tile; bool pinned; bool ps; };
+    std::vector<Entry> level[2];
+    if (e->has_head) {
+        KPhase f = blank();
+        f.type = PH_HEADF; f.layer = L - 1;
+        f.A = e->lin[L].Wf; f.a_lin = L; f.kw = 16 * tiles(L - 1); f.nkb = kblocks(f.kw); f.a_tile_stride = f.nkb * kFragBlock;
+        f.b_lds = u.lds_a[L - 1]; f.ldb = e->npad[L - 1] + kLdPad;
+        f.out_lds = u.lds_eo; f.out_ld = e->out_pad + kLdPad;            // (row-relative columns: the epilogue adds 16 (tile - tile0) to its row's base)
+        f.b_row = rowexp_fx(L - 1); f.o_row = rowexp_ring(0);
+        f.flags = PHF_WS_GEMM | PHF_WS_EPI;
+        level[0].push_back({f, e->out_pad / 16, 1000.0, false, false});
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        KPhase k = blank();
+        k.type = PH_FWD; k.layer = l;
+        if (l == 0) {
+            k.flags = PHF_MU1 | PHF_WS_EPI;
+        } else {
+            k.A = e->lin[l].Wf; k.a_lin = l; k.kw = 16 * tiles(l - 1); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
+            k.b_lds = u.lds_a[l - 1]; k.ldb = e->npad[l - 1] + kLdPad;
+            k.out_lds = u.lds_e[l]; k.out_ld = e->npad[l] + kLdPad;
+            k.b_row = rowexp_fx(l - 1); k.o_row = rowexp_e(l);
+            k.flags = PHF_WS_GEMM | PHF_WS_EPI;
+        }
+        level[0].push_back({k, tiles(l), 500.0, l == 0 && tiles(0) <= kUWaves, false});
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        KPhase k = blank();
+        k.type = PH_BWD; k.layer = l;
+        k.out_lds = u.lds_a[l]; k.out_ld = e->npad[l] + kLdPad; k.o_row = rowexp_fx(l);
+        k.flags = PHF_WS_EPI;
+        if (l == L - 1) {
+            k.sign = e->has_head ? 1.0f : 0.0f;
+            if (e->has_head) {
+                k.A = e->lin[L].Wb; k.a_lin = L; k.kw = e->out_pad; k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
+                k.b_lds = u.lds_eo; k.ldb = e->out_pad + kLdPad; k.b_row = rowexp_ring(0);
+                k.flags |= PHF_WS_GEMM;
+            }
+        } else {
+            k.A = e->lin[l + 1].Wb; k.a_lin = l + 1; k.kw = 16 * tiles(l + 1); k.nkb = kblocks(k.kw); k.a_tile_stride = k.nkb * kFragBlock;
+            k.b_lds = u.lds_e[l + 1]; k.ldb = e->npad[l + 1] + kLdPad; k.b_row = rowexp_e(l + 1); k.sign = -1.0f;
+            k.flags |= PHF_WS_GEMM;
+        }
+        level[1].push_back({k, tiles(l), 1300.0, false, l == L - 1 && e->has_head && e->out_pad > kShortK * kKB});
+    }
+    std::vector<KPhase> rows[kUWaves];
+    for (int lv = 0; lv < 2; ++lv) {
+        // the grain of every entry (4, 2 or 1 tiles per job) by exhaustive search: the combination whose longest-first deal has the
+        // shortest makespan (at most 7 entries per level: 3^7 deals of a few dozen jobs)
+        const int ne = (int)level[lv].size();
+        std::vector<int> grain(ne, 4), best_grain(ne, 4);
+        double best_span = 1e300;
+        std::vector<Job> jobs;
+        auto deal = [&](const std::vector<int>& gr, std::vector<KPhase>* mine) {
+            jobs.clear();
+            for (int i = 0; i < ne; ++i) make_jobs(level[lv][i].k, level[lv][i].ntiles, level[lv][i].epi_tile, gr[i], jobs, level[lv][i].pinned, level[lv][i].ps);
+            std::stable_sort(jobs.begin(), jobs.end(), [](const Job& a, const Job& b) { return (a.pin >= 0) != (b.pin >= 0) ? a.pin >= 0 : a.cost > b.cost; });
+            double load[kUWaves] = {0};
+            for (auto& j : jobs) {
+                int w = 0;
+                if (j.pin >= 0) w = j.pin;
+                else for (int i = 1; i < kUWaves; ++i) if (load[i] < load[w]) w = i;
+                load[w] += j.cost;
+                if (mine) mine[w].push_back(j.k);
+            }
+            double span = 0, sum = 0;
+            for (double v : load) { span = std::max(span, v); sum += v; }
+            return span + 1e-3 * sum;               // (ties: the deal with less work in total)
+        };
+        int combos = 1;
+        for (int i = 0; i < ne; ++i) combos *= 3;
+        for (int cidx = 0; cidx < combos; ++cidx) {
+            int c = cidx;
+            for (int i = 0; i < ne; ++i) { grain[i] = 4 >> (c % 3); c /= 3; }
+            const double span = deal(grain, nullptr);
+            if (span < best_span) { best_span = span; best_grain = grain; }
+        }
+        std::vector<KPhase> mine[kUWaves];
+        (void)deal(best_grain, mine);
+        for (int w = 0; w < kUWaves; ++w) {
+            if (mine[w].empty()) { KPhase k = blank(); k.type = PH_NOP; mine[w].push_back(k); }
+            mine[w][0].flags |= PHF_SYNC;                        // the level's barrier
+            rows[w].insert(rows[w].end(), mine[w].begin(), mine[w].end());
+        }
+    }
+    // the four fragment slots a row's GEMM starts from (u_prefetch), resolved here: offsets in 16-byte units from the row's A, -1 = none.
+    // (dep_e, dep_g, dep_se, next_g carry them: the unified-wave kernel has no other use for those fields)
+    for (int w = 0; w < kUWaves; ++w)
+        for (auto& k : rows[w]) {
+            int slot[4] = {-1, -1, -1, -1};
+            const int nt = std::min(k.ntiles, kUNT);
+            if (nt > 0 && (k.flags & PHF_WS_GEMM) && k.nkb > 0)
+                for (int sl = 0; sl < 4; ++sl) {
+                    const bool deep = nt <= 2;
+                    const int ti = deep ? (nt == 2 ? (sl & 1) : 0) : sl, kb = deep ? (nt == 2 ? (sl >> 1) : sl) : 0;
+                    if (ti < nt && kb < k.nkb) slot[sl] = (k.tile0 + k.rot * ti) * k.a_tile_stride + k.a_off0 + kb * kFragBlock;
+                }
+            k.dep_e = slot[0]; k.dep_g = slot[1]; k.dep_se = slot[2]; k.next_g = slot[3];
+        }
+    size_t R = 0;
+    for (int w = 0; w < kUWaves; ++w) R = std::max(R, rows[w].size());
+    std::vector<KPhase> ph;
+    for (int w = 0; w < kUWaves; ++w) {
+        while (rows[w].size() < R) { KPhase k = blank(); k.type = PH_NOP; rows[w].push_back(k); }
+        ph.insert(ph.end(), rows[w].begin(), rows[w].end());
+    }
+    int rc = dmalloc(u.phases, ph.size());
+    if (rc) return rc;
+    if (hipMemcpy(u.phases, ph.data(), ph.size() * sizeof(KPhase), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(MCPC_EHIP, "hipMemcpy of the phase table failed");
+    u.n_phases = (int)R;
+#ifdef MCPC_STAMPS
+    {
+        static const char* tn[6] = {"FWD", "HEADF", "HEADB", "BWD", "ENERGY", "NOP"};
+        for (int w = 0; w < kUWaves; ++w) {
+            fprintf(stderr, "[u-table] wave %d:", w);
+            for (size_t i = 0; i < R; ++i) {
+                const KPhase& k = rows[w][i];
+                fprintf(stderr, " %s%s(l%d t%d+%d kb%d)", (k.flags & PHF_SYNC) ? "|" : "", tn[k.type], k.layer, k.tile0, k.ntiles, (k.flags & PHF_WS_GEMM) ? k.nkb : 0);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
+    return 0;
+}
+
+// The automatic choice between the in-place and the unified-wave kernel for an engine whose unified plan fits (tuning ws=2 / ws=3 force
+// either): see DESIGN section 4 for the measurement behind it.
+bool choose_unified(const mcpc_engine* e) {
+    (void)e;
+    return true;
+}
+
 // The per-step schedule: every GEMM of a Langevin step with its operands, the epilogue that follows
 // it and the barrier it needs.  Output tiles are handed out 16 at a time (4 waves x kNT tiles).
 int build_phases(mcpc_engine* e) {
@@ -689,6 +903,7 @@ int setup_rounds(mcpc_engine* e, int n_cu) {
     if (hipFuncSetAttribute((const void*)mcpc_steps_ws2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->lds_bytes) != hipSuccess)
         return fail(MCPC_EHIP, "hipFuncSetAttribute failed for the round schedule");
     e->rr_k = k; e->rr_m = m; e->rr = true;
+    e->u_rr_name = "mcpc::mcpc_steps_u_kernel<true> (round schedule: k=" + std::to_string(k) + " launches per cycle, every 16-chain unit in m=" + std::to_string(m) + " of them)";
     e->rr_name = "mcpc::mcpc_steps_ws2_kernel<1, true> (round schedule: k=" + std::to_string(k) + " launches per cycle, every 16-chain unit in m=" + std::to_string(m) + " of them)";
     return 0;
 }
@@ -828,6 +1043,13 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     }
 
     if ((rc = e->ws == 2 ? build_phases_ws2(e) : build_phases(e))) return bail(rc);
+    // the unified-wave kernel beside the in-place kernel, where its plan fits (mcpc_steps_u.h)
+    if (e->ws == 2 && (kn.ws == -1 || kn.ws == 3) && !kn.no_lean && !kn.no_xl) {
+        (void)plan_lds_u(e);
+        e->u.on = e->u.ok && (kn.ws == 3 || choose_unified(e));
+        if (e->u.on && (rc = build_phases_u(e))) return bail(rc);
+    }
+    if (kn.ws == 3 && !e->u.on) return bail(fail(MCPC_ENOMEM, "tuning ws=3: the unified-wave kernel's LDS plan does not fit this network (%d bytes)", e->u.lds_bytes));
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
     if (hipMemset(e->err, 0, sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
     if ((rc = dmalloc(e->spillmax, (size_t)kMaxRingParts * kSpillTensors))) return bail(rc);
@@ -843,6 +1065,11 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     if (herr != hipSuccess) return bail(fail(MCPC_EHIP, "hipFuncSetAttribute(%d bytes LDS) failed: %s", e->lds_bytes, hipGetErrorString(herr)));
     if (e->ws == 2 && e->nwg_live > n_cu && kn.rr) {
         if ((rc = setup_rounds(e, n_cu))) return bail(rc);
+    }
+    if (e->u.on) {
+        if (hipFuncSetAttribute((const void*)mcpc_steps_u_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, e->u.lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mcpc_steps_u_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->u.lds_bytes) != hipSuccess)
+            return bail(fail(MCPC_EHIP, "hipFuncSetAttribute failed for the unified-wave kernel (%d bytes LDS)", e->u.lds_bytes));
     }
     *out = e;
     return MCPC_OK;
@@ -1383,6 +1610,22 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
     if (!e->dbg) { int rc = dmalloc(e->dbg, (size_t)e->nwg * 2 * kMaxWaves * 16); if (rc) return rc; }
     P.dbg = e->dbg;
 #endif
+    // The unified-wave kernel (mcpc_steps_u.h) serves the lean runs of an engine that holds its plan: fused SGD update with or without
+    // the Philox kick, Adam without noise.  Everything else -- gradients-only runs, injected noise -- keeps the main plan's kernel.
+    bool use_u = e->u.on && e->ws == 2 && r->update_x && P.lean_ok &&
+                 ((r->xopt_kind == MCPC_XOPT_SGD && r->noise_mode != MCPC_NOISE_EXTERNAL) ||
+                  (r->xopt_kind == MCPC_XOPT_ADAM && r->noise_mode == MCPC_NOISE_NONE));
+    if (use_u) {
+        const UPlan& u = e->u;
+        for (int l = 0; l < e->L; ++l) {
+            KLayer& K = P.layer[l];
+            K.lds_a = u.lds_a[l]; K.lds_e = u.lds_e[l]; K.lds_x = u.lds_x[l]; K.lds_bias = u.lds_bias[l];
+        }
+        if (e->has_head) { P.head.lds_eo = u.lds_eo; P.head.ld = e->out_pad + kLdPad; P.head.lds_bias = u.lds_hbias; P.head.lds_yw = u.lds_yw; }
+        P.phases = u.phases; P.n_phases = u.n_phases; P.g_first = 0;
+        P.lds_spillmax = u.lds_spillmax; P.lds_rowexp = u.lds_rowexp; P.lds_red = u.lds_red; P.lds_ws_sync = u.lds_ws_sync;
+        P.lds_floats = u.lds_bytes / 4; P.lds_zero = u.lds_zero; P.xl = 1;
+    }
 
     // ---- step segments: non-accumulating stretches run as one persistent launch; accumulating
     //      stretches are cut at the spill ring's capacity and followed by a Hebbian flush ----------
@@ -1429,7 +1672,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         for (int i = 0; i < e->rr_k; ++i) {
             Q.wg_list = e->rr_tab + e->rr_off[i]; Q.wg_rel = Q.wg_list + e->rr_count[i];
             { const int rc = prof_begin(); if (rc) return rc; }
-            hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1, true>), dim3(e->rr_count[i]), dim3(kWs2Threads), e->lds_bytes, stream, Q);
+            if (use_u) hipLaunchKernelGGL((mcpc_steps_u_kernel<true>), dim3(e->rr_count[i]), dim3(kUThreads), e->u.lds_bytes, stream, Q);
+            else hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1, true>), dim3(e->rr_count[i]), dim3(kWs2Threads), e->lds_bytes, stream, Q);
             { const int rc = prof_end((double)q * e->rr_count[i] / e->nwg_live); if (rc) return rc; }
         }
         HIP_TRY(hipGetLastError());
@@ -1486,7 +1730,8 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             if (rc) return rc;
         } else {
         { const int rc = prof_begin(); if (rc) return rc; }
-        if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1>), dim3(e->nwg_live), dim3(kWs2Threads), e->lds_bytes, stream, P);
+        if (use_u) hipLaunchKernelGGL((mcpc_steps_u_kernel<false>), dim3(e->nwg_live), dim3(kUThreads), e->u.lds_bytes, stream, P);
+        else if (e->ws == 2) hipLaunchKernelGGL((mcpc_steps_ws2_kernel<1>), dim3(e->nwg_live), dim3(kWs2Threads), e->lds_bytes, stream, P);
         else hipLaunchKernelGGL((mcpc_steps_kernel<1, 4>), dim3(e->nwg), dim3(256), e->lds_bytes, stream, P);
         { const int rc = prof_end((double)n); if (rc) return rc; }
         }
@@ -1530,14 +1775,15 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             double tot = 0, sum[16] = {0}, mx[16] = {0};
             for (size_t w = 0; w < (size_t)e->nwg * e->nw; ++w)
                 for (int i = 0; i < 16; ++i) { sum[i] += (double)h[w * 16 + i]; mx[i] = std::max(mx[i], (double)h[w * 16 + i]); }
-            if (e->ws == 2) {
+            static const char* names_u[16] = {"top of entry", "barrier", "gemm", "prefetch next", "epilogue", "-", "-", "presplit", "gemm fwd nt=1", "gemm fwd nt=2", "gemm fwd nt=3", "gemm fwd nt=4", "gemm bwd nt=1", "gemm bwd nt=2", "gemm bwd nt=3", "gemm bwd nt=4"};
+            if (e->ws == 2 && !use_u) {
                 fprintf(stderr, "[stamps] shader clock during the launch = %.3f GHz (s_memtime ticks per 100 MHz wall-clock tick)\n", sum[6] / sum[7] * 0.1);
                 sum[6] = sum[7] = 0;
             }
             for (int i = 0; i < 16; ++i) tot += sum[i];
             fprintf(stderr, "[stamps] launch t0=%d n=%d: mean cycles/step/wave = %.0f\n", t, n, tot / (e->nwg * e->nw) / n);
             for (int i = 0; i < 16; ++i)
-                fprintf(stderr, "[stamps]   %-18s %5.1f%%  mean %8.0f  max %8.0f cycles/step\n", (e->ws == 2 ? names_ws2 : names)[i], 100.0 * sum[i] / tot,
+                fprintf(stderr, "[stamps]   %-18s %5.1f%%  mean %8.0f  max %8.0f cycles/step\n", (use_u ? names_u : e->ws == 2 ? names_ws2 : names)[i], 100.0 * sum[i] / tot,
                         sum[i] / (e->nwg * e->nw) / n, mx[i] / n);
 #endif
         }
@@ -1691,6 +1937,8 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
 
 const char* mcpc_step_kernel_name(const mcpc_engine* e) {
     if (!e) return "";
+    // (an engine that holds the unified-wave kernel's plan runs its fused calls -- what a benchmark times -- on that kernel)
+    if (e->u.on) return e->rr ? e->u_rr_name.c_str() : "mcpc::mcpc_steps_u_kernel<false>";
     if (e->rr) return e->rr_name.c_str();
     if (e->ws == 2) return "mcpc::mcpc_steps_ws2_kernel<1, false>";
     return "mcpc::mcpc_steps_kernel<1, 4>";

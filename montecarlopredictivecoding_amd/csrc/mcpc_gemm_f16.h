@@ -70,6 +70,14 @@ __device__ __forceinline__ frag_t split8(f32x4 x0, f32x4 x1, float s) {
     f.h = u32x4{h[0], h[1], h[2], h[3]}; f.m = u32x4{m[0], m[1], m[2], m[3]};
     return f;
 }
+// the B planes of one k-block as a lane reads them: split here from fp32 (x 2^sb = h + m), or -- PS, unified-wave kernel -- already split by
+// the operand's producer (mcpc_ws2_lean.h: lean_headf writes a Bernoulli read-out's error that way: the same split2_pair with the same
+// exponent, once per value instead of once per k-block, wave and GEMM): the 32 bytes then hold [h0..h7][m0..m7]
+template <bool PS>
+__device__ __forceinline__ frag_t b_planes(f32x4 x0, f32x4 x1, float s) {
+    if constexpr (PS) { frag_t f; f.h = __builtin_bit_cast(u32x4, x0); f.m = __builtin_bit_cast(u32x4, x1); (void)s; return f; }
+    else return split8(x0, x1, s);
+}
 __device__ __forceinline__ f32x4 mfma4(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
@@ -117,7 +125,7 @@ struct GemmScale { int a_exp; int mode; int fixed_b; int run; int short_k; int s
 #ifdef MCPC_EXP_NOSPLIT    // timing experiment only (wrong results): the B planes of block 0 serve every block (no LDS reads, no split)
 #define MCPC_EXP_SPLIT8(a_, b_) bs[0]
 #else
-#define MCPC_EXP_SPLIT8(a_, b_) split8(a_, b_, bscale)
+#define MCPC_EXP_SPLIT8(a_, b_) b_planes<PS>(a_, b_, bscale)
 #endif
 // acc += W-tiles . B over nkb blocks.  On entry `pre` holds block 0 of every tile, requested by the caller's prefetch (one table
 // entry early); on return it is free.
@@ -134,7 +142,7 @@ struct GemmScale { int a_exp; int mode; int fixed_b; int run; int short_k; int s
 // 2.6e-8 with it; fp32 MFMA chain 1.0e-7 / 2.1e-8).  From K = 96 on the term changes neither figure (profiles/r05_f16x4_study.txt) and longer
 // GEMMs run THREE MFMAs per product.
 constexpr int kShortK = 2;
-template <int NT, int NTT, int CTT, int NW, bool MM>
+template <int NT, int NTT, int CTT, int NW, bool MM, bool PS = false>
 __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nkb, int kw,
                                            const float* B, int ldb, int lane, frag_t (&pre)[NTT], const float* zeros, int b_exp) {
     static_assert(CTT == 1, "one chain tile per workgroup (two were measured and dropped in rounds 4 and 5: DESIGN.md section 4)");
@@ -186,7 +194,7 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
     do { if constexpr (MM) { MCPC_M4(s_, G_, ct_, m, m); }                                           \
          MCPC_M4(s_, G_, ct_, m, h); MCPC_M4(s_, G_, ct_, h, m); MCPC_M4(s_, G_, ct_, h, h); } while (0)
 #endif
-#define MCPC_SPLIT1(ct_) bs[ct_] = split8(bC[ct_][0], bC[ct_][1], bscale)
+#define MCPC_SPLIT1(ct_) bs[ct_] = b_planes<PS>(bC[ct_][0], bC[ct_][1], bscale)
     // One k-block: the chain tile's planes are read by both sub-steps, so the next block's split goes into a second copy beside
     // (k, G1) and is moved over at the end of the block (8 v_mov)
 #define MCPC_BLOCK1(sa_, sb_, sc_, k_)                                                              \
@@ -251,6 +259,91 @@ __device__ __forceinline__ void gemm_fixed(f32x4 (&acc)[NTT][CTT], const gu32x4*
 #undef MCPC_M4
 #undef MCPC_LOAD_HALF
 #undef MCPC_LOAD_B
+}
+
+// ---- few tiles per wave: a deeper fragment stream (unified-wave kernel, mcpc_steps_u.h) --------------------------------------------------
+// With one or two tiles per wave the rotation above keeps 2 or 4 KiB of fragments in flight per wave -- one k-block ahead of 3 or 6 MFMAs
+// (48 / 96 cycles) -- and every k-block waits out an L2 round trip: ~750 cycles per block in the unified-wave kernel's 1-tile GEMMs
+// (profiles/r06_small_net.txt).  This form keeps W = 4 / NT k-blocks of the wave's NT tiles in flight (the same four fragment slots the
+// caller's prefetch fills, one table entry early: slot j NT + i = block j of tile i): GEMMs of at most W blocks find ALL their fragments in
+// registers, longer ones refill a slot as soon as its MFMAs are issued.  Per accumulator the MFMAs are those of gemm_fixed, in its order
+// ([a_m b_m,] a_m b_h, a_h b_m, a_h b_h per block, blocks ascending): bitwise the same sums.
+template <int NT, int NTT, bool MM, bool PS = false>
+__device__ __forceinline__ void gemm_deep(f32x4 (&acc)[NTT][1], const gu32x4* __restrict__ A, const int (&aoff)[NTT], int nkb, int kw,
+                                          const float* B, int ldb, int lane, frag_t (&pre)[NTT], const float* zeros, int b_exp) {
+    static_assert(NT == 1 || NT == 2, "one or two tiles");
+    static_assert(NTT == 4, "four fragment slots");
+    constexpr int W = 4 / NT;                                     // k-blocks in flight
+    if (nkb <= 0) return;
+    const int c = lane & 15, g = lane >> 4;
+    const float* bp = B + c * ldb + 8 * g;
+    const float* const bp_last = (uint32_t)(kKB * (nkb - 1) + 8 * g) < (uint32_t)kw ? bp + (nkb - 1) * kKB : zeros;
+    uint32_t voff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) voff[t] = (uint32_t)(aoff[t] + lane) * 16u;
+    const char __attribute__((address_space(1)))* const Ab = (const char __attribute__((address_space(1)))*)A;
+    const int last = nkb - 1;
+    frag_t f[W][NT];
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) f[j][i] = pre[j * NT + i];
+    f32x4 b0, b1;
+    frag_t bs;
+#define MCPC_DLOAD_B(k_)                                                                            \
+    do {                                                                                            \
+        const float* const src_ = (k_) < last ? bp + (k_) * kKB : bp_last;                          \
+        b0 = *reinterpret_cast<const f32x4*>(src_);                                                 \
+        b1 = *reinterpret_cast<const f32x4*>(src_ + 4);                                             \
+    } while (0)
+#define MCPC_DM(j_, ap_, bp_)                                                                       \
+    _Pragma("unroll") for (int i = 0; i < NT; ++i) acc[i][0] = mfma4(f[j_][i].ap_, bs.bp_, acc[i][0])
+#define MCPC_DSUB(j_)                                                                               \
+    do { if constexpr (MM) { MCPC_DM(j_, m, m); }                                                   \
+         MCPC_DM(j_, m, h); MCPC_DM(j_, h, m); MCPC_DM(j_, h, h); } while (0)
+#define MCPC_DREFILL(j_, k_)                                                                        \
+    do {                                                                                            \
+        const char __attribute__((address_space(1)))* const Ak_ = Ab + (size_t)MCPC_KSEL(k_) * (kFragBlock * 16u); \
+        _Pragma("unroll") for (int i = 0; i < NT; ++i) {                                            \
+            f[j_][i].h = *(const gu32x4*)(Ak_ + voff[i]);                                           \
+            f[j_][i].m = *(const gu32x4*)(Ak_ + voff[i] + 1024u);                                   \
+        }                                                                                           \
+    } while (0)
+    MCPC_DLOAD_B(0);
+    const float bscale = pow2i(b_exp);
+    bs = b_planes<PS>(b0, b1, bscale);
+    MCPC_DLOAD_B(1);
+    int k = 0;
+    // steady state: W blocks per round, every slot refilled with the block W ahead
+    for (; k + 2 * W <= nkb; k += W) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+            MCPC_DSUB(j);
+            MCPC_DREFILL(j, k + j + W);
+            const frag_t bsn = b_planes<PS>(b0, b1, bscale);       // block k + j + 1
+            MCPC_DLOAD_B(k + j + 2);
+            bs = bsn;
+        }
+    }
+    // tail: the up to 2 W - 1 blocks left; refills while a block W ahead exists
+#pragma unroll
+    for (int j = 0; j < 2 * W - 1; ++j) {
+        if (k + j < nkb) {
+            __builtin_amdgcn_sched_barrier(0);
+            MCPC_DSUB(j % W);
+            if (k + j + W < nkb) MCPC_DREFILL(j % W, k + j + W);
+            if (k + j + 1 < nkb) {
+                const frag_t bsn = b_planes<PS>(b0, b1, bscale);
+                MCPC_DLOAD_B(k + j + 2);
+                bs = bsn;
+            }
+        }
+    }
+#undef MCPC_DREFILL
+#undef MCPC_DSUB
+#undef MCPC_DM
+#undef MCPC_DLOAD_B
 }
 
 // Exponent for this lane's chain row of the B operand: 2^sb brings the row's largest |value| into [2^14, 2^15).  Lane (c, g) scans the
@@ -326,6 +419,36 @@ __device__ __forceinline__ void gemm_tiles(f32x4 (&acc)[NTT][CTT], const void* A
     if (mm && nkb <= kShortK) gemm_dispatch<1, NTT, CTT, NW, true>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, b_exp);
     else gemm_dispatch<1, NTT, CTT, NW, false>(acc, (const gu32x4*)A, aoff, nt, nkb, kw, B, ldb, lane, pre0, zeros, b_exp);
     if (gs.mode == GS_FRESH) gemm_unscale<NTT, CTT>(acc, gs.a_exp, b_exp);
+}
+
+// GEMM of the unified-wave kernel: fresh accumulators, the row's exponent from its producers' word (or a constant), un-scaled on return;
+// one or two tiles on the deep fragment stream (gemm_deep: `pre` = four (block, tile) slots), three or four on the rotation of gemm_fixed
+// (`pre` = block 0 of every tile).  ps (wave-uniform): the B operand is already in planes (the Bernoulli read-out's error: headf_planes).
+template <int NTT>
+__device__ __forceinline__ void gemm_tiles_u(f32x4 (&acc)[NTT][1], const void* A, const int (&aoff)[NTT], int nt, int nkb, int kw,
+                                             const float* B, int ldb, int lane, frag_t (&pre)[NTT], const float* zeros, int a_exp, int b_exp,
+                                             int short_k, bool ps) {
+    const bool mm = (short_k >= 0 ? short_k != 0 : nkb <= kShortK) && nkb <= kShortK;
+    const gu32x4* const Ag = (const gu32x4*)A;
+    if (ps) {                       // (long contractions only: never with the fourth product)
+        if (nt == 1) gemm_deep<1, NTT, false, true>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+        else if (nt == 2) gemm_deep<2, NTT, false, true>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+        else if (nt == 3) gemm_fixed<3, NTT, 1, 8, false, true>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+        else gemm_fixed<4, NTT, 1, 8, false, true>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+    } else if (nt == 1) {
+        if (mm) gemm_deep<1, NTT, true>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+        else gemm_deep<1, NTT, false>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+    } else if (nt == 2) {
+        if (mm) gemm_deep<2, NTT, true>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+        else gemm_deep<2, NTT, false>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+    } else if (nt == 3) {
+        if (mm) gemm_fixed<3, NTT, 1, 8, true>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+        else gemm_fixed<3, NTT, 1, 8, false>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+    } else {
+        if (mm) gemm_fixed<4, NTT, 1, 8, true>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+        else gemm_fixed<4, NTT, 1, 8, false>(acc, Ag, aoff, nkb, kw, B, ldb, lane, pre, zeros, b_exp);
+    }
+    gemm_unscale<NTT, 1>(acc, a_exp, b_exp);
 }
 
 // request the fragments of k-block 0 of a phase's GEMM (issued one phase early: weights do not depend on any barrier)

@@ -69,7 +69,7 @@ struct KHead {
 
 // One entry of the per-step phase table (built on the host, identical for every step):
 //   [prologue loads] -> acc = (from accb | 0) -> GEMM over nkb k-blocks -> [acc -> accb] -> epilogue -> [barrier]
-enum : int { PH_FWD = 0, PH_HEADF = 1, PH_HEADB = 2, PH_BWD = 3, PH_ENERGY = 4 };
+enum : int { PH_FWD = 0, PH_HEADF = 1, PH_HEADB = 2, PH_BWD = 3, PH_ENERGY = 4, PH_NOP = 5 };   // (PH_NOP: unified-wave kernel, a row without work)
 enum : int { PHF_ACC_FROM_B = 1, PHF_ACC_TO_B = 2, PHF_SYNC = 4, PHF_MU1 = 8 };
 struct KPhase {
     const void* A;         // packed weight fragments of this GEMM (unused when nkb == 0): layout of the GEMM core in use
@@ -87,7 +87,8 @@ struct KPhase {
     int dep_e, dep_g;      // wave-specialised kernels: entry whose completion by all E / all G waves must precede (-1: none;
                            // in-place variant: an index above the entry's own refers to the previous step)
     int a_lin;             // Linear whose packed weights A points into: KParams::wexp[a_lin] is the exponent they were scaled by
-    int rot;               // in-place variant: pair k owns tiles tile0 + ((k + rot) & 3) + 4 i (balances uneven chunks)
+    int rot;               // in-place variant: pair k owns tiles tile0 + ((k + rot) & 3) + 4 i (balances uneven chunks);
+                           // unified-wave kernel: the tile stride of a wave's row -- its tiles are tile0 + rot i, i < ntiles
     int dep_se;            // in-place variant: entry all E waves must have passed before this entry's block is STORED (its
                            // LDS rows are still read by their epilogues); dep_g is waited for at the same point
     int next_g;            // in-place variant: the next entry (cyclic) in which the GEMM waves have work -- they visit no other
@@ -262,6 +263,10 @@ __device__ __forceinline__ int load_wexp(const int* wexp, int lin) {
 // B exponent of the read-out error rows: a Bernoulli read-out's sigma(o) - y is bounded by 1 for targets in [0, 1] (2 for anything BCE
 // still makes sense of) -> a FIXED exponent, independent of how the read-out is cut into chunks; anything else: from the rows themselves
 __device__ __forceinline__ int headb_fixed_exp(int loss_kind) { return loss_kind == MCPC_LOSS_BERNOULLI ? 13 : kScaleAuto; }
+// unified-wave kernel: with that constant exponent the read-out's epilogue can write the error rows already split into the fp16 planes the
+// back-projection reads -- once per value instead of once per k-block, wave and step (the long contractions only: a short one keeps its
+// fourth product and its own code path)
+__device__ __forceinline__ bool headf_planes(int loss_kind, int out_pad) { return loss_kind == MCPC_LOSS_BERNOULLI && out_pad > kShortK * kKB; }
 
 // ---- row exponents kept by the producers (in-place kernel, lean epilogues) ------------------------------------------------------------
 // The GEMM core scales every chain row of its LDS operand by a power of two taken from the row's largest |value| (mcpc_gemm_f16.h).
@@ -1034,4 +1039,5 @@ __global__ void mcpc_philox_kernel(uint64_t seed, uint64_t step, int layer, uint
 #include "mcpc_steps_ws.h"
 #include "mcpc_ws2_lean.h"
 #include "mcpc_steps_ws2.h"
+#include "mcpc_steps_u.h"
 #include "mcpc_hebbian.h"

@@ -100,11 +100,15 @@ template <int ACT> __device__ __forceinline__ f32x4 act4(f32x4 x) {
 // e0acc: Linear 0 sees a constant input, so only sum_t e_1 is needed for its Hebbian sums; when the top layer has at most
 // one tile per wave (n_1 <= 64) the running sum is held in registers for the whole launch (lean_load_e0 / lean_flush_e0)
 // instead of a global read-modify-write in every step.
-template <int CTT, int NW, int NTW, int ACT, bool XL = false>
+// REG (unified-wave kernel, mcpc_steps_u.h): the wave computed the block itself -- it arrives in registers (racc[i][ct], zeros when the entry has
+// no GEMM), nothing is waited for and nothing is read from out_lds.
+template <int CTT, int NW, int NTW, int ACT, bool XL = false, bool REG = false>
 __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
                                           int slot, int rec_idx, const int* prog_g, int need, int* err, int& dead,
-                                          f32x4 (&e0acc)[CTT], bool e0_in_regs, float* rx = nullptr, unsigned row_gen = 0u) {
+                                          f32x4 (&e0acc)[CTT], bool e0_in_regs, float* rx = nullptr, unsigned row_gen = 0u,
+                                          const f32x4 (*racc)[CTT] = nullptr) {
     if (nt <= 0) return 0.f;                  // (a layer with fewer tiles than waves: nothing to load, nothing to wait for)
+    const int tstep = REG ? ph.rot : NW;      // tile(i) = tile0 + kk + tstep i: the unified-wave kernel's rows carry their own stride (kk = 0)
     const KLayer& Ly = P.layer[ph.layer];
     const int l = ph.layer;
     const bool has_gemm = (ph.flags & PHF_WS_GEMM) && ph.nkb > 0;
@@ -120,7 +124,7 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
     const float* const bsrc = l == 0 ? P.mu1 : Ly.bias;                  // mu1: a row per chain; bias: one row
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));     // unused slots repeat slot 0
+        const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + tstep * (i < nt ? i : 0));     // unused slots repeat slot 0
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
             if constexpr (XL) {
@@ -142,12 +146,18 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
         }
     }
     f32x4 av[NTW][CTT];
-    if (has_gemm) {
+    if constexpr (REG) {
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int ct = 0; ct < CTT; ++ct) av[i][ct] = racc[i][ct];
+        (void)has_gemm; (void)prog_g; (void)need; (void)err; (void)dead; (void)orowb;
+    } else if (has_gemm) {
         ws_wait_one(prog_g, need, err, dead);
         const char* const src = reinterpret_cast<const char*>(lds + ph.out_lds);
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
-            const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));
+            const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + tstep * (i < nt ? i : 0));
 #pragma unroll
             for (int ct = 0; ct < CTT; ++ct) av[i][ct] = *reinterpret_cast<const f32x4*>(src + orowb[ct] + tb);
         }
@@ -170,7 +180,7 @@ __device__ __forceinline__ float lean_fwd(const KParams& P, const KPhase& ph, fl
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         if (i >= nt) continue;
-        const int tile = ph.tile0 + kk + NW * i;
+        const int tile = ph.tile0 + kk + tstep * i;
         const uint32_t tb = 64u * (uint32_t)tile;
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
@@ -250,12 +260,13 @@ __device__ __forceinline__ void lean_store_x(const KParams& P, const float* lds,
 // in front of the wait for the partner's block -- the generic epilogue loads them behind it, one L2/HBM round trip exposed
 // per x update -- and the arithmetic is the generic epilogue's, operation for operation (s_tab: row of the bias-correction
 // table).
-template <int CTT, int NW, int NTW, int ACT, bool NOISE, bool ADAM = false, bool XL = false>
+template <int CTT, int NW, int NTW, int ACT, bool NOISE, bool ADAM = false, bool XL = false, bool REG = false>
 __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
                                          int t, const int* prog_g, int need, int* err, int& dead, int s_tab = 0, float* rx = nullptr,
-                                         unsigned row_gen = 0u) {
+                                         unsigned row_gen = 0u, const f32x4 (*racc)[CTT] = nullptr) {
     static_assert(!(NOISE && ADAM), "Adam with the fused kick takes the generic epilogue");
     if (nt <= 0) return;
+    const int tstep = REG ? ph.rot : NW;
     const KLayer& Ly = P.layer[ph.layer];
     const int l = ph.layer, n = Ly.n;
     const bool from_g = ((ph.flags & PHF_WS_GEMM) && ph.nkb > 0) || (ph.flags & PHF_WS2_HANDOFF);
@@ -273,7 +284,7 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
     const char* const e_lds = reinterpret_cast<const char*>(lds + Ly.lds_e);
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));
+        const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + tstep * (i < nt ? i : 0));
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
             if constexpr (XL) {
@@ -287,7 +298,7 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
             }
             if constexpr (ADAM) {
                 // (moments are kept tile-major: one contiguous KiB per wave access, tile_major_offset in mcpc_kernels.h)
-                const uint32_t mb = (mul24(L.chain[ct] >> 4, (uint32_t)Ly.ntiles) + (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0))) * 1024u + 16u * (uint32_t)(L.c + 16 * L.q);
+                const uint32_t mb = (mul24(L.chain[ct] >> 4, (uint32_t)Ly.ntiles) + (uint32_t)(ph.tile0 + kk + tstep * (i < nt ? i : 0))) * 1024u + 16u * (uint32_t)(L.c + 16 * L.q);
                 mv[i][ct] = gld4s(Ly.m, mb);
                 vv[i][ct] = gld4s(Ly.v, mb);
             }
@@ -303,12 +314,18 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
         }
     }
     f32x4 av[NTW][CTT];
-    if (from_g) {
+    if constexpr (REG) {       // (unified-wave kernel: the back-projection arrives in registers, zeros when there is none)
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int ct = 0; ct < CTT; ++ct) av[i][ct] = racc[i][ct];
+        (void)from_g; (void)prog_g; (void)need; (void)err; (void)dead; (void)orowb;
+    } else if (from_g) {
         ws_wait_one(prog_g, need, err, dead);
         const char* const src = reinterpret_cast<const char*>(lds + ph.out_lds);
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
-            const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + NW * (i < nt ? i : 0));
+            const uint32_t tb = 64u * (uint32_t)(ph.tile0 + kk + tstep * (i < nt ? i : 0));
 #pragma unroll
             for (int ct = 0; ct < CTT; ++ct) av[i][ct] = *reinterpret_cast<const f32x4*>(src + orowb[ct] + tb);
         }
@@ -325,7 +342,7 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         if (i >= nt) continue;
-        const int tile = ph.tile0 + kk + NW * i;
+        const int tile = ph.tile0 + kk + tstep * i;
         const uint32_t tb = 64u * (uint32_t)tile;
         const bool pad_tile = 16 * tile + 16 > n;                  // wave-uniform: only the last tile of a ragged layer
 #pragma unroll
@@ -387,12 +404,15 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
 // ---- HEADF entry (read-out chunk): out = acc + bias, e_o = dL/dout -> ring slot (LDS), loss, spills, output records -----
 // XL: bias from LDS; YB (with XL only): the target is 0/1, its words come from LDS and no fp32 target is requested -- a compile-time
 // choice, so that the 0/1 case holds no global load at all (see the note on loads under an `if` below).
-template <int CTT, int NW, int NTW, bool XL = false, bool YB = false>
+template <int CTT, int NW, int NTW, bool XL = false, bool YB = false, bool REG = false>
 __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
                                             int slot, int rec_idx, bool do_energy, const int* prog_g, int need, int* err, int& dead,
-                                            bool ybin, float* rx = nullptr) {
+                                            bool ybin, float* rx = nullptr, const f32x4 (*racc)[CTT] = nullptr, unsigned row_gen = 0u) {
     if (nt <= 0) return 0.f;
+    const int tstep = REG ? ph.rot : NW;
     const KHead& H = P.head;
+    // unified-wave kernel: a Bernoulli read-out's error goes to LDS as planes (see below; headf_planes is the GEMM side's test too)
+    const bool planes = REG && headf_planes(H.loss_kind, H.npad);
     const int kind = H.loss_kind, n = H.n, mask_start = H.mask_start;
     const uint32_t npad4 = 4u * (uint32_t)H.npad;
     uint32_t rowb[CTT], orowb[CTT];
@@ -406,7 +426,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
     const uint32_t wrow4 = 4u * (uint32_t)H.ywords;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const int tile = ph.tile0 + kk + NW * (i < nt ? i : 0);
+        const int tile = ph.tile0 + kk + tstep * (i < nt ? i : 0);
         const uint32_t tb = 64u * (uint32_t)tile;
         if constexpr (XL) {
             bv[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(lds + H.lds_bias) + 16u * L.q + tb);
@@ -443,14 +463,22 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
             }
         }
     }
-    ws_wait_one(prog_g, need, err, dead);
     char* const eo = reinterpret_cast<char*>(lds + ph.out_lds);
     f32x4 av[NTW][CTT];
+    if constexpr (REG) {
 #pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const uint32_t cb = 64u * (uint32_t)(kk + NW * (i < nt ? i : 0));               // column inside the chunk
+        for (int i = 0; i < NTW; ++i)
 #pragma unroll
-        for (int ct = 0; ct < CTT; ++ct) av[i][ct] = *reinterpret_cast<const f32x4*>(eo + orowb[ct] + cb);
+            for (int ct = 0; ct < CTT; ++ct) av[i][ct] = racc[i][ct];
+        (void)prog_g; (void)err; (void)dead;
+    } else {
+        ws_wait_one(prog_g, need, err, dead);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            const uint32_t cb = 64u * (uint32_t)(kk + tstep * (i < nt ? i : 0));               // column inside the chunk
+#pragma unroll
+            for (int ct = 0; ct < CTT; ++ct) av[i][ct] = *reinterpret_cast<const f32x4*>(eo + orowb[ct] + cb);
+        }
     }
     const float inv_var = H.inv_var;
     float* const spill = slot >= 0 ? H.spill_e + (size_t)slot * P.Bpad * H.npad : nullptr;
@@ -461,8 +489,8 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
         if (i >= nt) continue;
-        const int tile = ph.tile0 + kk + NW * i;
-        const uint32_t tb = 64u * (uint32_t)tile, cb = 64u * (uint32_t)(kk + NW * i);
+        const int tile = ph.tile0 + kk + tstep * i;
+        const uint32_t tb = 64u * (uint32_t)tile, cb = 64u * (uint32_t)(kk + tstep * i);
         const bool inside = 16 * tile >= mask_start && 16 * tile + 16 <= n;        // wave-uniform: every unit of the tile counts
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
@@ -513,7 +541,19 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                 }
                 e.x = ev[0]; e.y = ev[1]; e.z = ev[2]; e.w = ev[3];
             }
-            *reinterpret_cast<f32x4*>(eo + orowb[ct] + cb) = e;
+            if (REG && planes) {
+                // the chunk as the back-projection's GEMM reads it: per 8 units [h0..h7][m0..m7] (mcpc_gemm_f16.h: b_planes), split here, once,
+                // with the constant exponent of a bounded read-out error -- the lane's units 4 q .. 4 q + 3 of the tile are one half of a group
+                unsigned h0, m0, h1, m1;
+                const float sc = pow2i(headb_fixed_exp(MCPC_LOSS_BERNOULLI));
+                split2_pair(f32x2{e.x, e.y}, sc, h0, m0);
+                split2_pair(f32x2{e.z, e.w}, sc, h1, m1);
+                char* const gp = eo + (orowb[ct] - 16u * L.q) + cb + 32u * (uint32_t)(L.q >> 1) + 8u * (uint32_t)(L.q & 1);
+                *reinterpret_cast<uint2*>(gp) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(gp + 16) = make_uint2(m0, m1);
+            } else {
+                *reinterpret_cast<f32x4*>(eo + orowb[ct] + cb) = e;
+            }
             rmx = absmax4(rmx, e);
 #ifdef MCPC_EXP_SPILL_LINEAR
             if (slot >= 0) spill_st4(spill, (uint32_t)P.Bpad * npad4, mul24(L.chain[ct] - (uint32_t)L.c, npad4) + 1024u * (uint32_t)tile + 16u * (uint32_t)(L.c + 16 * L.q), mask4(e, L.livem[ct]), P.spill_sys != 0);
@@ -530,7 +570,8 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
     }
     if (slot >= 0) spill_track(lds + P.lds_spillmax, kSpillIdEo, omx, L.c + 16 * L.q);
     // (a ring slot is reused inside a step: its generation is the entry, `need` = entries completed so far)
-    if (CTT == 1 && rx != nullptr && ph.o_row >= 0) rowexp_track(rx, ph.o_row, L.c, rmx, (unsigned)need);
+    // (the unified-wave kernel keeps the whole e_o row in LDS: its chunks of one step combine under the step's generation)
+    if (CTT == 1 && rx != nullptr && ph.o_row >= 0) rowexp_track(rx, ph.o_row, L.c, rmx, REG ? row_gen : (unsigned)need);
     return lsum;
 }
 

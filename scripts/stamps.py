@@ -25,6 +25,6 @@ if os.environ.get("STAMPS_NET") == "ml":          # mcpc_ml's net 20-128-128-784
 eng = Engine(SIZES, [L.ACT_RELU] * 3, SIZES[0], N_OUT, B, device=dev)
 eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y); eng.load_state(xs)
 learn = len(sys.argv) > 3 and sys.argv[3] == "learn"       # learning mode: Hebbian sums over all K steps (flushes overlap)
-eng.run(K, loss_kind=L.LOSS_BERNOULLI, lr=0.03, noise_mode=L.NOISE_PHILOX, seed=1, energy_mode=L.ENERGY_ALL,
+eng.run(K, loss_kind=(L.LOSS_NONE if os.environ.get("STAMPS_LOSS") == "none" else L.LOSS_BERNOULLI), lr=0.03, noise_mode=L.NOISE_PHILOX, seed=1, energy_mode=(L.ENERGY_LAST if os.environ.get("STAMPS_ENERGY") == "last" else L.ENERGY_ALL),
         **(dict(acc_begin=0, acc_end=K) if learn else {}))
 torch.cuda.synchronize()

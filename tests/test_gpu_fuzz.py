@@ -34,7 +34,7 @@ def _random_case(i):
     return case, mode
 
 
-@pytest.mark.parametrize("kernel", ["default", "barrier"])
+@pytest.mark.parametrize("kernel", ["default", "inplace", "barrier"])
 @pytest.mark.parametrize("i", range(N_CASES))
 def test_random_shape_matches_oracle(i, kernel):
     from montecarlopredictivecoding_amd import _lib as L
@@ -60,7 +60,7 @@ def test_random_shape_matches_oracle(i, kernel):
     ref = mo.run(net, inputs, X0, lspec, xopt, T, noise=noise, noise_var=1.5, accumulate_p_at=list(range(mode["acc_begin"], T)))
 
     eng = Engine(sizes, [act_l] * len(sizes), case["n_in"], n_out, B, device=DEV, ecoef=case["ecoef"],
-                 tuning={"barrier": "ws=0", "default": None}[kernel])
+                 tuning={"barrier": "ws=0", "inplace": "ws=2", "default": None}[kernel])
     eng.bind_params([torch.from_numpy(w).to(DEV) for w in W], [None if x is None else torch.from_numpy(x).to(DEV) for x in b])
     eng.bind_inputs(None if case["inputs_zero"] else torch.from_numpy(inputs).to(DEV))
     if target is not None:

@@ -23,7 +23,7 @@ POISONS = {"snan": 0x7FA00000, "inf": 0x7F800000, "huge": 0x7F7FFFFF, "zero": 0x
 # (latent sizes, n_out, batch): batches are multiples of 16 so that the LAST row of every workgroup is a live chain
 CASES = [([40, 384, 200], 784, 48), ([33, 17, 21], 50, 32), ([200], 0, 16), ([17, 200, 33], 120, 64), ([30, 256, 256], 784, 32),
          ([21, 40], 17, 80), ([16, 496], 0, 16)]
-FORMS = [None, "ws=0", "overlay16=1", "no_xl=1", "no_lean=1"]
+FORMS = [None, "ws=2", "ws=0", "overlay16=1", "no_xl=1", "no_lean=1"]      # (None: the unified-wave kernel where its plan fits, else the in-place kernel)
 
 
 def test_poison_reaches_every_compute_unit():
