@@ -991,8 +991,8 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
         if ((rc = dmalloc(e->ypad, (size_t)e->Bpad * e->out_pad)) || (rc = dmalloc(e->ytile, (size_t)e->Bpad * e->out_pad))) return bail(rc);
         if (hipMemset(e->ypad, 0, (size_t)e->Bpad * e->out_pad * 4) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
         e->ywords = (e->out_pad + 31) / 32;
-        if ((rc = dmalloc(e->ybits, (size_t)e->Bpad * e->ywords)) || (rc = dmalloc(e->y_binary, 2))) return bail(rc);
-        if (hipMemset(e->y_binary, 0, 2 * sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));   // [1] stays 0
+        if ((rc = dmalloc(e->ybits, (size_t)e->Bpad * e->ywords)) || (rc = dmalloc(e->y_binary, 3))) return bail(rc);
+        if (hipMemset(e->y_binary, 0, 3 * sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));   // [1] stays 0; [2]: target in [-1, 2]
     }
     // Linear descriptors + gradient sums
     const int nlin = e->L + (e->has_head ? 1 : 0);
@@ -1132,6 +1132,7 @@ int mcpc_bind_target(mcpc_engine* e, const float* target, void* stream_) {
     hipLaunchKernelGGL(mcpc_tile_major_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream_, e->ypad, e->ytile, e->Bpad, e->out_pad);
     // a 0/1 target (the Bernoulli read-out's usual one) is also kept bit-packed; the flag tells the step kernel which to read
     HIP_TRY(hipMemsetAsync(e->y_binary, 0xff, sizeof(int), (hipStream_t)stream_));
+    HIP_TRY(hipMemsetAsync(e->y_binary + 2, 0xff, sizeof(int), (hipStream_t)stream_));      // cleared by the first value outside [-1, 2] (headb_fixed_exp)
     hipLaunchKernelGGL(mcpc_pack_target_bits_kernel, dim3(grid_for((size_t)e->Bpad * e->ywords)), dim3(256), 0, (hipStream_t)stream_,
                        e->ypad, e->ybits, e->y_binary, e->Bpad, e->out_pad, e->ywords);
     HIP_TRY(hipGetLastError());
@@ -1566,7 +1567,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         KHead& H = P.head;
         const Lin& ln = e->lin[e->L];
         H.Wf = (const f32x4*)ln.Wf; H.Wb = (const f32x4*)ln.Wb; H.bias = ln.bias_pad;
-        H.ybits = e->ybits; H.y_binary = e->knobs.no_ybits ? e->y_binary + 1 : e->y_binary; H.ywords = e->ywords;
+        H.ybits = e->ybits; H.y_binary = e->knobs.no_ybits ? e->y_binary + 1 : e->y_binary; H.y_bounded = e->y_binary + 2; H.ywords = e->ywords;
         H.y = e->ypad; H.ytile = e->ytile; H.rec_out = r->rec_count > 0 ? r->rec_out : nullptr; H.spill_e = e->spill_eo;
         H.spill_tm = e->lin[e->L].spill_tm ? 1 : 0;
         H.n = e->d.n_out; H.npad = e->out_pad; H.ntiles = e->out_pad / 16;
@@ -1690,6 +1691,10 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             if (overlap && tail > 0 && rem <= e->half_slots && rem >= 2 * tail && std::min(end, acc_e) == acc_e) n = rem - tail;
         }
         else n = (t < acc_b ? std::min(end, acc_b) : end) - t;
+        // a launch's row-exponent words carry their generation -- the step of the launch, or step x entries + entry for a ring slot -- in 24
+        // bits (mcpc_kernels.h: rowexp_track): longer stretches are cut into several launches (a wrapped generation would never
+        // supersede the stale word)
+        n = std::min(n, ((1 << 24) - 2) / std::max(std::max(e->n_phases, e->u.n_phases), 1));
         int rr_q = 0;
         if (rr_ok && in_acc) {
             rr_q = n / e->rr_m;                               // a Hebbian segment is one cycle (fewer steps than rr_m left: plain launch)

@@ -53,6 +53,7 @@ struct KHead {
     const float* ytile;    // the same image tile-major (tile_major_offset): what the lean read-out epilogue reads of an fp32 target
     const uint32_t* ybits; // the same bit-packed, [Bpad][ywords] (bit u & 31 of word u >> 5 = y[chain][u]); valid iff *y_binary
     const int* y_binary;   // device flag set by mcpc_bind_target: every target value is exactly 0.0f or 1.0f
+    const int* y_bounded;  // device flag set by mcpc_bind_target: every target value lies in [-1, 2] (headb_fixed_exp)
     int ywords;            // words per chain = ceil(npad / 32)
     float* rec_out;        // [rec_count][B][n] or null
     float* spill_e;        // [slots][Bpad][npad]
@@ -260,13 +261,16 @@ __device__ __forceinline__ int load_wexp(const int* wexp, int lin) {
     typedef __attribute__((address_space(4))) const int cint;
     return ((cint*)wexp)[lin];
 }
-// B exponent of the read-out error rows: a Bernoulli read-out's sigma(o) - y is bounded by 1 for targets in [0, 1] (2 for anything BCE
-// still makes sense of) -> a FIXED exponent, independent of how the read-out is cut into chunks; anything else: from the rows themselves
-__device__ __forceinline__ int headb_fixed_exp(int loss_kind) { return loss_kind == MCPC_LOSS_BERNOULLI ? 13 : kScaleAuto; }
+// B exponent of the read-out error rows: a Bernoulli read-out's sigma(o) - y is bounded by 1 for targets in [0, 1], by 3 for targets in
+// [-1, 2] (3 x 2^13 < 65 504: both fp16 pieces stay finite) -> a FIXED exponent, independent of how the read-out is cut into chunks.
+// `bounded` is what mcpc_bind_target found (KHead::y_bounded): the reference's BCEWithLogitsLoss (utils/model.py:17-22) takes ANY target and
+// stays finite, so a target outside that range (un-normalised 0..255 pixels) must not meet a constant scale -- it takes the exponent of
+// the rows themselves like every unbounded read-out error (round 6, ADVICE r5: e 2^13 overflowed fp16 to Inf from |y| ~ 8 on, silently).
+__device__ __forceinline__ int headb_fixed_exp(int loss_kind, bool bounded) { return loss_kind == MCPC_LOSS_BERNOULLI && bounded ? 13 : kScaleAuto; }
 // unified-wave kernel: with that constant exponent the read-out's epilogue can write the error rows already split into the fp16 planes the
 // back-projection reads -- once per value instead of once per k-block, wave and step (the long contractions only: a short one keeps its
 // fourth product and its own code path)
-__device__ __forceinline__ bool headf_planes(int loss_kind, int out_pad) { return loss_kind == MCPC_LOSS_BERNOULLI && out_pad > kShortK * kKB; }
+__device__ __forceinline__ bool headf_planes(int loss_kind, bool bounded, int out_pad) { return loss_kind == MCPC_LOSS_BERNOULLI && bounded && out_pad > kShortK * kKB; }
 
 // ---- row exponents kept by the producers (in-place kernel, lean epilogues) ------------------------------------------------------------
 // The GEMM core scales every chain row of its LDS operand by a power of two taken from the row's largest |value| (mcpc_gemm_f16.h).
@@ -580,6 +584,7 @@ __global__ __launch_bounds__(NW * 64, MCPC_BARRIER_WAVES_PER_EU) void mcpc_steps
     // fused fast paths of the x update (wave-uniform, fixed for the launch)
     const int upd_mode = (P.update_x && P.xopt == MCPC_XOPT_SGD)
                              ? (P.noise_mode == MCPC_NOISE_PHILOX ? 2 : (P.noise_mode == MCPC_NOISE_NONE ? 1 : 0)) : 0;
+    const bool y_bounded = P.has_head && *P.head.y_bounded != 0;      // (headb_fixed_exp)
     // every float of the plan starts a launch as zero (row tails and padding columns are never written afterwards)
     for (int i = tid; i < P.lds_floats / 4; i += NW * 64) st4(lds + 4 * i, splat(0.f));
     __syncthreads();
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(NW * 64, MCPC_BARRIER_WAVES_PER_EU) void mcpc_steps
             if (ph.type != PH_HEADB) issue_epilogue_loads<CTT, NW, NTW>(P, ph, lds, nt, wave, lane, chain0, pa, pb);
             if (nt > 0 && ph.nkb > 0) {
                 // HEADB phases add up in accb over the chunks of the read-out, in scaled units (accb_run / accb_aexp); every other GEMM is fresh
-                const int hb_exp = ph.type == PH_HEADB ? headb_fixed_exp(P.head.loss_kind) : kScaleAuto;
+                const int hb_exp = ph.type == PH_HEADB ? headb_fixed_exp(P.head.loss_kind, y_bounded) : kScaleAuto;
                 GemmScale gs{load_wexp(P.wexp, ph.a_lin), ph.type == PH_HEADB ? GS_ACCUM : GS_FRESH, hb_exp, accb_run,
                              ph.type == PH_HEADB ? (P.head.npad <= kShortK * kKB ? 1 : 0) : -1, hb_exp == kScaleAuto ? 1 : 0};
                 gemm_tiles<NTW, CTT, NW>(acc, ph.A, aoff, nt, ph.nkb, ph.kw, lds + ph.b_lds, ph.ldb, lane, pre0, lds + P.lds_zero, gs);
@@ -779,23 +784,27 @@ __global__ void mcpc_pack_kernel(const float* __restrict__ W, const float* __res
 
 // Bit-pack a padded target image [Bpad][npad] whose values are all exactly 0.0f / 1.0f (binarised MNIST, the Bernoulli
 // read-out's usual target): 98 B per chain instead of 3 136 B re-read from HBM in every step.  *flag is cleared by the first
-// value that is neither; the step kernel then reads the fp32 image as before.  One thread per 32-unit word.
+// value that is neither; the step kernel then reads the fp32 image as before.  flag[2] is cleared by the first value outside [-1, 2]
+// (headb_fixed_exp: the read-out error's constant fp16 scale holds for bounded targets only).  One thread per 32-unit word.
 __global__ void mcpc_pack_target_bits_kernel(const float* __restrict__ ypad, uint32_t* __restrict__ bits, int* __restrict__ flag,
                                              int Bpad, int npad, int ywords) {
     const size_t total = (size_t)Bpad * ywords;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int row = idx / ywords, w = idx % ywords;
         uint32_t word = 0;
-        bool ok = true;
+        bool ok = true, bounded = true;
         for (int j = 0; j < 32; ++j) {
             const int u = 32 * w + j;
             if (u >= npad) break;
-            const uint32_t pat = __float_as_uint(ypad[(size_t)row * npad + u]);
+            const float v = ypad[(size_t)row * npad + u];
+            const uint32_t pat = __float_as_uint(v);
             if (pat == 0x3F800000u) word |= 1u << j;
             else if (pat != 0u) ok = false;
+            if (!(v >= -1.0f && v <= 2.0f)) bounded = false;          // (NaN: not bounded)
         }
         bits[idx] = word;
-        if (!ok) *flag = 0;
+        if (!ok) flag[0] = 0;
+        if (!bounded) flag[2] = 0;          // (flag[1] is the constant 0 of tuning no_ybits)
     }
 }
 

@@ -84,7 +84,7 @@ __device__ __forceinline__ void u_energy_row(const KParams& P, const float* lds,
 template <bool MIX, bool PLAIN>
 __device__ __forceinline__ void u_epilogue(const KParams& P, const KPhase& ph, float* lds, int nt, const LeanLane<1>& LL, int slot, int rec_idx,
                                            bool do_energy, int t, int s_tab, float* rx, unsigned row_gen, const f32x4 (&acc)[kUNT][1],
-                                           f32x4 (&e0acc)[1], bool e0_in_regs, bool& e0_dirty, float& en_acc, bool ybin, bool lean_adam,
+                                           f32x4 (&e0acc)[1], bool e0_in_regs, bool& e0_dirty, float& en_acc, bool ybin, bool hplanes, bool lean_adam,
                                            int upd_mode, int lane) {
     constexpr int CTT = 1, NW = kUWaves, NTW = kUNT;
     int dead = 0;
@@ -98,8 +98,8 @@ __device__ __forceinline__ void u_epilogue(const KParams& P, const KPhase& ph, f
         if (do_energy) { esum = wave_sum(esum); if (lane == ph.layer) en_acc += esum; }
     } else if (ph.type == PH_HEADF) {
         float lsum;
-        if (ybin) lsum = lean_headf<CTT, NW, NTW, true, true, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, do_energy, nullptr, 0, P.err, dead, true, rx, acc, row_gen);
-        else lsum = lean_headf<CTT, NW, NTW, true, false, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, do_energy, nullptr, 0, P.err, dead, false, rx, acc, row_gen);
+        if (ybin) lsum = lean_headf<CTT, NW, NTW, true, true, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, do_energy, nullptr, 0, P.err, dead, true, rx, acc, row_gen, hplanes);
+        else lsum = lean_headf<CTT, NW, NTW, true, false, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, do_energy, nullptr, 0, P.err, dead, false, rx, acc, row_gen, hplanes);
         if (do_energy) { lsum = wave_sum(lsum); if (lane == kMaxLatent) en_acc += lsum; }
     } else if (ph.type == PH_BWD) {
         if (lean_adam) {
@@ -155,6 +155,8 @@ __global__ __launch_bounds__(kUThreads, 2) void mcpc_steps_u_kernel(const KParam
     LL.livem[0] = chain0 + c < P.B ? ~0u : 0u;
     const bool has_head = P.has_head != 0;
     const bool ybin = has_head && *P.head.y_binary != 0;
+    const bool y_bounded = has_head && *P.head.y_bounded != 0;      // (headb_fixed_exp: the bound target lies in [-1, 2])
+    const bool hplanes = has_head && headf_planes(P.head.loss_kind, y_bounded, P.head.npad);   // the read-out error travels as fp16 planes
     const bool no_loss = has_head && P.head.loss_kind == MCPC_LOSS_NONE;
     const bool e0_in_regs = P.layer[0].ntiles <= NW;
     bool e0_dirty = false;
@@ -215,14 +217,14 @@ __global__ __launch_bounds__(kUThreads, 2) void mcpc_steps_u_kernel(const KParam
                 int fixed_b;
                 int short_k = -1;
                 if (head_gemm) {
-                    const int hb_exp = headb_fixed_exp(P.head.loss_kind);
+                    const int hb_exp = headb_fixed_exp(P.head.loss_kind, y_bounded);
                     fixed_b = hb_exp == kScaleAuto ? rowexp_read(rx, ph.b_row, c) : hb_exp;
                     short_k = P.head.npad <= kShortK * kKB ? 1 : 0;
                 } else {
                     fixed_b = rowexp_read(rx, ph.b_row, c);
                 }
                 gemm_tiles_u<NTW>(acc, ph.A, aoff, nt, ph.nkb, ph.kw, lds + ph.b_lds, ph.ldb, lane, pre0, lds + P.lds_zero,
-                                  load_wexp(P.wexp, ph.a_lin), fixed_b, short_k, head_gemm && headf_planes(P.head.loss_kind, P.head.npad));
+                                  load_wexp(P.wexp, ph.a_lin), fixed_b, short_k, head_gemm && hplanes);
             }
 #ifdef MCPC_STAMPS        // GEMM time by row kind: slots 8..11 forward rows of 1..4 tiles, 12..15 update rows of 1..4 tiles
             {
@@ -239,8 +241,8 @@ __global__ __launch_bounds__(kUThreads, 2) void mcpc_steps_u_kernel(const KParam
             STAMP(3);
             if (live) {
                 // (ordinary steps -- nothing spilled, nothing recorded, no energies -- run instantiations in which all of that is compiled out)
-                if (plain) u_epilogue<MIX, true>(P, ph, lds, nt, LL, -1, -1, false, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, en_acc, ybin, lean_adam, upd_mode, lane);
-                else u_epilogue<MIX, false>(P, ph, lds, nt, LL, slot, rec_idx, do_energy, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, en_acc, ybin, lean_adam, upd_mode, lane);
+                if (plain) u_epilogue<MIX, true>(P, ph, lds, nt, LL, -1, -1, false, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, en_acc, ybin, hplanes, lean_adam, upd_mode, lane);
+                else u_epilogue<MIX, false>(P, ph, lds, nt, LL, slot, rec_idx, do_energy, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, en_acc, ybin, hplanes, lean_adam, upd_mode, lane);
                 STAMP(4);
             }
         }

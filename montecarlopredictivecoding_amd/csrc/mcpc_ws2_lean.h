@@ -407,12 +407,13 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
 template <int CTT, int NW, int NTW, bool XL = false, bool YB = false, bool REG = false>
 __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
                                             int slot, int rec_idx, bool do_energy, const int* prog_g, int need, int* err, int& dead,
-                                            bool ybin, float* rx = nullptr, const f32x4 (*racc)[CTT] = nullptr, unsigned row_gen = 0u) {
+                                            bool ybin, float* rx = nullptr, const f32x4 (*racc)[CTT] = nullptr, unsigned row_gen = 0u,
+                                            bool planes_ok = false) {
     if (nt <= 0) return 0.f;
     const int tstep = REG ? ph.rot : NW;
     const KHead& H = P.head;
     // unified-wave kernel: a Bernoulli read-out's error goes to LDS as planes (see below; headf_planes is the GEMM side's test too)
-    const bool planes = REG && headf_planes(H.loss_kind, H.npad);
+    const bool planes = REG && planes_ok;
     const int kind = H.loss_kind, n = H.n, mask_start = H.mask_start;
     const uint32_t npad4 = 4u * (uint32_t)H.npad;
     uint32_t rowb[CTT], orowb[CTT];
@@ -545,7 +546,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
                 // the chunk as the back-projection's GEMM reads it: per 8 units [h0..h7][m0..m7] (mcpc_gemm_f16.h: b_planes), split here, once,
                 // with the constant exponent of a bounded read-out error -- the lane's units 4 q .. 4 q + 3 of the tile are one half of a group
                 unsigned h0, m0, h1, m1;
-                const float sc = pow2i(headb_fixed_exp(MCPC_LOSS_BERNOULLI));
+                const float sc = pow2i(headb_fixed_exp(MCPC_LOSS_BERNOULLI, true));
                 split2_pair(f32x2{e.x, e.y}, sc, h0, m0);
                 split2_pair(f32x2{e.z, e.w}, sc, h1, m1);
                 char* const gp = eo + (orowb[ct] - 16u * L.q) + cb + 32u * (uint32_t)(L.q >> 1) + 8u * (uint32_t)(L.q & 1);

@@ -56,12 +56,25 @@ class _AliasLoader(importlib.abc.Loader):
 
     def __init__(self, target):
         self._target = target
+        self._own = None
 
     def create_module(self, spec):
-        return importlib.import_module(self._target)
+        module = importlib.import_module(self._target)
+        # importlib's _init_module_attrs is about to overwrite the module's __spec__ / __loader__ / __package__-related attributes with the
+        # ALIAS spec (name 'predictive_coding', this loader) -- for the real montecarlopredictivecoding_amd.* module, process-wide: relative
+        # imports inside it would then warn (`__package__ != __spec__.parent`) and resolve against the wrong parent on Pythons that stop
+        # consulting __package__, importlib.reload would be a silent no-op.  Remember what the module really is ...
+        self._own = {k: getattr(module, k) for k in ("__spec__", "__loader__", "__name__", "__package__", "__file__", "__cached__", "__path__")
+                     if hasattr(module, k)}
+        return module
 
     def exec_module(self, module):
-        pass                                    # (already executed under its own name)
+        # ... and put it back: the module keeps its own identity, sys.modules merely knows it under a second name
+        for k, v in (self._own or {}).items():
+            try:
+                setattr(module, k, v)
+            except (AttributeError, TypeError):
+                pass
 
 
 class _EmptyPackageLoader(importlib.abc.Loader):

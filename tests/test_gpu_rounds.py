@@ -174,7 +174,7 @@ def test_epilogue_operands_in_lds_match_global_memory(sizes, act, loss, xopt):
     else:
         kw.update(lr=0.03, noise_mode=L.NOISE_PHILOX if xopt == "sgd_noise" else L.NOISE_NONE, noise_var=1.5)
     outs = []
-    for tuning in (None, "no_xl=1", "no_lean=1"):
+    for tuning in ("ws=2", "ws=2,no_xl=1", "ws=2,no_lean=1"):      # (ws=2: the in-place kernel also where the unified-wave kernel would serve the call)
         eng = Engine(sizes, [a_dev] * len(sizes), sizes[0], n_out, batch, device=DEV, tuning=tuning)
         assert eng.query()["chains_per_wg"] == 16
         lds = eng.query()["lds_bytes"]

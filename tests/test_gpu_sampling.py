@@ -38,8 +38,11 @@ def _t_moments(nu):
     return m2, m4 - m2 * m2
 
 
-@pytest.mark.parametrize("name", ["tanh_gaussian", "relu_bernoulli"])
+@pytest.mark.parametrize("name", ["tanh_gaussian", "relu_bernoulli", "relu_zero"])
 def test_fused_sampler_sits_inside_the_reference_seed_spread(name):
+    """`relu_zero` is BASELINE config 5's call -- unclamped generation with `zero_fn`, figure_3.py:125-161 -- whose product is the read-out:
+    there the mean and the full covariance of `out` over chains and time are held inside the reference's seed spread too (the engine's
+    zero-loss path computes the read-out only on the steps that record it: csrc/mcpc_steps_u.h)."""
     from montecarlopredictivecoding_amd import _lib as L
     from montecarlopredictivecoding_amd.engine import Engine
     g = np.load(os.path.join(GOLDEN, f"g13_sampling_moments_{name}.npz"))
@@ -51,12 +54,21 @@ def test_fused_sampler_sits_inside_the_reference_seed_spread(name):
     eng = Engine(sizes, [act] * 3, case["n_in"], case["n_out"], B, device=DEV)
     eng.bind_params([torch.from_numpy(w).to(DEV) for w in W], [torch.from_numpy(v).to(DEV) for v in b])
     eng.bind_inputs(None)
-    eng.bind_target(torch.from_numpy(target).to(DEV))
+    if target is not None:
+        eng.bind_target(torch.from_numpy(target).to(DEV))
     eng.load_state([torch.from_numpy(x).to(DEV) for x in X0])
-    kind = L.LOSS_GAUSSIAN if case["loss"] == "gaussian" else L.LOSS_BERNOULLI
+    kind = {"gaussian": L.LOSS_GAUSSIAN, "bernoulli": L.LOSS_BERNOULLI, "zero": L.LOSS_NONE}[case["loss"]]
+    gen = case["loss"] == "zero"
     res = eng.run(T, loss_kind=kind, loss_var=case["var"], xopt=L.XOPT_SGD, lr=lr, noise_mode=L.NOISE_PHILOX, noise_var=nvar,
-                  seed=20260104, step_base=0, energy_mode=L.ENERGY_ALL, rec_begin=burn, rec_stride=1, rec_count=T - burn, rec_x=True)
+                  seed=20260104, step_base=0, energy_mode=L.ENERGY_ALL, rec_begin=burn, rec_stride=1, rec_count=T - burn, rec_x=True,
+                  rec_out=gen)
     eng.sync_check()
+    if gen:
+        o = res.rec_out.double().reshape(-1, case["n_out"])
+        out_mean = o.mean(0)
+        out_cov = (o.T @ o / o.shape[0] - torch.outer(out_mean, out_mean)).cpu().numpy()
+        out_mean = out_mean.cpu().numpy()
+        del o
     x = torch.cat(res.rec_x, dim=2).double().reshape(-1, sum(sizes))           # [(T - burn) * B, 38]: x_t before the update of step t
     mean = x.mean(0)
     cov = (x.T @ x / x.shape[0] - torch.outer(mean, mean)).cpu().numpy()
@@ -71,7 +83,12 @@ def test_fused_sampler_sits_inside_the_reference_seed_spread(name):
     groups = {"means": _z(mean, g["mean"]),
               "variances": _z(np.diag(cov), np.array([np.diag(c) for c in g["cov"]])),
               "covariances": _z(cov[iu], np.array([c[iu] for c in g["cov"]])),
-              "energies": _z(energies, g["energies"])}
+              "energies": _z(energies[1:] if gen else energies, g["energies"][:, 1:] if gen else g["energies"])}     # (a zero loss has no spread)
+    if gen:
+        ju = np.triu_indices(out_cov.shape[0], k=1)
+        groups["read-out means"] = _z(out_mean, g["out_mean"])
+        groups["read-out variances"] = _z(np.diag(out_cov), np.array([np.diag(c) for c in g["out_cov"]]))
+        groups["read-out covariances"] = _z(out_cov[ju], np.array([c[ju] for c in g["out_cov"]]))
     for key, z in groups.items():
         # every entry inside 8 spreads of a further reference seed.  (The spread of an entry is itself estimated from 12 seeds:
         # Student t with 11 degrees of freedom, P(|t| > 8) = 6e-6 per entry, 703 covariance entries.  Leaving one REFERENCE seed out
@@ -83,6 +100,9 @@ def test_fused_sampler_sits_inside_the_reference_seed_spread(name):
     # in plain numbers: the stationary variances -- what a mis-scaled kick or correlated normals would move first -- within 2 % (6 spreads)
     np.testing.assert_allclose(np.diag(cov), np.array([np.diag(c) for c in g["cov"]]).mean(0), rtol=2e-2)
     np.testing.assert_allclose(energies, g["energies"].mean(0), rtol=2e-3)
+    if gen:
+        assert energies[0] == 0.0
+        np.testing.assert_allclose(np.diag(out_cov), np.array([np.diag(c) for c in g["out_cov"]]).mean(0), rtol=2e-2)
 
 
 def _corr(a, b):

@@ -200,3 +200,35 @@ def test_unified_kernel_on_the_round_schedule_and_sliced_calls():
     for a, c in zip(outs[0][1], [x.cpu().numpy() for x in xs]):
         assert np.array_equal(a, c)
     eng.close()
+
+
+@pytest.mark.parametrize("y_lo,y_hi", [(-1.0, 2.0), (0.0, 255.0), (-40.0, 3.0)], ids=["bounded", "pixels-0-255", "negative"])
+@pytest.mark.parametrize("tuning", [None, "ws=2", "ws=0"], ids=["default", "inplace", "barrier"])
+def test_bernoulli_read_out_with_targets_outside_the_unit_interval(tuning, y_lo, y_hi):
+    """the reference's BCEWithLogitsLoss (utils/model.py:17-22) takes any target and stays finite; the back-projection of the
+    Bernoulli read-out's error used a CONSTANT fp16 scale that assumes |sigmoid(o) - y| <= 2 and overflowed to Inf from |y| ~ 8 on
+    (un-normalised 0..255 pixels).  mcpc_bind_target now records whether the target lies in [-1, 2]; outside, the rows scale by their own
+    maximum like every unbounded read-out error.  Every kernel form against the oracle, a learning call."""
+    from montecarlopredictivecoding_amd import _lib as L
+    case = _case([20, 128, 128], 784, "relu", "bernoulli", 40, seed=77)
+    W, b, X0, inputs, target = make_case_inputs(case)
+    r = np.random.RandomState(4)
+    target = (y_lo + (y_hi - y_lo) * r.rand(*target.shape)).astype(np.float32)
+    T, acc0, seed, lr = 12, 4, 21, 0.002
+    eng = _engine(case, W, b, target, tuning)
+    res, xs = _run(eng, X0, T, loss_kind=L.LOSS_BERNOULLI, lr=lr, seed=seed, step_base=0, noise_var=1.0, noise_mode=L.NOISE_PHILOX,
+                   acc_begin=acc0, acc_end=T, energy_mode=L.ENERGY_ALL)
+    g = eng.read_param_grads_flat().cpu().numpy()
+    eng.close()
+    en = res.energies.cpu().numpy()
+    assert np.isfinite(en).all() and all(np.isfinite(x).all() for x in xs) and np.isfinite(g).all()
+    net = mo.NetSpec(sizes=case["sizes"], acts=[mo.ACT_RELU] * 3, W=W, b=b, ecoef=case["ecoef"], has_head=True)
+    ref = mo.run(net, inputs, X0, mo.LossSpec(mo.LOSS_BERNOULLI, target, 1.0, 0), mo.XOpt(mo.OPT_SGD, lr), T,
+                 noise=lambda t, l: philox.layer_normals(seed, t, l, 0, 40, case["sizes"][l]), noise_var=1.0, accumulate_p_at=list(range(acc0, T)))
+    grp = "Bernoulli read-out, targets outside [0, 1] (3 ranges x 3 kernels)"
+    scale = max(1.0, float(np.abs(ref.overall).max()))
+    parity_log.close(grp, "overall[t]", en[:, -1], ref.overall, rtol=1e-6, atol=1e-6 * scale)
+    for l in range(3):
+        parity_log.close(grp, "x final", xs[l], ref.xs[l], rtol=0, atol=1e-5 * max(1.0, float(np.abs(ref.xs[l]).max())))
+    want = np.concatenate([np.concatenate([gw.reshape(-1), gb.reshape(-1)]) for gw, gb in zip(ref.gW, ref.gb)])
+    parity_log.close(grp, "dF/dtheta bucket", g, want, rtol=5e-4, atol=5e-4 * max(1.0, float(np.abs(want).max())))

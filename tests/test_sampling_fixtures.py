@@ -18,9 +18,17 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def test_sampling_fixtures_are_well_formed():
-    for name in ("tanh_gaussian", "relu_bernoulli"):
+    for name in ("tanh_gaussian", "relu_bernoulli", "relu_zero"):
         g = np.load(os.path.join(GOLDEN, f"g13_sampling_moments_{name}.npz"))
         case = json.loads(str(g["case_json"]))
+        if name == "relu_zero":
+            # unclamped generation (figure_3.py:125-161): a zero loss, and the read-out's moments beside the latents'
+            no = case["n_out"]
+            assert case["loss"] == "zero" and np.all(g["energies"][:, 0] == 0)
+            assert g["out_mean"].shape == (12, no) and g["out_cov"].shape == (12, no, no)
+            for c in g["out_cov"]:
+                assert np.allclose(c, c.T, atol=1e-12) and np.linalg.eigvalsh(c).min() > -1e-9
+            assert (np.array([np.diag(c) for c in g["out_cov"]]).std(0, ddof=1) / np.array([np.diag(c) for c in g["out_cov"]]).mean(0) < 0.02).all()
         n = sum(case["sizes"])
         assert g["mean"].shape == (12, n) and g["cov"].shape == (12, n, n) and g["energies"].shape == (12, 3)
         assert (int(g["burn"]), int(g["T"]), case["B"]) == (500, 2500, 4096)
