@@ -32,6 +32,7 @@ staged    (round 5) a model built on the CPU -- how most of the reference's call
 rejected  any call when no HIP device is visible (there is no CPU path: ``MCPCLibraryError``) and ``plot_progress`` (out of scope).
 """
 import collections
+import threading
 import os
 import typing
 import warnings
@@ -70,21 +71,42 @@ class _few_cpu_threads:
     on all of them: the HIP runtime's completion handling starves, and the very same kernels take 52 instead of 14.5 ms per recipe iteration
     on a 256-thread host (measured, scripts/staging_cost.py; with 8 threads 14.8).  Capped for the duration of the call, restored on exit."""
     CAP = 8
+    # `torch.set_num_threads` is process-global: nested staged calls (a callback that trains another model) and trainers on several Python
+    # threads share ONE cap -- the outermost entry saves the caller's value, the last exit restores it, and only if nobody else has changed
+    # the setting meanwhile (a script that calls set_num_threads inside a callback keeps what it set; ADVICE r5).  A side effect the staging
+    # warning states: the user's callbacks and optimizer_p.step() inside a staged call run under the cap too.
+    _lock = threading.Lock()
+    _depth = 0
+    _saved = None
 
     def __init__(self, active):
-        self.active, self.saved = bool(active), None
+        self.active, self.entered = bool(active), False
 
     def __enter__(self):
         if self.active:
-            n = torch.get_num_threads()
-            if n > self.CAP:
-                self.saved = n
-                torch.set_num_threads(self.CAP)
+            cls = _few_cpu_threads
+            with cls._lock:
+                if cls._depth == 0:
+                    n = torch.get_num_threads()
+                    if n > cls.CAP:
+                        cls._saved = n
+                        torch.set_num_threads(cls.CAP)
+                    else:
+                        cls._saved = None
+                cls._depth += 1
+                self.entered = True
         return self
 
     def __exit__(self, *exc):
-        if self.saved is not None:
-            torch.set_num_threads(self.saved)
+        if self.entered:
+            cls = _few_cpu_threads
+            with cls._lock:
+                cls._depth -= 1
+                if cls._depth == 0 and cls._saved is not None:
+                    if torch.get_num_threads() == cls.CAP:          # still the cap this context set: nobody chose another value meanwhile
+                        torch.set_num_threads(cls._saved)
+                    cls._saved = None
+            self.entered = False
         return False
 
 

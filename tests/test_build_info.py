@@ -89,3 +89,31 @@ def test_step_kernel_keeps_its_arguments_out_of_scratch(tmp_path):
         body = body[:body.index("s_endpgm")]
         n_scratch = len(re.findall(r"^\s*scratch_(load|store)", body, flags=re.M))
         assert n_scratch == 0, f"{k}: {n_scratch} scratch instructions in the step kernel"
+    # the unified-wave kernel (round 6): the same demands
+    ustep = {k: v for k, v in usage.items() if "mcpc_steps_u_kernel" in k}
+    assert len(ustep) == 2, sorted(usage)
+    for k, u in ustep.items():
+        assert u["VGPRs Spill"] == 0 and u["ScratchSize"] <= 128 and u["VGPRs"] <= 256, (k, u)
+        body = text[text.index(f"\n{k}:"):]
+        body = body[:body.index("s_endpgm")]
+        assert not re.findall(r"^\s*scratch_(load|store)", body, flags=re.M), f"{k}: scratch instructions in the unified-wave kernel"
+    # the Hebbian flush: no scratch traffic in any mcpc_heb7_kernel<*>, with ONE known exception that is not in a loop --
+    # <17, 2, false> (136 accumulators + the double-buffered split at 256 VGPRs) parks one address register in scratch before its stage
+    # loop and reloads it once behind it (`scratch_store_dword` in the prologue, `scratch_load_dword` after the loop's exit label)
+    heb = {k: v for k, v in usage.items() if "mcpc_heb7_kernel" in k}
+    assert len(heb) >= 6, sorted(usage)
+    for k, u in heb.items():
+        body = text[text.index(f"\n{k}:"):]
+        body = body[:body.index("s_endpgm")]
+        lines = body.splitlines()
+        scratch = [i for i, ln in enumerate(lines) if re.match(r"\s*scratch_(load|store)", ln)]
+        if "ILi17ELi2ELb0E" in k:
+            assert u["VGPRs Spill"] <= 1 and len(scratch) <= 2, (k, u, len(scratch))
+            # neither of the two sits inside a loop: no backward branch jumps over it
+            labels = {m.group(1): i for i, ln in enumerate(lines) for m in [re.match(r"(\.LBB\d+_\d+):", ln)] if m}
+            for i, ln in enumerate(lines):
+                m = re.match(r"\s*s_cbranch_\w+\s+(\.LBB\d+_\d+)", ln) or re.match(r"\s*s_branch\s+(\.LBB\d+_\d+)", ln)
+                if m and m.group(1) in labels and labels[m.group(1)] < i:          # a backward branch: the loop [target, branch]
+                    assert not any(labels[m.group(1)] <= sidx <= i for sidx in scratch), (k, ln.strip())
+        else:
+            assert u["VGPRs Spill"] == 0 and not scratch, (k, u, len(scratch))

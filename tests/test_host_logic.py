@@ -331,3 +331,26 @@ def test_static_langevin_check_is_an_allow_list():
     assert {i.opname for i in dis.get_instructions(kick)} <= recognise._KICK_ALLOWED_OPS
     import weakref
     assert isinstance(recognise._FUSED_ANNOUNCED, weakref.WeakSet)
+
+
+def test_staged_calls_thread_cap_is_reentrant_and_respects_the_users_own_setting():
+    """the cap on torch's intra-op threads during a staged call (pc_trainer._few_cpu_threads) is process-global state: nested
+    calls share one cap, the outermost restores the caller's value, and a value the user sets inside a callback is kept."""
+    import torch
+    from montecarlopredictivecoding_amd.predictive_coding.pc_trainer import _few_cpu_threads as cap
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(16)
+        with cap(True):
+            assert torch.get_num_threads() == cap.CAP
+            with cap(True):
+                assert torch.get_num_threads() == cap.CAP
+            assert torch.get_num_threads() == cap.CAP          # the inner exit did not lift the outer cap
+        assert torch.get_num_threads() == 16
+        with cap(True):
+            torch.set_num_threads(4)                            # e.g. a callback's own choice
+        assert torch.get_num_threads() == 4
+        with cap(False):
+            assert torch.get_num_threads() == 4
+    finally:
+        torch.set_num_threads(before)
