@@ -127,7 +127,9 @@ int parse_tuning(const char* str, Knobs& k) {
 // run (lean runs: fused SGD update with or without the Philox kick, Adam without noise), everything else stays on the main plan's kernel.
 struct UPlan {
     bool ok = false;                // the plan fits the LDS (whole read-out error + state rows resident)
-    bool on = false;                // ... and the engine uses it (tuning ws=3, or the automatic choice: choose_unified)
+    bool on = false;                // ... and the engine holds its table (automatic tuning, or ws=3)
+    bool prefer = false;            // ... and uses it for every lean run (tuning ws=3, or the automatic choice: choose_unified); otherwise
+                                    // only for zero-loss runs, whose read-out this kernel alone skips on the steps nobody records
     int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_ws_sync = 0, lds_zero = 0, lds_spillmax = 0, lds_rowexp = 0;
     int lds_x[kMaxLatent]{}, lds_bias[kMaxLatent]{}, lds_hbias = 0, lds_yw = 0, lds_bytes = 0;
     KPhase* phases = nullptr;
@@ -588,26 +590,32 @@ int plan_lds_u(mcpc_engine* e) {
     UPlan& u = e->u;
     u.ok = false;
     const int CT = e->ct, L = e->L;
-    int off = 0;
-    for (int l = 0; l < L; ++l) { u.lds_a[l] = off; off += CT * (e->npad[l] + kLdPad); }
-    u.lds_e[0] = 0;
-    for (int l = 1; l < L; ++l) { u.lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
-    u.lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
-    u.lds_ws_sync = off; off += 16;
-    u.lds_eo = off;
-    if (e->has_head) off += CT * (e->out_pad + kLdPad);
-    u.lds_zero = off; off += 16;
-    u.lds_spillmax = off; off += kSpillTensors;
-    u.lds_rowexp = off; off += kRowExpFloats;
-    for (int l = 0; l < L; ++l) { u.lds_x[l] = off; off += CT * (e->npad[l] + kLdPad); }
-    for (int l = 0; l < L; ++l) { u.lds_bias[l] = off; off += l >= 1 ? e->npad[l] : CT * (e->npad[0] + kLdPad); }
-    if (e->has_head) {
-        const int ywords = (e->out_pad + 31) / 32;
-        u.lds_hbias = off; off += e->out_pad;
-        u.lds_yw = off; off += (CT * ywords + 3) / 4 * 4;
+    // two tries: everything the epilogues read per step in LDS; else the bit-packed target rows stay in global memory (the read-out's
+    // epilogue requests its words in front of its row's GEMM: mcpc_steps_u.h) -- cfg-M's plan is 1 792 bytes over the 160 KiB with them
+    // and fits to the byte without
+    for (int yw_in_lds = 1; yw_in_lds >= 0 && !u.ok; --yw_in_lds) {
+        int off = 0;
+        for (int l = 0; l < L; ++l) { u.lds_a[l] = off; off += CT * (e->npad[l] + kLdPad); }
+        u.lds_e[0] = 0;
+        for (int l = 1; l < L; ++l) { u.lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
+        u.lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
+        u.lds_ws_sync = off;                                // (no progress counters in this kernel)
+        u.lds_eo = off;
+        if (e->has_head) off += CT * (e->out_pad + kLdPad);
+        u.lds_zero = off; off += 16;
+        u.lds_spillmax = off; off += kSpillTensors;
+        u.lds_rowexp = off; off += (rowexp_ring(0) + 1) * 16;      // the ids this kernel uses: FX_l, E_l and ONE read-out row word
+        for (int l = 0; l < L; ++l) { u.lds_x[l] = off; off += CT * (e->npad[l] + kLdPad); }
+        for (int l = 0; l < L; ++l) { u.lds_bias[l] = off; off += l >= 1 ? e->npad[l] : CT * (e->npad[0] + kLdPad); }
+        u.lds_yw = -1;
+        if (e->has_head) {
+            const int ywords = (e->out_pad + 31) / 32;
+            u.lds_hbias = off; off += e->out_pad;
+            if (yw_in_lds) { u.lds_yw = off; off += (CT * ywords + 3) / 4 * 4; }
+        }
+        u.lds_bytes = off * (int)sizeof(float);
+        u.ok = u.lds_bytes <= 160 * 1024;
     }
-    u.lds_bytes = off * (int)sizeof(float);
-    u.ok = u.lds_bytes <= 160 * 1024;
     return 0;
 }
 
@@ -774,11 +782,20 @@ int build_phases_u(mcpc_engine* e) {
 }
 
 // The automatic choice between the in-place and the unified-wave kernel for an engine whose unified plan fits (tuning ws=2 / ws=3 force
-// either): see DESIGN section 4 for the measurement behind it.
-bool choose_unified(const mcpc_engine* e) {
-    (void)e;
-    return true;
+// either).  Measured on one MI355X (profiles/r06_small_net.txt, us per 16-chain unit-step, MCPC / MAP / learning call):
+//   20-128-128-784 (476 tile-blocks of GEMM per step)   in-place 21.3 / 23.1 / 23.9    unified 16.8 / 18.0 / 19.3
+//   30-256-256-784 (1 080 tile-blocks: cfg-M)            in-place 26.4 / 30.0 / 29.4    unified 29.3 / 31.0 / 32.4
+// A step's fixed costs per table entry are what the unified form removes; the overlap of GEMM and epilogue waves is what it gives up, and
+// at cfg-M's width that overlap is worth more.  The unit is what both scale with: (unit tile, 32-deep k-block) pairs of all GEMMs of a step.
+// A ZERO-LOSS call (unclamped generation) runs on the unified kernel whatever the width: only that kernel skips the read-out on the steps
+// nobody records (cfg-M's net: 16.6 against 25.3 us per step) -- mcpc_run decides that per run.
+int gemm_tile_blocks(const mcpc_engine* e) {
+    int n = 0;
+    for (int l = 1; l < e->L; ++l) n += (e->npad[l] / 16) * kblocks(e->npad[l - 1]) + (e->npad[l - 1] / 16) * kblocks(e->npad[l]);
+    if (e->has_head) n += (e->out_pad / 16) * kblocks(e->npad[e->L - 1]) + (e->npad[e->L - 1] / 16) * kblocks(e->out_pad);
+    return n;
 }
+bool choose_unified(const mcpc_engine* e) { return gemm_tile_blocks(e) <= 800; }
 
 // The per-step schedule: every GEMM of a Langevin step with its operands, the epilogue that follows
 // it and the barrier it needs.  Output tiles are handed out 16 at a time (4 waves x kNT tiles).
@@ -1046,7 +1063,8 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
     // the unified-wave kernel beside the in-place kernel, where its plan fits (mcpc_steps_u.h)
     if (e->ws == 2 && (kn.ws == -1 || kn.ws == 3) && !kn.no_lean && !kn.no_xl) {
         (void)plan_lds_u(e);
-        e->u.on = e->u.ok && (kn.ws == 3 || choose_unified(e));
+        e->u.on = e->u.ok;
+        e->u.prefer = e->u.ok && (kn.ws == 3 || choose_unified(e));
         if (e->u.on && (rc = build_phases_u(e))) return bail(rc);
     }
     if (kn.ws == 3 && !e->u.on) return bail(fail(MCPC_ENOMEM, "tuning ws=3: the unified-wave kernel's LDS plan does not fit this network (%d bytes)", e->u.lds_bytes));
@@ -1613,7 +1631,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
 #endif
     // The unified-wave kernel (mcpc_steps_u.h) serves the lean runs of an engine that holds its plan: fused SGD update with or without
     // the Philox kick, Adam without noise.  Everything else -- gradients-only runs, injected noise -- keeps the main plan's kernel.
-    bool use_u = e->u.on && e->ws == 2 && r->update_x && P.lean_ok &&
+    bool use_u = e->u.on && (e->u.prefer || (e->has_head && r->loss_kind == MCPC_LOSS_NONE)) && e->ws == 2 && r->update_x && P.lean_ok &&
                  ((r->xopt_kind == MCPC_XOPT_SGD && r->noise_mode != MCPC_NOISE_EXTERNAL) ||
                   (r->xopt_kind == MCPC_XOPT_ADAM && r->noise_mode == MCPC_NOISE_NONE));
     if (use_u) {
@@ -1943,7 +1961,7 @@ int mcpc_query(const mcpc_engine* e, int32_t* lds_bytes, int32_t* chains_per_wg,
 const char* mcpc_step_kernel_name(const mcpc_engine* e) {
     if (!e) return "";
     // (an engine that holds the unified-wave kernel's plan runs its fused calls -- what a benchmark times -- on that kernel)
-    if (e->u.on) return e->rr ? e->u_rr_name.c_str() : "mcpc::mcpc_steps_u_kernel<false>";
+    if (e->u.prefer) return e->rr ? e->u_rr_name.c_str() : "mcpc::mcpc_steps_u_kernel<false>";
     if (e->rr) return e->rr_name.c_str();
     if (e->ws == 2) return "mcpc::mcpc_steps_ws2_kernel<1, false>";
     return "mcpc::mcpc_steps_kernel<1, 4>";

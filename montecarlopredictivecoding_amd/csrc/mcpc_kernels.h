@@ -65,7 +65,8 @@ struct KHead {
     int lds_eo;            // float offset of the read-out error chunk
     int ld;                // its row stride = kChunkTiles*16 + kLdPad
     int lds_bias;          // KParams::xl: float offset of the bias row [npad]
-    int lds_yw;            // KParams::xl: float offset of the bit-packed target rows [chains][ywords]
+    int lds_yw;            // KParams::xl: float offset of the bit-packed target rows [chains][ywords]; < 0 (unified-wave kernel, a plan without
+                           // the room): they stay in global memory
 };
 
 // One entry of the per-step phase table (built on the host, identical for every step):

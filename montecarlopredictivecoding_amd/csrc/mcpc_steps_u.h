@@ -85,7 +85,7 @@ template <bool MIX, bool PLAIN>
 __device__ __forceinline__ void u_epilogue(const KParams& P, const KPhase& ph, float* lds, int nt, const LeanLane<1>& LL, int slot, int rec_idx,
                                            bool do_energy, int t, int s_tab, float* rx, unsigned row_gen, const f32x4 (&acc)[kUNT][1],
                                            f32x4 (&e0acc)[1], bool e0_in_regs, bool& e0_dirty, float& en_acc, bool ybin, bool hplanes, bool lean_adam,
-                                           int upd_mode, int lane) {
+                                           int upd_mode, int lane, const uint32_t* ywreg) {
     constexpr int CTT = 1, NW = kUWaves, NTW = kUNT;
     int dead = 0;
     const int act = P.layer[ph.layer].act;
@@ -98,7 +98,8 @@ __device__ __forceinline__ void u_epilogue(const KParams& P, const KPhase& ph, f
         if (do_energy) { esum = wave_sum(esum); if (lane == ph.layer) en_acc += esum; }
     } else if (ph.type == PH_HEADF) {
         float lsum;
-        if (ybin) lsum = lean_headf<CTT, NW, NTW, true, true, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, do_energy, nullptr, 0, P.err, dead, true, rx, acc, row_gen, hplanes);
+        if (ybin && ywreg != nullptr) lsum = lean_headf<CTT, NW, NTW, true, true, true, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, do_energy, nullptr, 0, P.err, dead, true, rx, acc, row_gen, hplanes, ywreg);
+        else if (ybin) lsum = lean_headf<CTT, NW, NTW, true, true, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, do_energy, nullptr, 0, P.err, dead, true, rx, acc, row_gen, hplanes);
         else lsum = lean_headf<CTT, NW, NTW, true, false, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, do_energy, nullptr, 0, P.err, dead, false, rx, acc, row_gen, hplanes);
         if (do_energy) { lsum = wave_sum(lsum); if (lane == kMaxLatent) en_acc += lsum; }
     } else if (ph.type == PH_BWD) {
@@ -157,6 +158,9 @@ __global__ __launch_bounds__(kUThreads, 2) void mcpc_steps_u_kernel(const KParam
     const bool ybin = has_head && *P.head.y_binary != 0;
     const bool y_bounded = has_head && *P.head.y_bounded != 0;      // (headb_fixed_exp: the bound target lies in [-1, 2])
     const bool hplanes = has_head && headf_planes(P.head.loss_kind, y_bounded, P.head.npad);   // the read-out error travels as fp16 planes
+    // a plan without the room for the bit-packed target rows (cfg-M): a 0/1 target's words come from global memory, requested in front of
+    // the row's GEMM so that they are older than every fragment load the epilogue would otherwise wait behind
+    const bool yw_glob = has_head && P.head.lds_yw < 0 && ybin;
     const bool no_loss = has_head && P.head.loss_kind == MCPC_LOSS_NONE;
     const bool e0_in_regs = P.layer[0].ntiles <= NW;
     bool e0_dirty = false;
@@ -213,6 +217,15 @@ __global__ __launch_bounds__(kUThreads, 2) void mcpc_steps_u_kernel(const KParam
             const bool head_gemm = ph.type == PH_BWD && ph.a_lin == L && (ph.flags & PHF_WS_GEMM);
             if (head_gemm && no_loss) ph.flags &= ~PHF_WS_GEMM;
             const bool live = nt > 0 && !(ph.type == PH_HEADF && skip_head);
+            uint32_t ywreg[NTW] = {0u, 0u, 0u, 0u};
+            if (yw_glob && ph.type == PH_HEADF) {
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) {
+                    const int tile = ph.tile0 + ph.rot * (i < nt ? i : 0);
+                    ywreg[i] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(
+                        (gbytes_t)P.head.ybits + mul24(LL.chain[0], 4u * (uint32_t)P.head.ywords) + 4u * (uint32_t)(tile >> 1));
+                }
+            }
             if (live && (ph.flags & PHF_WS_GEMM) && ph.nkb > 0) {
                 int fixed_b;
                 int short_k = -1;
@@ -241,8 +254,8 @@ __global__ __launch_bounds__(kUThreads, 2) void mcpc_steps_u_kernel(const KParam
             STAMP(3);
             if (live) {
                 // (ordinary steps -- nothing spilled, nothing recorded, no energies -- run instantiations in which all of that is compiled out)
-                if (plain) u_epilogue<MIX, true>(P, ph, lds, nt, LL, -1, -1, false, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, en_acc, ybin, hplanes, lean_adam, upd_mode, lane);
-                else u_epilogue<MIX, false>(P, ph, lds, nt, LL, slot, rec_idx, do_energy, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, en_acc, ybin, hplanes, lean_adam, upd_mode, lane);
+                if (plain) u_epilogue<MIX, true>(P, ph, lds, nt, LL, -1, -1, false, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, en_acc, ybin, hplanes, lean_adam, upd_mode, lane, yw_glob ? ywreg : nullptr);
+                else u_epilogue<MIX, false>(P, ph, lds, nt, LL, slot, rec_idx, do_energy, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, en_acc, ybin, hplanes, lean_adam, upd_mode, lane, yw_glob ? ywreg : nullptr);
                 STAMP(4);
             }
         }

@@ -168,10 +168,12 @@ __device__ __forceinline__ void ws2_fill_constants(const KParams& P, float* lds,
     if (P.has_head) {
         const KHead& H = P.head;
         for (int i = tid; i < H.npad / 4; i += kWs2Threads) st4(lds + H.lds_bias + 4 * i, ld4(H.bias + 4 * i));
-        uint32_t* const yw = reinterpret_cast<uint32_t*>(lds + H.lds_yw);
-        for (int idx = tid; idx < ct_rows * H.ywords; idx += kWs2Threads) {
-            const int r = idx / H.ywords, w = idx - r * H.ywords;
-            yw[idx] = H.ybits[(size_t)(chain0 + r) * H.ywords + w];
+        if (H.lds_yw >= 0) {
+            uint32_t* const yw = reinterpret_cast<uint32_t*>(lds + H.lds_yw);
+            for (int idx = tid; idx < ct_rows * H.ywords; idx += kWs2Threads) {
+                const int r = idx / H.ywords, w = idx - r * H.ywords;
+                yw[idx] = H.ybits[(size_t)(chain0 + r) * H.ywords + w];
+            }
         }
     }
 }

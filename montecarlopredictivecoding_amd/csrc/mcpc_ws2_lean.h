@@ -404,11 +404,12 @@ __device__ __forceinline__ void lean_bwd(const KParams& P, const KPhase& ph, flo
 // ---- HEADF entry (read-out chunk): out = acc + bias, e_o = dL/dout -> ring slot (LDS), loss, spills, output records -----
 // XL: bias from LDS; YB (with XL only): the target is 0/1, its words come from LDS and no fp32 target is requested -- a compile-time
 // choice, so that the 0/1 case holds no global load at all (see the note on loads under an `if` below).
-template <int CTT, int NW, int NTW, bool XL = false, bool YB = false, bool REG = false>
+// YWG (with XL, YB, REG): the target words were requested from global memory by the caller, in front of the row's GEMM (ywreg[i])
+template <int CTT, int NW, int NTW, bool XL = false, bool YB = false, bool REG = false, bool YWG = false>
 __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, float* lds, int nt, int kk, const LeanLane<CTT>& L,
                                             int slot, int rec_idx, bool do_energy, const int* prog_g, int need, int* err, int& dead,
                                             bool ybin, float* rx = nullptr, const f32x4 (*racc)[CTT] = nullptr, unsigned row_gen = 0u,
-                                            bool planes_ok = false) {
+                                            bool planes_ok = false, const uint32_t* ywreg = nullptr) {
     if (nt <= 0) return 0.f;
     const int tstep = REG ? ph.rot : NW;
     const KHead& H = P.head;
@@ -440,7 +441,10 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
         }
 #pragma unroll
         for (int ct = 0; ct < CTT; ++ct) {
-            if constexpr (XL && YB) {
+            if constexpr (XL && YB && YWG) {
+                yv[i][ct] = splat(0.f);
+                yw[i][ct] = ywreg[i];
+            } else if constexpr (XL && YB) {
                 yv[i][ct] = splat(0.f);
                 yw[i][ct] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds + H.lds_yw) + mul24(L.lrow[ct], wrow4) + 4u * (uint32_t)(tile >> 1));
             } else if constexpr (XL) {

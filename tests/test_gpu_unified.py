@@ -162,9 +162,37 @@ def test_default_tuning_picks_the_unified_kernel_where_its_plan_fits_and_keeps_t
                        energy_mode=L.ENERGY_ALL)
         assert np.isfinite(res.energies.cpu().numpy()).all()
         eng.close()
+    # a net whose whole read-out error and state rows do not fit the LDS together has no unified plan: ws=3 says so
+    wide = _case([256, 256, 256, 256], 1000, "relu", "bernoulli", 32)
+    Ww, bw, _, _, tw = make_case_inputs(wide)
     with pytest.raises(Exception, match="unified-wave"):
-        _engine(_case([30, 256, 256], 784, "relu", "bernoulli", 32), *make_case_inputs(_case([30, 256, 256], 784, "relu", "bernoulli", 32))[:2],
-                make_case_inputs(_case([30, 256, 256], 784, "relu", "bernoulli", 32))[4], "ws=3")
+        _engine(wide, Ww, bw, tw, "ws=3")
+
+
+@pytest.mark.parametrize("loss", ["bernoulli", "zero"])
+def test_cfg_m_width_on_the_unified_kernel(loss):
+    """cfg-M's net (30-256-256-784): the unified plan fits the 160 KiB only with the bit-packed target rows left in global memory (the
+    read-out's epilogue requests its words in front of the row's GEMM).  The automatic choice keeps the in-place kernel for its MCPC /
+    MAP calls (profiles/r06_small_net.txt) and takes the unified kernel for a ZERO-LOSS call, whose read-out only that kernel skips."""
+    from montecarlopredictivecoding_amd import _lib as L
+    case = _case([30, 256, 256], 784, "relu", loss, 80, seed=12)
+    W, b, X0, inputs, target = make_case_inputs(case)
+    kind = L.LOSS_BERNOULLI if loss == "bernoulli" else L.LOSS_NONE
+    T = 19
+    kw = dict(loss_kind=kind, lr=0.03, seed=9, step_base=0, noise_var=2.0, noise_mode=L.NOISE_PHILOX, energy_mode=L.ENERGY_ALL, acc_begin=7, acc_end=T if loss == "bernoulli" else 7,
+              rec_begin=3, rec_stride=6, rec_count=3, rec_x=True, rec_out=True)
+    outs = []
+    for tuning in ("ws=3", "ws=2", None):
+        eng = _engine(case, W, b, target if loss == "bernoulli" else None, tuning)
+        assert ("steps_u_kernel" in eng.query()["step_kernel"]) == (tuning == "ws=3")
+        res, xs = _run(eng, X0, T, **kw)
+        outs.append((res.energies.cpu().numpy(), xs + [r.cpu().numpy() for r in res.rec_x] + [res.rec_out.cpu().numpy()], eng.read_param_grads_flat().cpu().numpy()))
+        eng.close()
+    for o in outs[1:]:
+        for a, c in zip(outs[0][1], o[1]):
+            assert np.array_equal(a, c)
+        np.testing.assert_allclose(outs[0][0], o[0], rtol=2e-6, atol=1e-9)
+        assert np.array_equal(outs[0][2], o[2])
 
 
 def test_unified_kernel_on_the_round_schedule_and_sliced_calls():
