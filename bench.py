@@ -55,7 +55,7 @@ PEAK_F16X3_TFLOPS = 2516.0 / 3.0
 # library measures during the timed launches (mcpc_last_shader_clock_ghz: 1.8-2.0 GHz; the 2.4 GHz peak only as a fallback).
 L1_FILL_BYTES_PER_CLK = 64
 PEAK_SHADER_GHZ = 2.4
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")
 
 
 def pmc_traffic(mode, kernel_name, csrc, batch, T, launches_per_call):
@@ -418,7 +418,11 @@ def main():
                 # error of the dot products against fp64 that of an fp32 MFMA chain (profiles/r05_f16x4_study.txt, DESIGN section 4: what
                 # limits both is the fp32 accumulation), parity tolerances unchanged
                 "arithmetic": "fp32 operands as two fp16 pieces (22 bits, power-of-two row scaling), products as 3 fp16 MFMA terms, fp32 "
-                              "accumulate: the accuracy of an fp32 MFMA chain (profiles/r05_f16x4_study.txt)",
+                              "accumulate: on independent operands the accuracy of an fp32 MFMA chain (0.5-1.6e-7 of sum|terms|, "
+                              "profiles/r05_f16x4_study.txt); WORST CASE per term 3 x 2^-22 = 7.2e-7 of |a b| when every operand rounds "
+                              "the same way (one repeated value against same-sign weights), beside the fp32 accumulation both share -- "
+                              "measured there 0.58 / 1.26 / 3.65e-6 of sum|terms| at K = 96 / 256 / 784 against 1.43 / 3.80 / 11.7e-6 for "
+                              "torch's fp32 GEMM on the same GPU (tests/test_gpu_accuracy.py)",
                 "timed_mode": ("learning call: Hebbian sums over the sampling steps + normalised grad read-out"
                                + (" + 1 RCCL all-reduce of %d floats" % n_params if world > 1 else "")) if primary_learning
                               else "inference-only call (no Hebbian sums)",

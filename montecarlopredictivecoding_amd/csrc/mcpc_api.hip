@@ -88,6 +88,16 @@ struct Knobs {
     int rr_qmax = 100;        // round schedule: most steps per launch in stretches without Hebbian accumulation
     int heb171 = 0;           // 1: the 17-tile group of a read-out on <17, 1> with twice the activation groups instead of <17, 2> (A/B)
     int heb_fp32 = 0;         // 1: the tiled Hebbian GEMM runs on the fp32 MFMA (mcpc_heb_kernel) instead of the fp16x6 form (A/B, parity tests)
+    // unified-wave kernel: the cost model its rows are dealt by (build_phases_u) -- developer knobs for its calibration.  The defaults started
+    // from in-kernel stamps (shader cycles: 2000 / 1200 / 330 / 68 / 1000 / 1300 / 500) and were then moved by a grid search on the step time
+    // itself (scripts/u_cost_search.py, profiles/r06_small_net.txt: 16.9 -> 16.1 us per MCPC step at batch 256): what the model has to get
+    // right is the ORDER of the jobs' costs and where a split stops paying, and a row's fixed cost and the read-out's epilogue weigh more in
+    // that than their stamps say (they sit on the level's critical path)
+    int u_row = 5000;         // per row: descriptor, the next row's fragment requests, the epilogue's fixed part
+    int u_gemm0 = 1200;       // per GEMM, before its first k-block
+    int u_kb = 200;           // per k-block beyond its tiles' MFMAs and requests (the B split; nothing with the operand in planes)
+    int u_kbt = 68;           // per k-block and tile
+    int u_eh = 3000, u_eb = 1300, u_ef = 500;      // per tile of an epilogue: read-out / x update / prediction error
 };
 
 int parse_tuning(const char* str, Knobs& k) {
@@ -108,7 +118,8 @@ int parse_tuning(const char* str, Knobs& k) {
         struct { const char* name; int* dst; } table[] = {
             {"ws", &k.ws}, {"no_overlap", &k.no_overlap},
             {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"cu_slack", &k.cu_slack}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
-            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}, {"heb_fp32", &k.heb_fp32}, {"heb171", &k.heb171}, {"rr", &k.rr}, {"rr_qmax", &k.rr_qmax}, {"no_xl", &k.no_xl}};
+            {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}, {"heb_fp32", &k.heb_fp32}, {"heb171", &k.heb171}, {"rr", &k.rr}, {"rr_qmax", &k.rr_qmax}, {"no_xl", &k.no_xl},
+            {"u_row", &k.u_row}, {"u_gemm0", &k.u_gemm0}, {"u_kb", &k.u_kb}, {"u_kbt", &k.u_kbt}, {"u_eh", &k.u_eh}, {"u_eb", &k.u_eb}, {"u_ef", &k.u_ef}};
         bool found = false;
         for (auto& t : table)
             if (key == t.name) { *t.dst = val; found = true; }
@@ -642,8 +653,9 @@ int build_phases_u(mcpc_engine* e) {
     // in planes (`ps`: the read-out's back-projection; the table is built before the loss is known and assumes the Bernoulli read-out the
     // reference trains with); ~1200 before the first block; per row ~2000 for its descriptor, the next row's fragment requests and the
     // epilogue's fixed part; per tile of an epilogue: read-out ~1000, x update with the Philox kick ~1300, prediction error ~500.
-    auto gemm_cost = [](int nt, int nkb, bool ps) { return nkb > 0 ? 1200.0 + nkb * ((ps ? 130.0 : 330.0) + 68.0 * nt) : 0.0; };
-    const double row_cost = 2000.0;
+    const Knobs& kn = e->knobs;
+    auto gemm_cost = [&](int nt, int nkb, bool ps) { return nkb > 0 ? (double)kn.u_gemm0 + nkb * ((double)std::max(kn.u_kb - (ps ? 200 : 0), 0) + (double)kn.u_kbt * nt) : 0.0; };
+    const double row_cost = (double)kn.u_row;
     auto make_jobs = [&](const KPhase& proto, int nt_total, double epi_tile, int g, std::vector<Job>& out, bool pinned, bool ps) {
         if (pinned) g = 1;
         for (int t = 0; t < nt_total; t += g) {
@@ -664,7 +676,7 @@ int build_phases_u(mcpc_engine* e) {
         f.out_lds = u.lds_eo; f.out_ld = e->out_pad + kLdPad;            // (row-relative columns: the epilogue adds 16 (tile - tile0) to its row's base)
         f.b_row = rowexp_fx(L - 1); f.o_row = rowexp_ring(0);
         f.flags = PHF_WS_GEMM | PHF_WS_EPI;
-        level[0].push_back({f, e->out_pad / 16, 1000.0, false, false});
+        level[0].push_back({f, e->out_pad / 16, (double)kn.u_eh, false, false});
     }
     for (int l = L - 1; l >= 0; --l) {
         KPhase k = blank();
@@ -678,7 +690,7 @@ int build_phases_u(mcpc_engine* e) {
             k.b_row = rowexp_fx(l - 1); k.o_row = rowexp_e(l);
             k.flags = PHF_WS_GEMM | PHF_WS_EPI;
         }
-        level[0].push_back({k, tiles(l), 500.0, l == 0 && tiles(0) <= kUWaves, false});
+        level[0].push_back({k, tiles(l), (double)kn.u_ef, l == 0 && tiles(0) <= kUWaves, false});
     }
     for (int l = L - 1; l >= 0; --l) {
         KPhase k = blank();
@@ -697,7 +709,7 @@ int build_phases_u(mcpc_engine* e) {
             k.b_lds = u.lds_e[l + 1]; k.ldb = e->npad[l + 1] + kLdPad; k.b_row = rowexp_e(l + 1); k.sign = -1.0f;
             k.flags |= PHF_WS_GEMM;
         }
-        level[1].push_back({k, tiles(l), 1300.0, false, l == L - 1 && e->has_head && e->out_pad > kShortK * kKB});
+        level[1].push_back({k, tiles(l), (double)kn.u_eb, false, l == L - 1 && e->has_head && e->out_pad > kShortK * kKB});
     }
     std::vector<KPhase> rows[kUWaves];
     for (int lv = 0; lv < 2; ++lv) {

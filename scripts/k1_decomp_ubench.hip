@@ -15,6 +15,7 @@
 // 34.8 / 19.6: profiles/r04_k1_bounds.txt) for the CT = 2 lines to mean anything -- EW is chosen for that.
 //   hipcc --offload-arch=gfx950 -O3 -Imontecarlopredictivecoding_amd/csrc -Iscripts scripts/k1_decomp_ubench.hip -o scripts/bin/k1_decomp_ubench
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -248,6 +249,44 @@ template <int CT, int NE, bool PRE, int MODE, int NG = 1> double run(const char*
     return us;
 }
 
+// Round 6: the MIXED shard -- 32-chain and 16-chain units of ONE 6000-chain shard side by side on the chip, more units
+// than CUs in total under a round schedule.  Both forms run here at the same time on disjoint CUs (two streams; u32 + u16 = 256 resident
+// workgroups, step counts chosen so that both kernels take about the same time), which gives each form's cost per unit-step WITH the other
+// beside it (shared L2s, shared clock); a schedule that keeps all 256 CUs busy then needs (n32 c32 + n16 c16) / 256 per step of the shard.
+template <int NE32>
+static void run_mixed(int u32, int u16, int ew, const u32x4* A, const Table& tab, float* out, double calib) {
+    const int s32 = 140, s16 = 200;
+    const size_t lds32 = (size_t)(16 * 2 * LDB + 16 * 2 * 256 + 16) * 4, lds16 = (size_t)(16 * LDB + 16 * 256 + 16) * 4;
+    hipFuncSetAttribute((const void*)kmodel<2, NE32, false, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32);
+    hipFuncSetAttribute((const void*)kmodel<1, 1, false, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+    hipStream_t sa, sb; hipStreamCreate(&sa); hipStreamCreate(&sb);
+    hipEvent_t a0, a1, b0, b1; hipEventCreate(&a0); hipEventCreate(&a1); hipEventCreate(&b0); hipEventCreate(&b1);
+    float* out2 = out + (size_t)128 * 1024;
+    double best32 = 1e30, best16 = 1e30;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipDeviceSynchronize();
+        hipEventRecord(a0, sa);
+        hipLaunchKernelGGL((kmodel<2, NE32, false, 3, 1>), dim3(u32), dim3(256 + 256 * NE32), lds32, sa, A, tab, out, rep ? s32 : 10, ew);
+        hipEventRecord(a1, sa);
+        hipEventRecord(b0, sb);
+        hipLaunchKernelGGL((kmodel<1, 1, false, 3, 1>), dim3(u16), dim3(512), lds16, sb, A, tab, out2, rep ? s16 : 10, ew);
+        hipEventRecord(b1, sb);
+        hipEventSynchronize(a1); hipEventSynchronize(b1);
+        if (!rep) continue;
+        float ma, mb; hipEventElapsedTime(&ma, a0, a1); hipEventElapsedTime(&mb, b0, b1);
+        best32 = std::min(best32, ma * 1e3 / s32); best16 = std::min(best16, mb * 1e3 / s16);
+    }
+    printf("mixed launch: %3d x 32 chains (4 G + %d E) beside %3d x 16 chains, EW=%3d: %6.2f us per 32-chain unit-step, %6.2f per 16-chain unit-step (alone: see above)\n",
+           u32, 4 * NE32, u16, ew, best32, best16);
+    for (int n32 : {0, 60, 100, 140, 188}) {
+        const int n16 = (6000 - 32 * n32 + 15) / 16;
+        const double per_step = (n32 * best32 + n16 * best16) / 256.0;
+        printf("   6000 chains as %3d x 32 + %3d x 16 units (%3d units), every CU busy: %6.2f us per step in the model = %6.2f at the product's calibration (x %.3f)\n",
+               n32, n16, n32 + n16, per_step, per_step * calib, calib);
+    }
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     size_t units;
     const Table tab = make_table(&units);
@@ -284,5 +323,11 @@ int main(int argc, char** argv) {
         run<1, 1, false, 3, 2>("16 chains, 8 G + 4 E, split in the G waves (round 4's (vi))", 256, ew, A, tab, out);
     }
     run<2, 1, true, 3, 2>("32 chains, 8 G + 4 E, B pre-split", 188, 96 + 18, A, tab, out);
+    // --- round 6: the mixed shard (calibration: the product's 26.9 us per 16-chain unit-step over the model's figure at EW = 96)
+    {
+        const double m16 = run<1, 1, false, 3>("16 chains, 4 G + 4 E (today's form), calibration of the mixed shard", 256, 96, A, tab, out);
+        run_mixed<2>(100, 156, 96, A, tab, out, 26.9 / m16);
+        run_mixed<2>(128, 128, 96, A, tab, out, 26.9 / m16);
+    }
     return 0;
 }
