@@ -86,9 +86,13 @@ typedef struct mcpc_net_desc {
     int64_t spill_budget_bytes;          /* HBM budget for the Hebbian spill ring; 0 = default: room for 384 steps in three parts (17 GB at 6000
                                           * chains of cfg-M's net), at least 6 GiB, at most a quarter of the device's memory */
     const char* tuning;                  /* NULL, or developer overrides of the schedule heuristics as "key=value,key=value"
-                                          * (parsed once by mcpc_create, not kept): ws=0|2 step kernel (0: the barrier kernel, the
+                                          * (parsed once by mcpc_create, not kept): ws=0|2|3 step kernel (0: the barrier kernel, the
                                           * fallback and the independent form parity checks replay the default against; 2: the in-place
-                                          * wave-specialised kernel, the default), no_overlap=1, slot_cap=N, spill_gb=N, ring_parts=N,
+                                          * wave-specialised kernel for every run; 3: the unified-wave kernel for the runs it serves -- fused
+                                          * SGD / Adam updates -- or an error when its LDS plan does not fit; default: in-place, with the
+                                          * unified-wave kernel for small networks and for zero-loss calls), u_row / u_gemm0 / u_kb / u_kbt /
+                                          * u_eh / u_eb / u_ef=N (cost model the unified-wave kernel's rows are dealt by),
+                                          * no_overlap=1, slot_cap=N, spill_gb=N, ring_parts=N,
                                           * flush_tail=N, flush_streams=1|2, cu_slack=N, dw_ksplit=N, ws_prio=0|1|2, stagger=N, no_lean=1,
                                           * no_ybits=1, overlay16=1, heb_fp32=1 (the Hebbian GEMM on the fp32 MFMA instead of its fp16
                                           * form), rr=0 (shards of more 16-chain units than CUs as ONE launch in hardware rounds instead of

@@ -11,21 +11,25 @@
 //   * no block crosses LDS between a GEMM and its epilogue, nothing is published or polled in between;
 //   * the whole read-out error e_o stays in LDS (the plan only exists when it fits: plan_lds_u), so its back-projection is ONE GEMM over
 //     K = n_out inside the x update of the last latent layer, not a ring of chunks with an accumulator carried across entries;
-//   * a step is two LEVELS, not a chain: every forward entry (read-out chunks, FWD_{L-1} .. FWD_0) depends only on the previous step's x
-//     updates, every x update only on this step's forward entries -- a wave runs through a level without waiting for anybody, and
-//     meets the others at most twice per step (and then, by the order of the table, behind entries of slack);
+//   * a step is two LEVELS, not a chain: every forward job (read-out tiles, FWD_{L-1} .. FWD_0) depends only on the previous step's x
+//     updates, every x update only on this step's forward jobs -- two workgroup barriers per step (LDS-scoped fences) and nothing else
+//     synchronises; with a barrier on either side of a level no tile belongs to a wave;
+//   * every wave walks its OWN table (P.phases[w * n_rows + p]): a row is a JOB -- up to four consecutive unit tiles of one entry = one
+//     GEMM call + one epilogue call -- and the host deals a level's jobs to the eight waves by a cost model, longest first, with the grain
+//     of every entry chosen for the shortest makespan (mcpc_api.hip: build_phases_u);
 //   * with a zero loss (reference utils/model.py:31-33 `zero_fn`: unclamped generation, figure_3.py:125-161) the read-out is dead code on
 //     every step whose output is not recorded: e_o = 0, so its back-projection vanishes and `out` is consumed by nothing.  Those steps skip
-//     the read-out entries and the back-projection GEMM -- the arithmetic of everything that IS computed is unchanged (the x update adds
+//     the read-out rows and the back-projection GEMM -- the arithmetic of everything that IS computed is unchanged (the x update adds
 //     the same +0), the recorded outputs are those of the steps they are recorded at.  (A step that spills for the Hebbian sums keeps the
 //     read-out: its zeros are what the flush must see.)
-// Dependencies are progress counters in LDS as in the in-place kernel (bounded spins, device error word), one counter per wave:
-//   prog[w] = table entries completed by wave w (absolute: step * n_entries + index + 1);  an entry waits for "all waves past dep_e".
-// Tile ownership: wave w owns tiles tile0 + w + 8 i of every entry, so the state rows X_l, the error rows E_l a wave's x update reads
-// and the e_1 sums stay with one wave for the whole launch; only GEMM B operands (FX_l, E_l, e_o) cross waves.
+//   * a Bernoulli read-out's error (bounded: a constant fp16 scale) goes to LDS already split into the two fp16 planes its back-projection
+//     reads (mcpc_ws2_lean.h: lean_headf, headf_planes) -- once per value instead of once per k-block, wave and step.
+// What was measured on the way and is NOT here (profiles/r06_small_net.txt): per-entry progress counters instead of the barriers (25.5
+// against 24.4 us per step in the first table form); every level's B operands split once by the whole workgroup between two more barriers
+// (the GEMMs 20 % shorter, the pass and its barrier dearer: 19.5 against 18.8).
 // Arithmetic: the GEMM core (mcpc_gemm_f16.h) and the lean epilogues (mcpc_ws2_lean.h, REG = true) of the in-place kernel, operation for
 // operation -- trajectories are bitwise those of the other kernel forms (tests/test_gpu_unified.py); energies differ in the order their
-// per-wave partial sums are formed (8 waves instead of 4) and agree to rounding.
+// per-wave partial sums are formed (8 waves' shares instead of 4) and agree to rounding.
 // Only the lean paths run here (fused SGD update with or without the Philox kick, Adam without noise; state in LDS): mcpc_run picks this
 // kernel per run and keeps the in-place / barrier kernels for everything else.
 #pragma once
@@ -33,7 +37,7 @@
 namespace mcpc {
 
 constexpr int kUWaves = 8;                      // waves per workgroup, all alike (two per SIMD)
-constexpr int kUNT = 4;                         // unit tiles per wave and table entry: an entry hands out 32 tiles
+constexpr int kUNT = 4;                         // unit tiles per row (job) at most: the four fragment slots and accumulator tiles of a wave
 constexpr int kUThreads = kUWaves * 64;
 
 // request the first fragments of an upcoming row's GEMM (weights need no dependency), into the four slots the GEMM forms expect
