@@ -443,7 +443,7 @@ __device__ __forceinline__ float lean_headf(const KParams& P, const KPhase& ph, 
         for (int ct = 0; ct < CTT; ++ct) {
             if constexpr (XL && YB && YWG) {
                 yv[i][ct] = splat(0.f);
-                yw[i][ct] = ywreg[i];
+                yw[i][ct] = ywreg[i];                 // (i: a compile-time index after unrolling -- the caller's array stays in registers)
             } else if constexpr (XL && YB) {
                 yv[i][ct] = splat(0.f);
                 yw[i][ct] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds + H.lds_yw) + mul24(L.lrow[ct], wrow4) + 4u * (uint32_t)(tile >> 1));
