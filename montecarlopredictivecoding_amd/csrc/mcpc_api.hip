@@ -98,7 +98,6 @@ struct Knobs {
     int u_kb = 200;           // per k-block beyond its tiles' MFMAs and requests (the B split; nothing with the operand in planes)
     int u_kbt = 68;           // per k-block and tile
     int u_eh = 3000, u_eb = 1300, u_ef = 500;      // per tile of an epilogue: read-out / x update / prediction error
-    int u_hb_grain = 0, u_hf_grain = 0;             // > 0: tiles per job of the read-out's back-projection / of the read-out (A/B; 0: the search's choice)
 };
 
 int parse_tuning(const char* str, Knobs& k) {
@@ -120,7 +119,7 @@ int parse_tuning(const char* str, Knobs& k) {
             {"ws", &k.ws}, {"no_overlap", &k.no_overlap},
             {"slot_cap", &k.slot_cap}, {"spill_gb", &k.spill_gb}, {"cu_slack", &k.cu_slack}, {"ring_parts", &k.ring_parts}, {"flush_tail", &k.flush_tail}, {"flush_streams", &k.flush_streams}, {"dw_ksplit", &k.dw_ksplit},
             {"ws_prio", &k.ws_prio}, {"stagger", &k.stagger}, {"no_lean", &k.no_lean}, {"no_ybits", &k.no_ybits}, {"overlay16", &k.overlay16}, {"heb_fp32", &k.heb_fp32}, {"heb171", &k.heb171}, {"rr", &k.rr}, {"rr_qmax", &k.rr_qmax}, {"no_xl", &k.no_xl},
-            {"u_row", &k.u_row}, {"u_gemm0", &k.u_gemm0}, {"u_kb", &k.u_kb}, {"u_kbt", &k.u_kbt}, {"u_eh", &k.u_eh}, {"u_eb", &k.u_eb}, {"u_ef", &k.u_ef}, {"u_hb_grain", &k.u_hb_grain}, {"u_hf_grain", &k.u_hf_grain}};
+            {"u_row", &k.u_row}, {"u_gemm0", &k.u_gemm0}, {"u_kb", &k.u_kb}, {"u_kbt", &k.u_kbt}, {"u_eh", &k.u_eh}, {"u_eb", &k.u_eb}, {"u_ef", &k.u_ef}};
         bool found = false;
         for (auto& t : table)
             if (key == t.name) { *t.dst = val; found = true; }
@@ -145,8 +144,7 @@ struct UPlan {
     int lds_a[kMaxLatent]{}, lds_e[kMaxLatent]{}, lds_eo = 0, lds_red = 0, lds_ws_sync = 0, lds_zero = 0, lds_spillmax = 0, lds_rowexp = 0;
     int lds_x[kMaxLatent]{}, lds_bias[kMaxLatent]{}, lds_hbias = 0, lds_yw = 0, lds_bytes = 0;
     KPhase* phases = nullptr;
-    int n_phases = 0;               // rows of the table: 8 pinned + the forward level's jobs + the updates'
-    int n_fwd = 0;                  // ... of them the forward level's
+    int n_phases = 0;
 };
 
 struct mcpc_engine {
@@ -611,13 +609,13 @@ int plan_lds_u(mcpc_engine* e) {
         for (int l = 0; l < L; ++l) { u.lds_a[l] = off; off += CT * (e->npad[l] + kLdPad); }
         u.lds_e[0] = 0;
         for (int l = 1; l < L; ++l) { u.lds_e[l] = off; off += CT * (e->npad[l] + kLdPad); }
-        u.lds_red = off; off += 2 * (L + 1) * kUSlots;      // per step parity, energy column (layers, loss) and job: its partial sum
-        u.lds_ws_sync = off; off += 4;                      // the levels' job counters, per step parity
+        u.lds_red = off; off += 2 * (kMaxLatent + 1) * kMaxWaves;
+        u.lds_ws_sync = off;                                // (no progress counters in this kernel)
         u.lds_eo = off;
         if (e->has_head) off += CT * (e->out_pad + kLdPad);
         u.lds_zero = off; off += 16;
         u.lds_spillmax = off; off += kSpillTensors;
-        u.lds_rowexp = off; off += (2 * L + 1) * 16;        // this kernel's own ids (build_phases_u): FX_l = l, E_l = L + l, the read-out row = 2 L
+        u.lds_rowexp = off; off += (rowexp_ring(0) + 1) * 16;      // the ids this kernel uses: FX_l, E_l and ONE read-out row word
         for (int l = 0; l < L; ++l) { u.lds_x[l] = off; off += CT * (e->npad[l] + kLdPad); }
         for (int l = 0; l < L; ++l) { u.lds_bias[l] = off; off += l >= 1 ? e->npad[l] : CT * (e->npad[0] + kLdPad); }
         u.lds_yw = -1;
@@ -632,19 +630,18 @@ int plan_lds_u(mcpc_engine* e) {
     return 0;
 }
 
-// Table of the unified-wave kernel.  One step = two levels, each opened by a workgroup barrier:
+// Tables of the unified-wave kernel: every wave walks its OWN rows (u.phases[w * n_phases + p]).  One step = two levels, each opened by a
+// workgroup barrier:
 //   forward:  read-out tiles (HEADF: out, loss error -> e_o), FWD_{L-1} .. FWD_1 (prediction errors E_l), FWD_0 -- they read the FX_l the
 //             previous step's x updates left and write e_o / E_l;
 //   updates:  BWD_{L-1} (GEMM over the whole e_o), BWD_{L-2} .. BWD_0 (GEMM over E_{l+1}) -- they read e_o / E_l and write X_l, FX_l.
 // Inside a level the jobs are independent, and with a barrier on either side no tile belongs to a wave: a JOB is up to four consecutive
-// unit tiles of one entry (one GEMM call + one epilogue call of a wave); the table lists each level's jobs LONGEST FIRST and the waves
-// take them in that order at run time (one LDS atomic per job: mcpc_steps_u.h).  What the host decides is the GRAIN of every entry -- 4,
-// 2 or 1 tiles per job -- by exhaustive search for the shortest makespan of that longest-first deal under a cost model in cycles (fixed
-// cost per row, k-blocks x (operand split + MFMAs per tile), epilogue per tile).  Why four tiles where the work allows: the operand split
-// (24 VALU instructions per k-block) and the row's fixed costs are shared by the job's tiles -- a GEMM of 8 tiles as 2 jobs of 4 splits
-// its B operand twice, as 8 jobs of 1 eight times -- and heavy entries (the read-out's back-projection: K = n_out) are cut finer only as
-// far as the level's balance needs.  (One static assignment: the running sum of e_1 lives in registers of wave w for tile w of the top
-// layer -- lean_load_e0 -- so FWD_0's tiles are PINNED rows of their waves when that layer has at most 8.)
+// unit tiles of one entry (one GEMM call + one epilogue call of a wave), and the jobs of a level are dealt to the eight waves by cost,
+// longest first (a cost model in cycles: fixed cost per row, k-blocks x (operand split + MFMAs per tile), epilogue per tile).  Why four
+// tiles where the work allows: the operand split (24 VALU instructions per k-block) and the row's fixed costs are shared by the job's
+// tiles -- a GEMM of 8 tiles as 2 jobs of 4 splits its B operand twice, as 8 jobs of 1 eight times -- and heavy entries (the read-out's
+// back-projection: K = n_out) are cut finer only as far as the level's balance needs.  (The one exception: the running sum of e_1 lives in
+// registers of wave w for tile w of the top layer -- lean_load_e0 -- so FWD_0's tiles are pinned when that layer has at most 8.)
 int build_phases_u(mcpc_engine* e) {
     UPlan& u = e->u;
     const int L = e->L;
@@ -714,24 +711,15 @@ int build_phases_u(mcpc_engine* e) {
         }
         level[1].push_back({k, tiles(l), (double)kn.u_eb, false, l == L - 1 && e->has_head && e->out_pad > kShortK * kKB});
     }
-    // Row-exponent ids of this kernel's plan (plan_lds_u reserves 2 L + 1 words per chain row): FX_l = l (what the launch's fill writes
-    // under rowexp_fx(l)), E_l = L + l, the read-out error's row = 2 L
-    auto rid = [&](int id) { return id < 0 ? id : (id < kMaxLatent ? id : (id < 2 * kMaxLatent ? L + (id - kMaxLatent) : 2 * L)); };
-    for (int lv = 0; lv < 2; ++lv)
-        for (auto& en : level[lv]) { en.k.b_row = rid(en.k.b_row); en.k.o_row = rid(en.k.o_row); }
-    // The table: rows 0 .. 7 = wave w's pinned row (FWD_0's tile w while the running sum of e_1 lives in that wave's registers; else
-    // PH_NOP), then each level's jobs, LONGEST FIRST -- the waves take them in that order at run time (mcpc_steps_u.h: grab), so the deal
-    // below is only the model by which the grain of every entry (4, 2 or 1 tiles per job) is chosen: exhaustive search for the shortest
-    // longest-first makespan, at most kUSlots jobs per entry (a job's partial energy sum has a slot of its own: bitwise reproducible sums
-    // whatever wave ran it).
-    std::vector<KPhase> pinned(kUPinned), list[2];
-    for (auto& k : pinned) { k = blank(); k.type = PH_NOP; }
+    std::vector<KPhase> rows[kUWaves];
     for (int lv = 0; lv < 2; ++lv) {
+        // the grain of every entry (4, 2 or 1 tiles per job) by exhaustive search: the combination whose longest-first deal has the
+        // shortest makespan (at most 7 entries per level: 3^7 deals of a few dozen jobs)
         const int ne = (int)level[lv].size();
         std::vector<int> grain(ne, 4), best_grain(ne, 4);
         double best_span = 1e300;
         std::vector<Job> jobs;
-        auto deal = [&](const std::vector<int>& gr) {
+        auto deal = [&](const std::vector<int>& gr, std::vector<KPhase>* mine) {
             jobs.clear();
             for (int i = 0; i < ne; ++i) make_jobs(level[lv][i].k, level[lv][i].ntiles, level[lv][i].epi_tile, gr[i], jobs, level[lv][i].pinned, level[lv][i].ps);
             std::stable_sort(jobs.begin(), jobs.end(), [](const Job& a, const Job& b) { return (a.pin >= 0) != (b.pin >= 0) ? a.pin >= 0 : a.cost > b.cost; });
@@ -741,6 +729,7 @@ int build_phases_u(mcpc_engine* e) {
                 if (j.pin >= 0) w = j.pin;
                 else for (int i = 1; i < kUWaves; ++i) if (load[i] < load[w]) w = i;
                 load[w] += j.cost;
+                if (mine) mine[w].push_back(j.k);
             }
             double span = 0, sum = 0;
             for (double v : load) { span = std::max(span, v); sum += v; }
@@ -750,63 +739,55 @@ int build_phases_u(mcpc_engine* e) {
         for (int i = 0; i < ne; ++i) combos *= 3;
         for (int cidx = 0; cidx < combos; ++cidx) {
             int c = cidx;
-            bool ok = true;
-            for (int i = 0; i < ne; ++i) {
-                grain[i] = 4 >> (c % 3); c /= 3;
-                if (!level[lv][i].pinned && (level[lv][i].ntiles + grain[i] - 1) / grain[i] > kUSlots) ok = false;
-                const KPhase& ek = level[lv][i].k;
-                if (kn.u_hb_grain > 0 && ek.type == PH_BWD && ek.a_lin == L && (ek.flags & PHF_WS_GEMM) && grain[i] != kn.u_hb_grain) ok = false;
-                if (kn.u_hf_grain > 0 && ek.type == PH_HEADF && grain[i] != kn.u_hf_grain) ok = false;
-            }
-            if (!ok) continue;
-            const double span = deal(grain);
+            for (int i = 0; i < ne; ++i) { grain[i] = 4 >> (c % 3); c /= 3; }
+            const double span = deal(grain, nullptr);
             if (span < best_span) { best_span = span; best_grain = grain; }
         }
-        if (best_span >= 1e300) { u.on = u.prefer = false; return MCPC_OK; }      // an entry of more than 4 x kUSlots unit tiles: no unified table (the in-place kernel serves every run)
-        (void)deal(best_grain);
-        // energy slots: per entry (= per energy column: a layer's FWD entry, the read-out) its jobs in tile order
-        std::stable_sort(jobs.begin(), jobs.end(), [](const Job& a, const Job& b) { return (a.pin >= 0) != (b.pin >= 0) ? a.pin >= 0 : a.cost > b.cost; });
-        for (auto& j : jobs) {
-            // (tile0 / grain is unique per job of an entry and < kUSlots)
-            int g = 1;
-            for (int i = 0; i < ne; ++i) if (level[lv][i].k.type == j.k.type && level[lv][i].k.layer == j.k.layer) g = level[lv][i].pinned ? 1 : best_grain[i];
-            j.k.eslot = j.k.tile0 / g;
-            if (j.pin >= 0) pinned[j.pin] = j.k; else list[lv].push_back(j.k);
+        std::vector<KPhase> mine[kUWaves];
+        (void)deal(best_grain, mine);
+        for (int w = 0; w < kUWaves; ++w) {
+            if (mine[w].empty()) { KPhase k = blank(); k.type = PH_NOP; mine[w].push_back(k); }
+            mine[w][0].flags |= PHF_SYNC;                        // the level's barrier
+            rows[w].insert(rows[w].end(), mine[w].begin(), mine[w].end());
         }
     }
-    std::vector<KPhase> ph;
-    ph.insert(ph.end(), pinned.begin(), pinned.end());
-    ph.insert(ph.end(), list[0].begin(), list[0].end());
-    ph.insert(ph.end(), list[1].begin(), list[1].end());
     // the four fragment slots a row's GEMM starts from (u_prefetch), resolved here: offsets in 16-byte units from the row's A, -1 = none.
     // (dep_e, dep_g, dep_se, next_g carry them: the unified-wave kernel has no other use for those fields)
-    for (auto& k : ph) {
-        int slot[4] = {-1, -1, -1, -1};
-        const int nt = std::min(k.ntiles, kUNT);
-        if (nt > 0 && (k.flags & PHF_WS_GEMM) && k.nkb > 0)
-            for (int sl = 0; sl < 4; ++sl) {
-                const bool deep = nt <= 2;
-                const int ti = deep ? (nt == 2 ? (sl & 1) : 0) : sl, kb = deep ? (nt == 2 ? (sl >> 1) : sl) : 0;
-                if (ti < nt && kb < k.nkb) slot[sl] = (k.tile0 + k.rot * ti) * k.a_tile_stride + k.a_off0 + kb * kFragBlock;
-            }
-        k.dep_e = slot[0]; k.dep_g = slot[1]; k.dep_se = slot[2]; k.next_g = slot[3];
+    for (int w = 0; w < kUWaves; ++w)
+        for (auto& k : rows[w]) {
+            int slot[4] = {-1, -1, -1, -1};
+            const int nt = std::min(k.ntiles, kUNT);
+            if (nt > 0 && (k.flags & PHF_WS_GEMM) && k.nkb > 0)
+                for (int sl = 0; sl < 4; ++sl) {
+                    const bool deep = nt <= 2;
+                    const int ti = deep ? (nt == 2 ? (sl & 1) : 0) : sl, kb = deep ? (nt == 2 ? (sl >> 1) : sl) : 0;
+                    if (ti < nt && kb < k.nkb) slot[sl] = (k.tile0 + k.rot * ti) * k.a_tile_stride + k.a_off0 + kb * kFragBlock;
+                }
+            k.dep_e = slot[0]; k.dep_g = slot[1]; k.dep_se = slot[2]; k.next_g = slot[3];
+        }
+    size_t R = 0;
+    for (int w = 0; w < kUWaves; ++w) R = std::max(R, rows[w].size());
+    std::vector<KPhase> ph;
+    for (int w = 0; w < kUWaves; ++w) {
+        while (rows[w].size() < R) { KPhase k = blank(); k.type = PH_NOP; rows[w].push_back(k); }
+        ph.insert(ph.end(), rows[w].begin(), rows[w].end());
     }
     int rc = dmalloc(u.phases, ph.size());
     if (rc) return rc;
     if (hipMemcpy(u.phases, ph.data(), ph.size() * sizeof(KPhase), hipMemcpyHostToDevice) != hipSuccess)
         return fail(MCPC_EHIP, "hipMemcpy of the phase table failed");
-    u.n_phases = (int)ph.size();
-    u.n_fwd = (int)list[0].size();
+    u.n_phases = (int)R;
 #ifdef MCPC_STAMPS
     {
         static const char* tn[6] = {"FWD", "HEADF", "HEADB", "BWD", "ENERGY", "NOP"};
-        fprintf(stderr, "[u-table] %d pinned rows, %d forward jobs, %d update jobs (longest first):", kUPinned, u.n_fwd, u.n_phases - kUPinned - u.n_fwd);
-        for (size_t i = 0; i < ph.size(); ++i) {
-            const KPhase& k = ph[i];
-            if ((int)i == kUPinned || (int)i == kUPinned + u.n_fwd) fprintf(stderr, " |");
-            fprintf(stderr, " %s(l%d t%d+%d kb%d e%d)", tn[k.type], k.layer, k.tile0, k.ntiles, (k.flags & PHF_WS_GEMM) ? k.nkb : 0, k.eslot);
+        for (int w = 0; w < kUWaves; ++w) {
+            fprintf(stderr, "[u-table] wave %d:", w);
+            for (size_t i = 0; i < R; ++i) {
+                const KPhase& k = rows[w][i];
+                fprintf(stderr, " %s%s(l%d t%d+%d kb%d)", (k.flags & PHF_SYNC) ? "|" : "", tn[k.type], k.layer, k.tile0, k.ntiles, (k.flags & PHF_WS_GEMM) ? k.nkb : 0);
+            }
+            fprintf(stderr, "\n");
         }
-        fprintf(stderr, "\n");
     }
 #endif
     return 0;
@@ -1098,7 +1079,7 @@ int mcpc_create(const mcpc_net_desc* d, mcpc_engine** out) {
         e->u.prefer = e->u.ok && (kn.ws == 3 || choose_unified(e));
         if (e->u.on && (rc = build_phases_u(e))) return bail(rc);
     }
-    if (kn.ws == 3 && !e->u.on) return bail(fail(MCPC_ENOMEM, "tuning ws=3: the unified-wave kernel does not serve this network (its LDS plan takes %d bytes of 163840; no layer may have more than %d unit tiles)", e->u.lds_bytes, 4 * kUSlots));
+    if (kn.ws == 3 && !e->u.on) return bail(fail(MCPC_ENOMEM, "tuning ws=3: the unified-wave kernel's LDS plan does not fit this network (%d bytes)", e->u.lds_bytes));
     if ((rc = dmalloc(e->err, 1))) return bail(rc);
     if (hipMemset(e->err, 0, sizeof(int)) != hipSuccess) return bail(fail(MCPC_EHIP, "hipMemset failed"));
     if ((rc = dmalloc(e->spillmax, (size_t)kMaxRingParts * kSpillTensors))) return bail(rc);
@@ -1672,7 +1653,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
             K.lds_a = u.lds_a[l]; K.lds_e = u.lds_e[l]; K.lds_x = u.lds_x[l]; K.lds_bias = u.lds_bias[l];
         }
         if (e->has_head) { P.head.lds_eo = u.lds_eo; P.head.ld = e->out_pad + kLdPad; P.head.lds_bias = u.lds_hbias; P.head.lds_yw = u.lds_yw; }
-        P.phases = u.phases; P.n_phases = u.n_phases; P.g_first = u.n_fwd;      // (g_first: the unified-wave kernel's count of forward jobs)
+        P.phases = u.phases; P.n_phases = u.n_phases; P.g_first = 0;
         P.lds_spillmax = u.lds_spillmax; P.lds_rowexp = u.lds_rowexp; P.lds_red = u.lds_red; P.lds_ws_sync = u.lds_ws_sync;
         P.lds_floats = u.lds_bytes / 4; P.lds_zero = u.lds_zero; P.xl = 1;
     }
@@ -1743,7 +1724,7 @@ int mcpc_run(mcpc_engine* e, const mcpc_run_desc* r, void* stream_) {
         // a launch's row-exponent words carry their generation -- the step of the launch, or step x entries + entry for a ring slot -- in 24
         // bits (mcpc_kernels.h: rowexp_track): longer stretches are cut into several launches (a wrapped generation would never
         // supersede the stale word)
-        n = std::min(n, ((1 << 24) - 2) / std::max(e->n_phases, 1));
+        n = std::min(n, ((1 << 24) - 2) / std::max(std::max(e->n_phases, e->u.n_phases), 1));
         int rr_q = 0;
         if (rr_ok && in_acc) {
             rr_q = n / e->rr_m;                               // a Hebbian segment is one cycle (fewer steps than rr_m left: plain launch)

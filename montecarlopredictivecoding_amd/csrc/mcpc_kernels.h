@@ -96,7 +96,6 @@ struct KPhase {
     int next_g;            // in-place variant: the next entry (cyclic) in which the GEMM waves have work -- they visit no other
     int b_row, o_row;      // in-place variant: id of the B operand's / of the produced operand's row-exponent words (KParams::lds_rowexp;
                            // -1: none -- the GEMM wave scans the row itself)
-    int eslot;             // unified-wave kernel: the slot (< kUSlots) of this job's partial energy / loss sum in its column
 };
 
 // Phase descriptors are fetched through the constant address space: wave-uniform s_load_* on the scalar cache.

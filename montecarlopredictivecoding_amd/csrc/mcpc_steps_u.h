@@ -14,10 +14,9 @@
 //   * a step is two LEVELS, not a chain: every forward job (read-out tiles, FWD_{L-1} .. FWD_0) depends only on the previous step's x
 //     updates, every x update only on this step's forward jobs -- two workgroup barriers per step (LDS-scoped fences) and nothing else
 //     synchronises; with a barrier on either side of a level no tile belongs to a wave;
-//   * a row of the table is a JOB -- up to four consecutive unit tiles of one entry = one GEMM call + one epilogue call -- and the waves
-//     take a level's jobs at run time, longest first (one LDS atomic per job), with the grain of every entry chosen by the host for the
-//     shortest makespan under a cost model (mcpc_api.hip: build_phases_u); every job's partial energy sum has a slot of its own, so the
-//     energies are bitwise reproducible whichever wave ran which job;
+//   * every wave walks its OWN table (P.phases[w * n_rows + p]): a row is a JOB -- up to four consecutive unit tiles of one entry = one
+//     GEMM call + one epilogue call -- and the host deals a level's jobs to the eight waves by a cost model, longest first, with the grain
+//     of every entry chosen for the shortest makespan (mcpc_api.hip: build_phases_u);
 //   * with a zero loss (reference utils/model.py:31-33 `zero_fn`: unclamped generation, figure_3.py:125-161) the read-out is dead code on
 //     every step whose output is not recorded: e_o = 0, so its back-projection vanishes and `out` is consumed by nothing.  Those steps skip
 //     the read-out rows and the back-projection GEMM -- the arithmetic of everything that IS computed is unchanged (the x update adds
@@ -27,8 +26,10 @@
 //     reads (mcpc_ws2_lean.h: lean_headf, headf_planes) -- once per value instead of once per k-block, wave and step.
 // What was measured on the way and is NOT here (profiles/r06_small_net.txt): per-entry progress counters instead of the barriers (25.5
 // against 24.4 us per step in the first table form); every level's B operands split once by the whole workgroup between two more barriers
-// (the GEMMs 20 % shorter, the pass and its barrier dearer: 19.5 against 18.8); per-wave tables dealt by the host (level with the run-time
-// deal once their cost model had been calibrated by a grid search on this net: 16.2 against 16.4 -- and dependent on that calibration).
+// (the GEMMs 20 % shorter, the pass and its barrier dearer: 19.5 against 18.8); the jobs of a level taken by the waves at RUN TIME (one
+// LDS atomic per job, longest first, per-job energy slots): level with the host's deal on the reference's net (16.4 against 16.2) and
+// much slower on nets of many short jobs (30-200-72-100: 16.0 against 10.1 us) -- a job's descriptor can then be requested only when the
+// job before it has been taken, and its scalar-load latency lands in front of the short rows.
 // Arithmetic: the GEMM core (mcpc_gemm_f16.h) and the lean epilogues (mcpc_ws2_lean.h, REG = true) of the in-place kernel, operation for
 // operation -- trajectories are bitwise those of the other kernel forms (tests/test_gpu_unified.py); energies differ in the order their
 // per-wave partial sums are formed (8 waves' shares instead of 4) and agree to rounding.
@@ -41,8 +42,6 @@ namespace mcpc {
 constexpr int kUWaves = 8;                      // waves per workgroup, all alike (two per SIMD)
 constexpr int kUNT = 4;                         // unit tiles per row (job) at most: the four fragment slots and accumulator tiles of a wave
 constexpr int kUThreads = kUWaves * 64;
-constexpr int kUSlots = 16;                     // jobs per energy column at most (build_phases_u cuts no entry finer): slots of a step's partial sums
-constexpr int kUPinned = kUWaves;               // rows 0 .. 7 of the table: wave w's pinned row (FWD_0's tile w when its e_1 sum lives in w's registers)
 
 // request the first fragments of an upcoming row's GEMM (weights need no dependency), into the four slots the GEMM forms expect
 // (mcpc_gemm_f16.h: gemm_tiles_u): three or four tiles -- block 0 of every tile; one or two tiles -- the first 4 / nt blocks of each
@@ -72,18 +71,15 @@ __device__ __forceinline__ void u_barrier() {
     MCPC_WS_FENCE(__ATOMIC_ACQUIRE);
 }
 
-// step s (global step t) of this workgroup: the jobs' partial sums -> one fp64 row of the energy partials.  One slot per JOB (not per wave: which
-// wave runs a job is decided at run time), summed in slot order: bitwise reproducible whatever the waves' race for the jobs was.
-// Columns of `red`: layer l -> l, the loss -> L.
+// step s (global step t) of this workgroup: the eight waves' partial sums -> one fp64 row of the energy partials (fixed order)
 __device__ __forceinline__ void u_energy_row(const KParams& P, const float* lds, int s, int t, int unit, int lane, int L, bool has_head) {
-    const float* const red = lds + P.lds_red + (s & 1) * (L + 1) * kUSlots;
+    const float* const red = lds + P.lds_red + (s & 1) * (kMaxLatent + 1) * kMaxWaves;
     if (lane <= kMaxLatent) {
         double v = 0.0;
         const bool used = (lane < L) || (lane == kMaxLatent && has_head);
         if (used) {
-            const float* const col = red + (lane < L ? lane : L) * kUSlots;
 #pragma unroll
-            for (int j = 0; j < kUSlots; ++j) v += (double)col[j];
+            for (int ww = 0; ww < kUWaves; ++ww) v += (double)red[lane * kMaxWaves + ww];
         }
         const int erow = (P.energy_mode == MCPC_ENERGY_ALL) ? t : 0;
         P.epart[((size_t)erow * P.epart_slots + (size_t)unit) * (kMaxLatent + 1) + lane] = v;
@@ -95,7 +91,7 @@ __device__ __forceinline__ void u_energy_row(const KParams& P, const float* lds,
 template <bool MIX, bool PLAIN>
 __device__ __forceinline__ void u_epilogue(const KParams& P, const KPhase& ph, float* lds, int nt, const LeanLane<1>& LL, int slot, int rec_idx,
                                            bool do_energy, int t, int s_tab, float* rx, unsigned row_gen, const f32x4 (&acc)[kUNT][1],
-                                           f32x4 (&e0acc)[1], bool e0_in_regs, bool& e0_dirty, float* red, bool ybin, bool hplanes, bool lean_adam,
+                                           f32x4 (&e0acc)[1], bool e0_in_regs, bool& e0_dirty, float& en_acc, bool ybin, bool hplanes, bool lean_adam,
                                            int upd_mode, int lane, bool yw_glob, const uint32_t (&ywreg)[kUNT]) {
     constexpr int CTT = 1, NW = kUWaves, NTW = kUNT;
     int dead = 0;
@@ -106,13 +102,13 @@ __device__ __forceinline__ void u_epilogue(const KParams& P, const KPhase& ph, f
         if (act == MCPC_ACT_RELU) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_RELU, true, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, nullptr, 0, P.err, dead, e0acc, e0_in_regs, rx, row_gen, acc);
         else if (act == MCPC_ACT_TANH) esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_TANH, true, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, nullptr, 0, P.err, dead, e0acc, e0_in_regs, rx, row_gen, acc);
         else esum = lean_fwd<CTT, NW, NTW, MCPC_ACT_IDENTITY, true, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, nullptr, 0, P.err, dead, e0acc, e0_in_regs, rx, row_gen, acc);
-        if (do_energy) { esum = wave_sum(esum); if (lane == 0) red[ph.layer * kUSlots + ph.eslot] = esum; }       // this job's share of E_l
+        if (do_energy) { esum = wave_sum(esum); if (lane == ph.layer) en_acc += esum; }
     } else if (ph.type == PH_HEADF) {
         float lsum;
         if (ybin && yw_glob) lsum = lean_headf<CTT, NW, NTW, true, true, true, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, do_energy, nullptr, 0, P.err, dead, true, rx, acc, row_gen, hplanes, ywreg);
         else if (ybin) lsum = lean_headf<CTT, NW, NTW, true, true, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, do_energy, nullptr, 0, P.err, dead, true, rx, acc, row_gen, hplanes);
         else lsum = lean_headf<CTT, NW, NTW, true, false, true>(P, ph, lds, nt, 0, LL, slot, rec_idx, do_energy, nullptr, 0, P.err, dead, false, rx, acc, row_gen, hplanes);
-        if (do_energy) { lsum = wave_sum(lsum); if (lane == 0) red[P.L * kUSlots + ph.eslot] = lsum; }            // ... of the loss
+        if (do_energy) { lsum = wave_sum(lsum); if (lane == kMaxLatent) en_acc += lsum; }
     } else if (ph.type == PH_BWD) {
         if (lean_adam) {
             if (act == MCPC_ACT_RELU) lean_bwd<CTT, NW, NTW, MCPC_ACT_RELU, false, true, true, true>(P, ph, lds, nt, 0, LL, t, nullptr, 0, P.err, dead, s_tab, rx, row_gen, acc);
@@ -182,50 +178,19 @@ __global__ __launch_bounds__(kUThreads, 2) void mcpc_steps_u_kernel(const KParam
     // the exponents the packed weights were scaled by (one per Linear), once: lane j of a VGPR holds Linear j's -- a v_readlane per GEMM
     // where a scalar load from device memory sat in front of every GEMM's first block (its latency exposed: the exponent is needed at once)
     const int wexp_v = lane <= kMaxLatent ? P.wexp[lane] : 0;
-    // The rows of a level are JOBS any wave may run: a wave takes the next one of the level's list -- longest first, the host's order -- with
-    // one LDS atomic, while it still works on the one before (the descriptor and the first fragments of a row travel during the previous
-    // row, as ever; the first row of a level is taken before the level's barrier: weights need no dependency).  Table (mcpc_api.hip:
-    // build_phases_u): rows 0 .. 7 = wave w's pinned row (or PH_NOP), then the forward level's jobs, then the updates'.  Counters: one per
-    // level and step parity; the other parity's is cleared by wave 0 behind a barrier that lies between its last and its next use.
-    const int nF = P.g_first, nB = n_ent - kUPinned - nF;
-    int* const ctr = reinterpret_cast<int*>(lds + P.lds_ws_sync);          // [2 level + parity]
-    const KPhase* const tab = P.phases;
-    auto grab = [&](int level, int s_) -> int {
-        int j = 0;
-        if (lane == 0) j = __hip_atomic_fetch_add(&ctr[2 * level + (s_ & 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        j = __builtin_amdgcn_readfirstlane(j);
-        return j < (level ? nB : nF) ? kUPinned + (level ? nF : 0) + j : -1;
-    };
-    auto nop_row = []() { KPhase k{}; k.type = PH_NOP; k.dep_e = k.dep_g = k.dep_se = k.next_g = -1; k.rot = 1; return k; };
-    const KPhase pinned = load_phase(tab, w);
-    const bool has_pinned = pinned.type != PH_NOP;
-    KPhase ph_next = pinned;
-    if (!has_pinned) { const int i0 = grab(0, 0); ph_next = nop_row(); if (i0 >= 0) ph_next = load_phase(tab, i0); }
+    // loop-carried: the descriptor of the upcoming row and the first fragments of its GEMM (one prefetch site, as in the in-place
+    // kernel's GEMM waves: mcpc_steps_ws2_body.inc).  Every wave walks its OWN rows: P.phases[w * n_ent .. + n_ent).
+    const KPhase* const tab = P.phases + (size_t)w * n_ent;
+    KPhase ph_next = load_phase(tab, 0);
     int nt_next, aoff[NTW];
     frag_t pre0[NTW];
 #pragma unroll
     for (int i = 0; i < NTW; ++i) { pre0[i] = frag_zero(); aoff[i] = 0; }
     u_prefetch(ph_next, lane, P.dummy, nt_next, aoff, pre0);
 
+    bool energy_prev = false;                  // the step before this one left partial energy sums in LDS
     STAMP_DECL
-    int s = 0, level = 0;
-    bool sync_now = true, more = P.n_steps > 0;
-#pragma unroll 1
-    while (more) {
-        KPhase ph = ph_next;
-        const int nt = nt_next;
-        // ---- the row after this one
-        int s_n = s, level_n = level;
-        bool sync_n = false;
-        int idx = ph.type == PH_NOP ? -1 : grab(level, s);               // (a wave on a level's NOP row has seen that list run out already)
-        if (idx < 0) {
-            sync_n = true;
-            if (level == 0) level_n = 1; else { level_n = 0; s_n = s + 1; }
-            more = s_n < P.n_steps;
-            if (more) idx = (level_n == 0 && has_pinned) ? w : grab(level_n, s_n);
-        }
-        if (more) { ph_next = nop_row(); if (idx >= 0) ph_next = load_phase(tab, idx); }
-        // ---- this row's step
+    for (int s = 0; s < P.n_steps; ++s) {
         const int t = t_first + s;
         const int s_tab = MIX ? t - P.t0 : s;
         const bool do_energy = (P.energy_mode == MCPC_ENERGY_ALL) || (P.energy_mode == MCPC_ENERGY_LAST && t == P.T - 1);
@@ -238,76 +203,79 @@ __global__ __launch_bounds__(kUThreads, 2) void mcpc_steps_u_kernel(const KParam
         // zero loss: the read-out is computed on the steps that record it (or spill it), nowhere else -- see the header
         const bool skip_head = no_loss && slot < 0 && (rec_idx < 0 || P.head.rec_out == nullptr);
         const bool plain = slot < 0 && rec_idx < 0 && !do_energy;
-        float* const red = lds + P.lds_red + (s & 1) * (L + 1) * kUSlots;
+        float* const red = lds + P.lds_red + (s & 1) * (kMaxLatent + 1) * kMaxWaves;
+        float en_acc = 0.f;
         const unsigned row_gen = (unsigned)(s + 1);
-        f32x4 acc[NTW][CTT];
+#pragma unroll 1
+        for (int p = 0; p < n_ent; ++p) {
+            KPhase ph = ph_next;
+            const int nt = nt_next;
+            const int pn = p + 1 < n_ent ? p + 1 : 0;
+            if (pn != 0 || s + 1 < P.n_steps) ph_next = load_phase(tab, pn);
+            f32x4 acc[NTW][CTT];
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) acc[i][0] = splat(0.f);
-        STAMP(0);
-        // level boundary: what this level reads is complete, what it writes is no longer read
-        if (sync_now) {
-            u_barrier();
-            STAMP(1);
-            if (w == 0) {
-                if (level == 0) {
-                    // the previous step's energies: every job's partial sum is in LDS now (the other half of `red`)
-                    const bool e_prev = s > 0 && ((P.energy_mode == MCPC_ENERGY_ALL) || (P.energy_mode == MCPC_ENERGY_LAST && t - 1 == P.T - 1));
-                    if (e_prev) u_energy_row(P, lds, s - 1, t - 1, unit, lane, L, has_head);
+            for (int i = 0; i < NTW; ++i) acc[i][0] = splat(0.f);
+            STAMP(0);
+            // level boundary: what this level reads is complete, what it writes is no longer read
+            if (ph.flags & PHF_SYNC) {
+                u_barrier();
+                STAMP(1);
+                // the previous step's energies: every wave's partial sums are in LDS now (the other half of `red`)
+                if (p == 0 && s > 0 && w == 0 && energy_prev) u_energy_row(P, lds, s - 1, t - 1, unit, lane, L, has_head);
+            }
+            // rows this step does not need (zero loss: read-out chunks; the read-out's back-projection)
+            const bool head_gemm = ph.type == PH_BWD && ph.a_lin == L && (ph.flags & PHF_WS_GEMM);
+            if (head_gemm && no_loss) ph.flags &= ~PHF_WS_GEMM;
+            const bool live = nt > 0 && !(ph.type == PH_HEADF && skip_head);
+            uint32_t ywreg[NTW] = {0u, 0u, 0u, 0u};
+            if (yw_glob && ph.type == PH_HEADF) {
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) {
+                    const int tile = ph.tile0 + ph.rot * (i < nt ? i : 0);
+                    ywreg[i] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(
+                        (gbytes_t)P.head.ybits + mul24(LL.chain[0], 4u * (uint32_t)P.head.ywords) + 4u * (uint32_t)(tile >> 1));
                 }
-                if (lane == 0) ctr[2 * level + ((s + 1) & 1)] = 0;       // the NEXT step's counter of this level (last used a step ago)
             }
-        }
-        // rows this step does not need (zero loss: read-out rows; the read-out's back-projection)
-        const bool head_gemm = ph.type == PH_BWD && ph.a_lin == L && (ph.flags & PHF_WS_GEMM);
-        if (head_gemm && no_loss) ph.flags &= ~PHF_WS_GEMM;
-        const bool live = nt > 0 && ph.type != PH_NOP && !(ph.type == PH_HEADF && skip_head);
-        uint32_t ywreg[NTW] = {0u, 0u, 0u, 0u};
-        if (yw_glob && ph.type == PH_HEADF) {
-#pragma unroll
-            for (int i = 0; i < NTW; ++i) {
-                const int tile = ph.tile0 + ph.rot * (i < nt ? i : 0);
-                ywreg[i] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(
-                    (gbytes_t)P.head.ybits + mul24(LL.chain[0], 4u * (uint32_t)P.head.ywords) + 4u * (uint32_t)(tile >> 1));
+            if (live && (ph.flags & PHF_WS_GEMM) && ph.nkb > 0) {
+                int fixed_b;
+                int short_k = -1;
+                if (head_gemm) {
+                    const int hb_exp = headb_fixed_exp(P.head.loss_kind, y_bounded);
+                    fixed_b = hb_exp == kScaleAuto ? rowexp_read(rx, ph.b_row, c) : hb_exp;
+                    short_k = P.head.npad <= kShortK * kKB ? 1 : 0;
+                } else {
+                    fixed_b = rowexp_read(rx, ph.b_row, c);
+                }
+                gemm_tiles_u<NTW>(acc, ph.A, aoff, nt, ph.nkb, ph.kw, lds + ph.b_lds, ph.ldb, lane, pre0, lds + P.lds_zero,
+                                  __builtin_amdgcn_readlane(wexp_v, ph.a_lin), fixed_b, short_k, head_gemm && hplanes);
             }
-        }
-        if (live && (ph.flags & PHF_WS_GEMM) && ph.nkb > 0) {
-            int fixed_b;
-            int short_k = -1;
-            if (head_gemm) {
-                const int hb_exp = headb_fixed_exp(P.head.loss_kind, y_bounded);
-                fixed_b = hb_exp == kScaleAuto ? rowexp_read(rx, ph.b_row, c) : hb_exp;
-                short_k = P.head.npad <= kShortK * kKB ? 1 : 0;
-            } else {
-                fixed_b = rowexp_read(rx, ph.b_row, c);
-            }
-            gemm_tiles_u<NTW>(acc, ph.A, aoff, nt, ph.nkb, ph.kw, lds + ph.b_lds, ph.ldb, lane, pre0, lds + P.lds_zero,
-                              __builtin_amdgcn_readlane(wexp_v, ph.a_lin), fixed_b, short_k, head_gemm && hplanes);
-        }
 #ifdef MCPC_STAMPS        // GEMM time by row kind: slots 8..11 forward rows of 1..4 tiles, 12..15 update rows of 1..4 tiles
-        {
-            const unsigned long long now_ = mcpc_stamp(), d_ = now_ - st_last;
-            st_last = now_;
-            switch ((ph.type == PH_BWD ? 4 : 0) + (nt > 0 ? nt - 1 : 0)) {
-                case 0: st_sum[8] += d_; break; case 1: st_sum[9] += d_; break; case 2: st_sum[10] += d_; break; case 3: st_sum[11] += d_; break;
-                case 4: st_sum[12] += d_; break; case 5: st_sum[13] += d_; break; case 6: st_sum[14] += d_; break; default: st_sum[15] += d_; break;
+            {
+                const unsigned long long now_ = mcpc_stamp(), d_ = now_ - st_last;
+                st_last = now_;
+                switch ((ph.type == PH_BWD ? 4 : 0) + (nt > 0 ? nt - 1 : 0)) {
+                    case 0: st_sum[8] += d_; break; case 1: st_sum[9] += d_; break; case 2: st_sum[10] += d_; break; case 3: st_sum[11] += d_; break;
+                    case 4: st_sum[12] += d_; break; case 5: st_sum[13] += d_; break; case 6: st_sum[14] += d_; break; default: st_sum[15] += d_; break;
+                }
+            }
+#endif
+            // fragments of the next row travel while this one's epilogue runs
+            u_prefetch(ph_next, lane, P.dummy, nt_next, aoff, pre0);
+            STAMP(3);
+            if (live) {
+                // (ordinary steps -- nothing spilled, nothing recorded, no energies -- run instantiations in which all of that is compiled out)
+                if (plain) u_epilogue<MIX, true>(P, ph, lds, nt, LL, -1, -1, false, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, en_acc, ybin, hplanes, lean_adam, upd_mode, lane, yw_glob, ywreg);
+                else u_epilogue<MIX, false>(P, ph, lds, nt, LL, slot, rec_idx, do_energy, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, en_acc, ybin, hplanes, lean_adam, upd_mode, lane, yw_glob, ywreg);
+                STAMP(4);
             }
         }
-#endif
-        // fragments of the next row travel while this one's epilogue runs
-        if (more) u_prefetch(ph_next, lane, P.dummy, nt_next, aoff, pre0);
-        STAMP(3);
-        if (live) {
-            // (ordinary steps -- nothing spilled, nothing recorded, no energies -- run instantiations in which all of that is compiled out)
-            if (plain) u_epilogue<MIX, true>(P, ph, lds, nt, LL, -1, -1, false, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, red, ybin, hplanes, lean_adam, upd_mode, lane, yw_glob, ywreg);
-            else u_epilogue<MIX, false>(P, ph, lds, nt, LL, slot, rec_idx, do_energy, t, s_tab, rx, row_gen, acc, e0acc, e0_in_regs, e0_dirty, red, ybin, hplanes, lean_adam, upd_mode, lane, yw_glob, ywreg);
-            STAMP(4);
-        }
-        s = s_n; level = level_n; sync_now = sync_n;
+        // this wave's share of the step's energies (lane l: layer l, lane kMaxLatent: the loss)
+        if (do_energy && lane <= kMaxLatent) red[lane * kMaxWaves + w] = en_acc;
+        energy_prev = do_energy;
     }
-    const bool energy_last = (P.energy_mode == MCPC_ENERGY_ALL) || (P.energy_mode == MCPC_ENERGY_LAST && t_first + P.n_steps - 1 == P.T - 1);
     // every wave's last x update is in LDS (and its partial energy sums)
     u_barrier();
-    if (energy_last && w == 0) u_energy_row(P, lds, P.n_steps - 1, t_first + P.n_steps - 1, unit, lane, L, has_head);
+    if (energy_prev && w == 0) u_energy_row(P, lds, P.n_steps - 1, t_first + P.n_steps - 1, unit, lane, L, has_head);
     lean_store_x<CTT, NW>(P, lds, w, LL);                       // the state of this wave's tiles goes back to global memory
     spill_max_publish(P.spillmax, lds + P.lds_spillmax, lane);
     if (clk_wave && lane == 0) {
