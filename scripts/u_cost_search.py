@@ -15,9 +15,10 @@ from montecarlopredictivecoding_amd.engine import Engine  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 dev = torch.device("cuda", 0)
-sizes, n_out, B = [20, 128, 128], 784, 256
+sizes = [int(v) for v in os.environ.get("U_SIZES", "20,128,128").split(",")]
+n_out, B = int(os.environ.get("U_NOUT", "784")), int(os.environ.get("U_B", "256"))
 g = torch.Generator().manual_seed(1)
-dims = [20] + sizes + [n_out]
+dims = [sizes[0]] + sizes + [n_out]
 W = [((torch.rand(dims[j + 1], dims[j], generator=g) * 2 - 1) / dims[j] ** 0.5).to(dev) for j in range(4)]
 b = [((torch.rand(dims[j + 1], generator=g) * 2 - 1) / dims[j] ** 0.5).to(dev) for j in range(4)]
 y = (torch.rand(B, n_out, generator=g) < 0.13).float().to(dev)
@@ -25,7 +26,7 @@ xs = [((torch.rand(B, n, generator=g) * 2 - 1)).to(dev) for n in sizes]
 
 
 def measure(tuning):
-    eng = Engine(sizes, [L.ACT_RELU] * 3, 20, n_out, B, device=dev, tuning=tuning)
+    eng = Engine(sizes, [L.ACT_RELU] * len(sizes), sizes[0], n_out, B, device=dev, tuning=tuning)
     eng.bind_params(W, b); eng.bind_inputs(None); eng.bind_target(y)
     out = []
     for kw in (dict(noise_mode=L.NOISE_PHILOX, lr=0.03), dict(noise_mode=L.NOISE_NONE, xopt=L.XOPT_ADAM, lr=0.1),
