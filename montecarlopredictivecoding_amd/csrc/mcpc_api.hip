@@ -796,7 +796,9 @@ int build_phases_u(mcpc_engine* e) {
 // The automatic choice between the in-place and the unified-wave kernel for an engine whose unified plan fits (tuning ws=2 / ws=3 force
 // either).  Measured on one MI355X (profiles/r06_small_net.txt, us per 16-chain unit-step, MCPC / MAP / learning call):
 //   20-128-128-784 (476 tile-blocks of GEMM per step)   in-place 21.3 / 23.1 / 23.9    unified 16.8 / 18.0 / 19.3
-//   30-256-256-784 (1 080 tile-blocks: cfg-M)            in-place 26.4 / 30.0 / 29.4    unified 29.3 / 31.0 / 32.4
+//   30-200-200-784 (877)                                  in-place 25.3                  unified 23.2            (MCPC)
+//   30-224-224-784 (917)                                  in-place 25.5                  unified 26.8
+//   30-256-256-784 (1 080 tile-blocks: cfg-M)            in-place 26.4 / 30.0 / 29.4    unified 27.9-29.3 / 31.0 / 32.4
 // A step's fixed costs per table entry are what the unified form removes; the overlap of GEMM and epilogue waves is what it gives up, and
 // at cfg-M's width that overlap is worth more.  The unit is what both scale with: (unit tile, 32-deep k-block) pairs of all GEMMs of a step.
 // A ZERO-LOSS call (unclamped generation) runs on the unified kernel whatever the width: only that kernel skips the read-out on the steps
@@ -807,7 +809,7 @@ int gemm_tile_blocks(const mcpc_engine* e) {
     if (e->has_head) n += (e->out_pad / 16) * kblocks(e->npad[e->L - 1]) + (e->npad[e->L - 1] / 16) * kblocks(e->out_pad);
     return n;
 }
-bool choose_unified(const mcpc_engine* e) { return gemm_tile_blocks(e) <= 800; }
+bool choose_unified(const mcpc_engine* e) { return gemm_tile_blocks(e) <= 900; }
 
 // The per-step schedule: every GEMM of a Langevin step with its operands, the epilogue that follows
 // it and the barrier it needs.  Output tiles are handed out 16 at a time (4 waves x kNT tiles).
